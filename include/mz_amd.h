@@ -1,0 +1,152 @@
+/* include/mz_amd.h -- C ABI of libmzamd.so: the MI355X (gfx950) implementation of the multiz
+ * block-pair merge DP.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * What each group of entry points replaces in the reference (multiz/multiz @ /root/reference):
+ *
+ *   mz_yama_batch()            N independent calls of   yama()        mz_yama.h:22 / mz_yama.c:50-320
+ *   mz_dev_plan/dp/walk/emit   the phases of yama():    validity      mz_yama.c:58-71
+ *                                                       DP            mz_yama.c:83-255
+ *                                                       traceback     mz_yama.c:257-291
+ *                                                       emit          mz_yama.c:293-313
+ *   mz_set_scores()            init_scores70()/85()     mz_scores.c:94-122 (tables :34-81)
+ *
+ * The reference-signature drop-ins themselves -- yama(), pre_yama(), smooth(), mafBuild(),
+ * rmColDash(), mapping(), init_scores70(), init_scores85(), mafScoreRange() -- are declared in
+ * the sibling headers mz_yama.h, mz_preyama.h, mz_scores.h with the reference's own prototypes;
+ * they are thin C wrappers over the batch entry points below (a batch of one).
+ *
+ * A "batch" is a set of independent block pairs.  Device-side data layout (all in HBM):
+ *
+ *   poolA  : for pair p, M*K bytes at offA[p]; column r (1..M) = K contiguous bytes at
+ *            offA[p] + (r-1)*K  -- the reference's own column-major packing
+ *            (mz_preyama.c:203-214) minus the 1-based pointer array.
+ *   poolB  : same for the L x N block (mz_preyama.c:174-180).
+ *   poolLB/poolRB : int32, M+1 entries per pair at offBand[p]  (LB[]/RB[] of mz_yama.h:10-13).
+ *   tbw    : traceback workspace: one byte per (anti-diagonal step, lane), four steps per
+ *            dword, so every store is one coalesced 256-byte row per wave.
+ *   script : edit script per pair, reverse order, one byte per output column.
+ *   out    : merged blocks; pair p's OM columns of K+L bytes at offOut[p] (*OAL of yama()).
+ */
+#ifndef MZ_AMD_H
+#define MZ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_NEG      (-1073741824)          /* reference mz_yama.c:29, INT_MIN/2 */
+#define MZ_BIG      (0x3fffffff)
+#define MZ_FC 0                            /* reference mz_yama.c:24-26 */
+#define MZ_FI 1
+#define MZ_FD 2
+
+/* per-pair status: 0 ok, 1..4 = the reference fatal() the input would hit (mz_yama.c:58-71),
+ * 5/6 traceback/emit invariants (mz_yama.c:274-276,290,308-312), >=16 = limits of this build */
+enum {
+    MZ_OK = 0,
+    MZ_E_TERMINATION = 1,
+    MZ_E_NARROW = 2,
+    MZ_E_LB_MONO = 3,
+    MZ_E_RB_MONO = 4,
+    MZ_E_TRACEBACK = 5,
+    MZ_E_EMIT = 6,
+    MZ_E_ROWS = 16,        /* K or L outside 1..127 (profile counters are int8 dot-product operands) */
+    MZ_E_SHAPE = 17,       /* M < 1 or N < 1 */
+    MZ_E_RANGE = 18,       /* K*L*(open+extend)*(M+N) >= 2^30: the reference's own int32 would overflow */
+    MZ_E_WORKSPACE = 19    /* workspace too small for this batch (caller must re-plan) */
+};
+
+enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1 };
+
+typedef struct mz_dev_batch {
+    int32_t n;
+    int32_t pad_;
+    /* inputs (device pointers) */
+    const int32_t *K, *L, *M, *N;
+    const int64_t *offA, *offB, *offBand;
+    const uint8_t *poolA, *poolB;
+    const int32_t *poolLB, *poolRB;
+    /* plan outputs (device, n entries each) */
+    int32_t *status;       /* MZ_OK or error                      */
+    int32_t *badrow;       /* row index for the error message     */
+    int32_t *mode;         /* MZ_MODE_*                           */
+    int64_t *cells;        /* tback_size, reference mz_yama.c:60-66 */
+    int64_t *szTb, *szScript, *szOut;      /* per-pair sizes (dwords, bytes, bytes) */
+    int64_t *offTb, *offScript, *offOut;   /* exclusive prefix sums of the above    */
+    int64_t *totals;       /* [0..2] totals of the three, [3] = number of failed pairs */
+    /* workspaces + results (device) */
+    uint32_t *tbw;
+    uint8_t  *script;
+    uint8_t  *out;
+    int64_t capTb, capScript, capOut;      /* capacities in the same units as the sizes */
+    int32_t *om;           /* OM per pair                          */
+    int32_t *final3;       /* C,D,I at (M,N), 3 per pair           */
+} mz_dev_batch;
+
+typedef struct mz_score_model {
+    int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */
+    int32_t gap_open;      /* the single non-zero value of gop[] (mz_scores.c:78-79)              */
+    int32_t gap_extend;
+} mz_score_model;
+
+
+/* ---------------------------------------------------------------- library life cycle */
+
+/* Select the GPU, create the stream, upload the HOXD70 tables.  Returns 0, or -1 with
+ * mz_last_error() set.  There is NO CPU fallback: without a usable HIP device every entry
+ * point fails. */
+int  mz_init(int device);
+void mz_finalize(void);
+const char *mz_last_error(void);
+/* the hipStream_t the library launches on (for callers that time with HIP events) */
+void *mz_stream(void);
+
+/* Score tables as the reference holds them (int ss[128][128] flattened row-major, int gop[16],
+ * gap_extend).  Fails (-1) unless ss is constant on the six byte classes and gop has the
+ * quasi-natural structure -- true of both reference tables. */
+int  mz_set_scores(const int *ss_flat, const int *gop16, int gap_extend);
+
+/* ---------------------------------------------------------------- host-buffer batch API */
+
+typedef struct mz_job {
+    int K, L, M, N;
+    const unsigned char *A;   /* M columns of K bytes, contiguous, column r at A + (r-1)*K */
+    const unsigned char *B;   /* N columns of L bytes                                      */
+    const int *LB, *RB;       /* int[M+1]                                                  */
+} mz_job;
+
+typedef struct mz_out {
+    int status;               /* MZ_OK or MZ_E_*                                           */
+    int badrow;               /* row named by the reference's message for status 2         */
+    int OM;                   /* number of merged columns                                  */
+    int score[3];             /* C, D, I at grid point (M, N)                              */
+    unsigned char *cols;      /* malloc()ed, OM*(K+L) bytes, caller frees; NULL on error   */
+} mz_out;
+
+/* Align n independent block pairs on the GPU.  Returns the number of failed pairs, or -1 on
+ * a device error. */
+int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
+
+/* ---------------------------------------------------------------- device-resident API */
+
+/* bytes of device memory needed for the per-pair plan/result arrays of an n-pair batch, and a
+ * helper that carves them out of one allocation (256-byte aligned slices) */
+size_t mz_dev_plan_bytes(int n);
+void   mz_dev_carve(mz_dev_batch *b, void *plan_mem);
+
+/* phases; all asynchronous on `stream` (hipStream_t; NULL = the library's stream) */
+int mz_dev_plan(const mz_dev_batch *b, void *stream);   /* validity + sizes + offsets        */
+int mz_dev_dp(const mz_dev_batch *b, void *stream);     /* DP + traceback bytes             */
+int mz_dev_walk(const mz_dev_batch *b, void *stream);   /* traceback -> edit script, OM     */
+int mz_dev_emit(const mz_dev_batch *b, void *stream);   /* merged columns                   */
+/* all four back to back.  If ms != NULL it receives the HIP-event time of {plan, dp, walk,
+ * emit} in milliseconds (forces a stream synchronize). */
+int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+"""ctypes binding of libmzamd.so (include/mz_amd.h).  No fallback of any kind: if the library
+is missing or no HIP device is usable, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmzamd.so")
+CSRC = os.path.join(HERE, "csrc")
+
+MZ_STATUS = {0: "ok", 1: "termination", 2: "narrow", 3: "lb_mono", 4: "rb_mono", 5: "traceback", 6: "emit",
+             16: "rows", 17: "shape", 18: "range", 19: "workspace"}
+
+
+def build(force: bool = False) -> str:
+    """compile libmzamd.so for gfx950 in-tree (hipcc + gcc via multiz_amd/csrc/Makefile)"""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class Job(C.Structure):
+    _fields_ = [("K", C.c_int), ("L", C.c_int), ("M", C.c_int), ("N", C.c_int),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("LB", C.c_void_p), ("RB", C.c_void_p)]
+
+
+class Out(C.Structure):
+    _fields_ = [("status", C.c_int), ("badrow", C.c_int), ("OM", C.c_int), ("score", C.c_int * 3),
+                ("cols", C.c_void_p)]
+
+
+class DevBatchC(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pad_", C.c_int32)] + \
+        [(k, C.c_void_p) for k in ("K", "L", "M", "N", "offA", "offB", "offBand", "poolA", "poolB", "poolLB", "poolRB",
+                                   "status", "badrow", "mode", "cells", "szTb", "szScript", "szOut",
+                                   "offTb", "offScript", "offOut", "totals", "tbw", "script", "out")] + \
+        [("capTb", C.c_int64), ("capScript", C.c_int64), ("capOut", C.c_int64), ("om", C.c_void_p), ("final3", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (there is no fallback path)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mz_last_error.restype = C.c_char_p
+        _lib.mz_init.argtypes = [C.c_int]
+        _lib.mz_stream.restype = C.c_void_p
+        _lib.mz_yama_batch.argtypes = [C.c_int, C.POINTER(Job), C.POINTER(Out)]
+        _lib.mz_set_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.mz_dev_plan_bytes.restype = C.c_size_t
+        _lib.mz_dev_plan_bytes.argtypes = [C.c_int]
+        _lib.mz_dev_carve.argtypes = [C.POINTER(DevBatchC), C.c_void_p]
+        for f in ("mz_dev_plan", "mz_dev_dp", "mz_dev_walk", "mz_dev_emit"):
+            getattr(_lib, f).argtypes = [C.POINTER(DevBatchC), C.c_void_p]
+        _lib.mz_dev_run.argtypes = [C.POINTER(DevBatchC), C.c_void_p, C.POINTER(C.c_float)]
+        _lib.free_cols = C.CDLL(None).free
+        _lib.free_cols.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc < 0:
+        raise RuntimeError(f"{what}: {lib().mz_last_error().decode()}")
+
+
+def init(device: int = 0):
+    _check(lib().mz_init(device), "mz_init")
+
+
+def set_scores_hoxd70():
+    lib().init_scores70()
+
+
+def set_scores_hoxd85():
+    lib().init_scores85()
+
+
+class Result:
+    __slots__ = ("status", "badrow", "OM", "score", "cols")
+
+    def __init__(self, status, badrow, OM, score, cols):
+        self.status, self.badrow, self.OM, self.score, self.cols = status, badrow, OM, score, cols
+
+
+def yama_batch(pairs: Sequence[tuple]) -> List[Result]:
+    """pairs: sequence of (A (M,K) uint8, B (N,L) uint8, LB int32[M+1], RB int32[M+1]).
+    Runs them as one GPU batch through the C ABI (mz_yama_batch)."""
+    n = len(pairs)
+    jobs = (Job * n)()
+    outs = (Out * n)()
+    keep = []
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        A = np.ascontiguousarray(A, dtype=np.uint8)
+        B = np.ascontiguousarray(B, dtype=np.uint8)
+        LB = np.ascontiguousarray(LB, dtype=np.int32)
+        RB = np.ascontiguousarray(RB, dtype=np.int32)
+        keep += [A, B, LB, RB]
+        jobs[i].M, jobs[i].K = A.shape
+        jobs[i].N, jobs[i].L = B.shape
+        jobs[i].A, jobs[i].B, jobs[i].LB, jobs[i].RB = A.ctypes.data, B.ctypes.data, LB.ctypes.data, RB.ctypes.data
+    rc = lib().mz_yama_batch(n, jobs, outs)
+    _check(rc, "mz_yama_batch")
+    res = []
+    for i in range(n):
+        o = outs[i]
+        cols = None
+        if o.status == 0:
+            w = jobs[i].K + jobs[i].L
+            cols = np.frombuffer(C.string_at(o.cols, o.OM * w), dtype=np.uint8).reshape(o.OM, w).copy()
+            lib().free_cols(o.cols)
+        res.append(Result(o.status, o.badrow, o.OM, np.array(list(o.score), dtype=np.int32), cols))
+    return res
+
+
+def yama_one(A, B, LB, RB) -> Result:
+    return yama_batch([(A, B, LB, RB)])[0]
+
+
+class DevBatch:
+    """A device-resident batch built from torch tensors (torch is plumbing: HBM allocations and the
+    current HIP stream).  Inputs are packed pools (see include/mz_amd.h)."""
+
+    def __init__(self, host: dict, device="cuda:0", cap_tb: Optional[int] = None):
+        import torch
+        self.torch = torch
+        self.dev = torch.device(device)
+        n = len(host["K"])
+        self.n = n
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
+        self.t = {k: t(host[k], np.int32) for k in ("K", "L", "M", "N", "poolLB", "poolRB")}
+        self.t.update({k: t(host[k], np.int64) for k in ("offA", "offB", "offBand")})
+        self.t.update({k: t(host[k], np.uint8) for k in ("poolA", "poolB")})
+        self.plan_mem = torch.empty(lib().mz_dev_plan_bytes(n), dtype=torch.uint8, device=self.dev)
+        self.c = DevBatchC()
+        self.c.n = n
+        for k, v in self.t.items():
+            setattr(self.c, k, v.data_ptr())
+        lib().mz_dev_carve(C.byref(self.c), self.plan_mem.data_ptr())
+        # sizes: traceback = 64 bytes per anti-diagonal step (wf64), script = M+N, out = (M+N)(K+L)
+        M, N = np.asarray(host["M"], dtype=np.int64), np.asarray(host["N"], dtype=np.int64)
+        K, L = np.asarray(host["K"], dtype=np.int64), np.asarray(host["L"], dtype=np.int64)
+        tb = int((((M + N) // 4 + 1) * 64).sum()) if cap_tb is None else int(cap_tb)
+        sc = int((((M + N + 3) // 4) * 4).sum())
+        ou = int(((((M + N) * (K + L) + 15) // 16) * 16).sum())
+        self.tbw = torch.empty(tb + 64, dtype=torch.int32, device=self.dev)
+        self.script = torch.empty(sc + 64, dtype=torch.uint8, device=self.dev)
+        self.out = torch.empty(ou + 64, dtype=torch.uint8, device=self.dev)
+        self.c.tbw, self.c.script, self.c.out = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr()
+        self.c.capTb, self.c.capScript, self.c.capOut = tb + 64, sc + 64, ou + 64
+
+    def stream_ptr(self):
+        return self.torch.cuda.current_stream(self.dev).cuda_stream
+
+    def run(self, timed: bool = False):
+        ms = (C.c_float * 4)() if timed else None
+        _check(lib().mz_dev_run(C.byref(self.c), self.stream_ptr(), ms), "mz_dev_run")
+        return list(ms) if timed else None
+
+    def _view(self, ptr, n, dtype):
+        # plan arrays live inside plan_mem; build views by offset
+        off = ptr - self.plan_mem.data_ptr()
+        nbytes = n * np.dtype(dtype).itemsize
+        return self.plan_mem[off: off + nbytes].cpu().numpy().view(dtype)
+
+    def results(self):
+        self.torch.cuda.synchronize(self.dev)
+        n = self.n
+        return dict(status=self._view(self.c.status, n, np.int32), mode=self._view(self.c.mode, n, np.int32),
+                    cells=self._view(self.c.cells, n, np.int64), om=self._view(self.c.om, n, np.int32),
+                    final3=self._view(self.c.final3, 3 * n, np.int32).reshape(n, 3),
+                    offOut=self._view(self.c.offOut, n, np.int64), totals=self._view(self.c.totals, 4, np.int64))
+
+    def output_cols(self, i: int, res: dict, K: int, L: int):
+        om, off = int(res["om"][i]), int(res["offOut"][i])
+        return self.out[off: off + om * (K + L)].cpu().numpy().reshape(om, K + L)

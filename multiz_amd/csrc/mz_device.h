@@ -1,0 +1,18 @@
+/* mz_device.h -- internal: launchers implemented in mz_device.hip, called by the C host shim. */
+#ifndef MZ_DEVICE_H
+#define MZ_DEVICE_H
+#include "../../include/mz_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* all asynchronous on `stream` (a hipStream_t) */
+int mzk_upload_scores(const mz_score_model *m, void *stream);
+int mzk_plan(const mz_dev_batch *b, void *stream);
+int mzk_dp(const mz_dev_batch *b, void *stream);
+int mzk_walk(const mz_dev_batch *b, void *stream);
+int mzk_emit(const mz_dev_batch *b, void *stream);
+const char *mzk_last_error(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,617 @@
+// mz_device.hip -- gfx950 (MI355X / CDNA4) kernels for the multiz block-pair merge DP.
+//
+// What is computed: exactly the recurrence of reference mz_yama.c:83-255 (three-state
+// C/D/I affine-gap sum-of-pairs DP over a band LB[]..RB[]), its traceback (mz_yama.c:257-291)
+// and the merged-column emit (mz_yama.c:293-313), bit for bit, for a whole batch of
+// independent block pairs.  How it is computed is not the reference's:
+//
+//  * per-cell sums over (row of A) x (row of B) are evaluated as small integer bilinear
+//    forms of per-column class/gap counts (oracle/yama_profile_oracle.c is the executable
+//    specification; integer-exact).  The counts are packed as int8/int16 vectors so that a
+//    cell costs a handful of v_dot4_i32_i8 / v_dot2_i32_i16 instead of 4*K*L table look-ups.
+//  * one 64-lane wave owns one block pair and sweeps anti-diagonals: lane = DP row mod 64,
+//    step t handles cells (r, t-r).  (r-1,c) and (r-1,c-1) come from the neighbouring lane
+//    through DPP wave rotates (no LDS traffic for the recurrence); (r,c-1) is the lane's own
+//    previous value.  Column profiles of B sit in an LDS ring, row records of A in LDS.
+//  * traceback bytes are stored "diagonal-major", four steps per dword, so that every store
+//    is one fully coalesced 256-byte row per wave.
+//
+// No MFMA anywhere: this is an integer max-plus recurrence, not a contraction.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "mz_device.h"
+
+#define WAVE   64
+#define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
+#define REC_DW 16           // dwords per staged row record
+
+struct ScoreConst { int S6[36]; int go; int ge; };
+__constant__ ScoreConst c_sc;
+
+// byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
+// reference score table is constant (mz_scores.c:39-54)
+__device__ __forceinline__ int byte_class(unsigned ch)
+{
+    const unsigned u = ch | 0x20u;           // fold case: only 'X' and 'x' map onto 'x'
+    int c = 5;
+    c = (u == 'a') ? 0 : c;
+    c = (u == 'c') ? 1 : c;
+    c = (u == 'g') ? 2 : c;
+    c = (u == 't') ? 3 : c;
+    c = (ch == '-') ? 4 : c;
+    return c;
+}
+
+__device__ __forceinline__ int pack4(int b0, int b1, int b2, int b3)
+{
+    return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((b3 & 0xff) << 24);
+}
+__device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot4(int a, int b, int acc) { return __builtin_amdgcn_sdot4(a, b, acc, false); }
+__device__ __forceinline__ int dot2(int a, int b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
+}
+// lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
+__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false); }
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// plan: validity prologue of yama (reference mz_yama.c:58-71), work sizes, kernel mode
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p];
+    int status = MZ_OK, badrow = -1, mode = MZ_MODE_WF64;
+    long long cells = 0, szTb = 0;
+
+    if (K < 1 || K > 127 || L < 1 || L > 127) status = MZ_E_ROWS;
+    else if (M < 1 || N < 1) status = MZ_E_SHAPE;
+    else if ((long long)K * L * (c_sc.go + c_sc.ge) * ((long long)M + N + 2) >= (1LL << 30)) status = MZ_E_RANGE;
+
+    if (status == MZ_OK) {
+        const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+        if (LB[0] != 0 || RB[M] != N) status = MZ_E_TERMINATION;
+        else {
+            const int need = N < 10 ? N : 10;
+            int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
+            int wf_ok = 1;
+            for (int r = lane; r <= M; r += WAVE) {
+                const int lo = LB[r], hi = RB[r];
+                if (hi - lo < need) key = min(key, (r << 2) | 0);
+                if (r > 0 && lo < LB[r-1]) key = min(key, (r << 2) | 1);
+                if (r > 0 && hi < RB[r-1]) key = min(key, (r << 2) | 2);
+                cells += hi - lo + 1;
+                // a lane must have left row r before row r+64 (same lane) and its right
+                // neighbour's row r+65 need it: RB[r] - LB[r+64] <= 62
+                if (r + WAVE <= M && hi - LB[r + WAVE] > 62) wf_ok = 0;
+            }
+            key = wave_min(key);
+            wf_ok = wave_min(wf_ok);
+            cells = wave_sum64(cells);
+            if (key != 0x7fffffff) {
+                badrow = key >> 2;
+                status = (key & 3) == 0 ? MZ_E_NARROW : (key & 3) == 1 ? MZ_E_LB_MONO : MZ_E_RB_MONO;
+            } else if (wf_ok) {
+                mode = MZ_MODE_WF64;
+                szTb = (long long)(((M + N) >> 2) + 1) * WAVE;
+            } else {
+                mode = MZ_MODE_STRIP;
+                // strips of 64 rows; strip s sweeps columns LB[first]..RB[last] with a 64-step skew.
+                // layout: [2*S header dwords rounded up to 64] + per strip ceil(steps/4)*64 dwords
+                const int S = (M + WAVE - 1) / WAVE;
+                long long acc = 0;
+                for (int s = lane; s < S; s += WAVE) {
+                    const int first = s * WAVE + 1, last = min(first + WAVE - 1, M);
+                    const int steps = RB[last] - LB[first] + 1 + (last - first);
+                    acc += (long long)((steps + 3) >> 2) * WAVE;
+                }
+                acc = wave_sum64(acc);
+                szTb = acc + (((2LL * S) + WAVE - 1) / WAVE) * WAVE;
+            }
+        }
+    }
+    if (lane == 0) {
+        const bool ok = status == MZ_OK;
+        b.status[p] = status;
+        b.badrow[p] = badrow;
+        b.mode[p] = mode;
+        b.cells[p] = ok ? cells : 0;
+        b.szTb[p] = ok ? szTb : 0;
+        b.szScript[p] = ok ? (((long long)M + N + 3) & ~3LL) : 0;
+        b.szOut[p] = ok ? (((long long)(M + N) * (K + L) + 15) & ~15LL) : 0;
+        b.om[p] = 0;
+    }
+}
+
+// exclusive prefix sums of the three size arrays (single workgroup; n is at most a few million)
+__global__ __launch_bounds__(1024) void k_scan(mz_dev_batch b)
+{
+    __shared__ long long part[3][1024];
+    __shared__ int nbad[1024];
+    const int tid = threadIdx.x, n = b.n;
+    const int per = (n + 1023) / 1024;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    long long s0 = 0, s1 = 0, s2 = 0;
+    int bad = 0;
+    for (int i = i0; i < i1; ++i) {
+        s0 += b.szTb[i]; s1 += b.szScript[i]; s2 += b.szOut[i];
+        bad += b.status[i] != MZ_OK;
+    }
+    part[0][tid] = s0; part[1][tid] = s1; part[2][tid] = s2; nbad[tid] = bad;
+    __syncthreads();
+    if (tid < 3) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) { long long v = part[tid][i]; part[tid][i] = run; run += v; }
+        b.totals[tid] = run;
+    } else if (tid == 3) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) run += nbad[i];
+        b.totals[3] = run;
+    }
+    __syncthreads();
+    s0 = part[0][tid]; s1 = part[1][tid]; s2 = part[2][tid];
+    for (int i = i0; i < i1; ++i) {
+        b.offTb[i] = s0; b.offScript[i] = s1; b.offOut[i] = s2;
+        s0 += b.szTb[i]; s1 += b.szScript[i]; s2 += b.szOut[i];
+    }
+}
+
+// after the scan: a pair whose slices do not fit the caller's workspace is failed, loudly
+__global__ void k_fit(mz_dev_batch b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n || b.status[i] != MZ_OK) return;
+    if (b.offTb[i] + b.szTb[i] > b.capTb || b.offScript[i] + b.szScript[i] > b.capScript ||
+        b.offOut[i] + b.szOut[i] > b.capOut)
+        b.status[i] = MZ_E_WORKSPACE;
+}
+
+// ------------------------------------------------------------------------------------------
+// DP
+// ------------------------------------------------------------------------------------------
+struct Tri { int C, D, I; };
+
+// everything a lane needs to know about its current DP row; built once per row by
+// stage_rows() (64 rows in parallel) and read back from LDS when the lane re-arms
+struct RowRegs {
+    int lo, hi;        // LB[r], RB[r]
+    int lb1;           // LB[r-1]
+    int tC;            // r>1 ? LB[r-2] : BIG   (guards of mz_yama.c:177-179,215-216)
+    int tY;            // r>1 ? 0 : BIG         (the bare "row > 1" guards, :181-182,217-218)
+    int mI;            // r<M ? gap_open : 0    (no open for trailing end-gaps, :123)
+    int rxC, ryC, rzC; // int8x4 row vectors for the three C-state gap sums
+    int rxI;           // ... for the I-state x sum
+    int rxD;           // ... for the D-state x sum (accumulator accD)
+    int accD;          // nA * L
+    int penDy;         // gap_open * L * (nA - PA00)
+    int penDz;         // gap_open * L * nA
+    int extD;          // gap_extend * L * nA
+    int w01, w23, w45; // int16x2 substitution row vector  cntA^T * S6
+};
+
+struct PairCtx {
+    int K, L, M, N;
+    const uint8_t *A, *B;
+    const int *LB, *RB;
+};
+
+__device__ __forceinline__ void rec_dead(int *dst)
+{
+    int4 *d = (int4 *)dst;
+    d[0] = make_int4(MZ_BIG, -1, MZ_BIG, MZ_BIG);
+    d[1] = make_int4(MZ_BIG, 0, 0, 0);
+    d[2] = make_int4(0, 0, 0, 0);
+    d[3] = make_int4(0, 0, 0, 0);
+}
+
+// Build the records of rows 64*blk+1 .. 64*blk+64 (lane <-> row) into LDS slot blk&1.
+// Column profile of A column r (appendix A.4 of SURVEY.md): class counts, non-dash / dash
+// counts and the two "same as previous column" counts PA00, PA11.
+__device__ __forceinline__ void stage_rows(int blk, int lane, const PairCtx &J, int *recs)
+{
+    const int rr = blk * WAVE + lane + 1;
+    int *dst = recs + (((blk & 1) * WAVE) + lane) * REC_DW;
+    if (rr > J.M) { rec_dead(dst); return; }
+
+    const int K = J.K, L = J.L;
+    const uint8_t *col = J.A + (long long)(rr - 1) * K;
+    unsigned cnt = 0;              // four 8-bit counters: classes 0..3
+    int dA = 0, a00 = 0, a11 = 0, other = 0;
+    for (int i = 0; i < K; ++i) {
+        const unsigned ch = col[i];
+        const bool dash = ch == '-';
+        const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
+        const int cl = byte_class(ch);
+        cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+        other += cl == 5;
+        dA += dash;
+        a00 += (!dash) & (!pdash);
+        a11 += dash & pdash;
+    }
+    const int nA = K - dA;
+    int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
+    int w[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += cn[k] * c_sc.S6[k * 6 + l];
+        w[l] = s;
+    }
+    const int go = c_sc.go;
+    const int lb1 = J.LB[rr - 1];
+    const int lb2 = rr > 1 ? J.LB[rr - 2] : 0;
+    int4 *d = (int4 *)dst;
+    d[0] = make_int4(J.LB[rr], J.RB[rr], lb1, rr > 1 ? lb2 : MZ_BIG);
+    d[1] = make_int4(rr > 1 ? 0 : MZ_BIG, rr < J.M ? go : 0,
+                     pack4(nA, dA, -a00, -a11), pack4(nA - a00, dA, 0, 0));
+    d[2] = make_int4(pack4(nA, dA, 0, -dA), pack4(0, K, 0, -dA), pack4(-a00, 0, 0, 0), nA * L);
+    d[3] = make_int4(go * L * (nA - a00), pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+}
+
+__device__ __forceinline__ void load_rec(RowRegs &R, const int *src)
+{
+    const int4 *s = (const int4 *)src;
+    const int4 a = s[0], b = s[1], c = s[2], d = s[3];
+    R.lo = a.x; R.hi = a.y; R.lb1 = a.z; R.tC = a.w;
+    R.tY = b.x; R.mI = b.y; R.rxC = b.z; R.ryC = b.w;
+    R.rzC = c.x; R.rxI = c.y; R.rxD = c.z; R.accD = c.w;
+    R.penDy = d.x; R.w01 = d.y; R.w23 = d.z; R.w45 = d.w;
+    R.penDz = c_sc.go * c.w;
+    R.extD = c_sc.ge * c.w;
+}
+
+// Stage the profiles of B columns first..first+63 (lane <-> column) into the LDS ring.
+// entry = { int8x4(dB, nB, PB11, PB00), int16x2(cnt0,cnt1), (cnt2,cnt3), (cnt4,cnt5) }
+__device__ __forceinline__ void stage_bcols(int first, int lane, const PairCtx &J, int4 *ring)
+{
+    const int cc = first + lane;
+    int4 e = make_int4(0, 0, 0, 0);
+    if (cc >= 1 && cc <= J.N) {
+        const int L = J.L;
+        const uint8_t *col = J.B + (long long)(cc - 1) * L;
+        unsigned cnt = 0;
+        int dB = 0, b00 = 0, b11 = 0, other = 0;
+        for (int j = 0; j < L; ++j) {
+            const unsigned ch = col[j];
+            const bool dash = ch == '-';
+            const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
+            const int cl = byte_class(ch);
+            cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+            other += cl == 5;
+            dB += dash;
+            b00 += (!dash) & (!pdash);
+            b11 += dash & pdash;
+        }
+        e.x = pack4(dB, L - dB, b11, b00);
+        e.y = pack2(cnt & 0xff, (cnt >> 8) & 0xff);
+        e.z = pack2((cnt >> 16) & 0xff, cnt >> 24);
+        e.w = pack2(dB, other);
+    }
+    ring[cc & (BRING - 1)] = e;
+}
+
+// interior tie order of mz_yama.c:138-154: the C-predecessor wins ties, then D only if
+// strictly greater than I.  m == x  <=>  x >= y && x >= z.
+__device__ __forceinline__ int pick(int x, int y, int z, int fD, int fI, int &flag)
+{
+    const int m = max(max(x, y), z);
+    const int f = (y > z) ? fD : fI;
+    flag = (x == m) ? 0 : f;
+    return m;
+}
+
+// One DP cell (r, c): the three updates of mz_yama.c:113-242 in profile form.
+//   left = (C,D,I)(r, c-1)   up = P(r-1, c)   dg = P(r-1, c-1)
+// q is the B-column profile.  Returns the new triple and the traceback byte (:253).
+__device__ __forceinline__ Tri cell(const RowRegs &R, int c, int N, int4 q, Tri left, Tri up, Tri dg,
+                                    int pkKy, int pkKz, int go, int ge, int &tbyte)
+{
+    const int cm1 = c - 1;
+    const bool g1  = cm1 > R.lb1;            // c > LB[r-1]+1
+    const bool gIz = cm1 > R.lo;             // c > LB[r]+1
+    const bool vI  = c > R.lo;               // I exists (c != LB[r])
+    const bool vC  = c > R.lb1;              // C exists
+    const bool gCx = cm1 > R.tC;             // r>1 && c > LB[r-2]+1
+    const bool gCy = cm1 > R.tY;             // r>1 && c > 1
+    const bool inN = c < N;
+    const bool gDx = (c > R.tC) & inN;       // r>1 && c > LB[r-2] && c < N   (c > LB[r-2] >= 0 implies c > 0)
+    const bool gDy = (c > R.tY) & inN;       // r>1 && 0 < c < N
+    const bool gDz = vC & inN;               // c > LB[r-1] && c < N
+    Tri o;
+    int fi, fc, fd, x, y, z, t;
+
+    // ---- I  (from the same row, previous column)
+    const int KnB = dot4(pkKy, q.x, 0);                 // K*nB
+    t = left.C - __mul24(dot4(R.rxI, q.x, 0), R.mI);    // K*nB - dA*PB00
+    x = g1 ? t : left.C;
+    y = left.D - __mul24(KnB, R.mI);
+    t = left.I - __mul24(dot4(pkKz, q.x, 0), R.mI);     // K*(nB - PB00)
+    z = gIz ? t : left.I;
+    o.I = pick(x, y, z, MZ_FD << 4, MZ_FI << 4, fi) - __mul24(KnB, ge);
+    o.I = vI ? o.I : MZ_NEG;
+
+    // ---- C  (diagonal)
+    t = dg.C - __mul24(dot4(R.rxC, q.x, 0), go);
+    x = gCx ? t : dg.C;
+    t = dg.D - __mul24(dot4(R.ryC, q.x, 0), go);
+    y = gCy ? t : dg.D;
+    t = dg.I - __mul24(dot4(R.rzC, q.x, 0), go);
+    z = g1 ? t : dg.I;                                   // c > 1 is implied by c > LB[r-1]+1
+    t = pick(x, y, z, MZ_FD, MZ_FI, fc);
+    t = dot2(R.w01, q.y, dot2(R.w23, q.z, dot2(R.w45, q.w, t)));
+    o.C = vC ? t : MZ_NEG;
+
+    // ---- D  (from the row above)
+    t = up.C - __mul24(dot4(R.rxD, q.x, R.accD), go);    // nA*L - PA00*dB
+    x = gDx ? t : up.C;
+    t = up.D - R.penDy;
+    y = gDy ? t : up.D;
+    t = up.I - R.penDz;
+    z = gDz ? t : up.I;
+    o.D = pick(x, y, z, MZ_FD << 2, MZ_FI << 2, fd) - R.extD;
+
+    tbyte = fc | fd | fi;
+    return o;
+}
+
+// wf64: 64 DP rows in flight, row r on lane (r-1)&63 (row 0 on lane 63), cell (r, t-r) at step t.
+__global__ __launch_bounds__(WAVE) void k_dp_wf64(mz_dev_batch b)
+{
+    __shared__ __attribute__((aligned(16))) int  s_rec[2 * WAVE * REC_DW];
+    __shared__ __attribute__((aligned(16))) int4 s_ring[BRING];
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_WF64) return;
+
+    PairCtx J;
+    J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
+    J.A = b.poolA + b.offA[p]; J.B = b.poolB + b.offB[p];
+    J.LB = b.poolLB + b.offBand[p]; J.RB = b.poolRB + b.offBand[p];
+    const int M = J.M, N = J.N;
+    const int go = c_sc.go, ge = c_sc.ge;
+    const int pkKy = pack4(0, J.K, 0, 0), pkKz = pack4(0, J.K, 0, -J.K);
+    uint32_t *tbw = b.tbw + b.offTb[p];
+
+    // ---- prologue: rows 1..128, B columns 1..64, arm the lanes
+    stage_rows(0, lane, J, s_rec);
+    stage_rows(1, lane, J, s_rec);
+    s_ring[0] = make_int4(0, 0, 0, 0);       // column 0 has no profile (only D is computed there)
+    stage_bcols(1, lane, J, s_ring);
+    int cst = WAVE;                           // highest staged B column
+    __builtin_amdgcn_s_waitcnt(0);            // LDS writes of this wave are in order; keep the compiler honest
+    __syncthreads();
+
+    RowRegs R;
+    int r;                                    // this lane's current row
+    Tri st = { MZ_NEG, MZ_NEG, MZ_NEG };      // (C,D,I) of this lane's latest cell; NEG while idle
+    if (lane == WAVE - 1) {
+        // row 0 (mz_yama.c:83-94): C = D = NEG, I(0,c) = I(0,c-1) - nB(c)*K*gap_extend.
+        // Expressed with the general cell by zeroing every penalty; C and D are forced to NEG
+        // after each step while row 0 is live.
+        r = 0;
+        R.lo = 0; R.hi = J.RB[0]; R.lb1 = MZ_BIG; R.tC = MZ_BIG; R.tY = MZ_BIG; R.mI = 0;
+        R.rxC = R.ryC = R.rzC = R.rxI = R.rxD = 0; R.accD = R.penDy = R.penDz = R.extD = 0;
+        R.w01 = R.w23 = R.w45 = 0;
+        st.C = st.D = st.I = 0;               // grid point (0,0)
+    } else {
+        r = lane + 1;
+        load_rec(R, s_rec + lane * REC_DW);
+    }
+
+    // wave-uniform bookkeeping of the oldest live row: rows finish strictly in order, one per step at most
+    int rlo = 0;                              // oldest row not yet finished
+    int lfin = WAVE - 1;                      // its lane
+    int tfin = __builtin_amdgcn_readlane(R.hi, WAVE - 1);   // step at which it computes its last cell
+    Tri up = { MZ_NEG, MZ_NEG, MZ_NEG }, dg;
+    unsigned tbword = 0;
+    const int Tend = M + N;
+
+    for (int t = 1; t <= Tend; ++t) {
+        // ---- predecessors from the neighbouring lane (row r-1): its cell of step t-1 is (r-1, c),
+        //      the one it had a step earlier is (r-1, c-1).  Read BEFORE a finished lane is re-armed.
+        dg = up;
+        up.C = ror1(st.C); up.D = ror1(st.D); up.I = ror1(st.I);
+
+        // ---- a finished row hands its lane to row+64
+        if (t > tfin) {
+            const int rn = rlo + WAVE;
+            if (lane == lfin) {
+                r = rn;
+                load_rec(R, s_rec + ((((rn - 1) >> 6) & 1) * WAVE + lane) * REC_DW);
+                st.C = st.D = st.I = MZ_NEG;
+            }
+            if (lfin == 0) {                  // lane 0 entered block k: every lane has left block k-1
+                stage_rows(((rn - 1) >> 6) + 1, lane, J, s_rec);
+                __syncthreads();
+            }
+            rlo += 1;
+            lfin = (lfin + 1) & (WAVE - 1);
+            tfin = rlo > M ? MZ_BIG : rlo + __builtin_amdgcn_readlane(R.hi, lfin);
+        }
+        // ---- keep the B-profile ring ahead of the leading column (t - rlo)
+        if (t - rlo > cst) {
+            stage_bcols(cst + 1, lane, J, s_ring);
+            cst += WAVE;
+            __syncthreads();
+        }
+
+        const int c = t - r;
+        const int4 q = s_ring[c & (BRING - 1)];
+        int tbyte;
+        Tri nw = cell(R, c, N, q, st, up, dg, pkKy, pkKz, go, ge, tbyte);
+        const bool active = (c >= R.lo) & (c <= R.hi);
+        st.C = active ? nw.C : MZ_NEG;
+        st.D = active ? nw.D : MZ_NEG;
+        st.I = active ? nw.I : MZ_NEG;
+        if (rlo == 0 && lane == WAVE - 1) { st.C = MZ_NEG; st.D = MZ_NEG; }   // row 0
+
+        // ---- traceback byte: four steps per dword, one coalesced row per store
+        tbword = __builtin_amdgcn_alignbyte(tbyte, tbword, 1);
+        if ((t & 3) == 3) tbw[(t >> 2) * WAVE + lane] = tbword;
+    }
+    if ((Tend & 3) != 3)
+        tbw[(Tend >> 2) * WAVE + lane] = tbword >> (8 * (3 - (Tend & 3)));
+
+    if (lane == ((M - 1) & (WAVE - 1))) {
+        b.final3[3 * p + 0] = st.C;
+        b.final3[3 * p + 1] = st.D;
+        b.final3[3 * p + 2] = st.I;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
+// traceback bytes; writes the edit script in reverse order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.n || b.status[p] != MZ_OK) return;
+    const int M = b.M[p], N = b.N[p];
+    const uint32_t *tbw = b.tbw + b.offTb[p];
+    uint8_t *ops = b.script + b.offScript[p];
+    const int mode = b.mode[p];
+    const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
+
+    // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
+    int node = (fC >= fD && fC >= fI) ? MZ_FC : (fD >= fI) ? MZ_FD : MZ_FI;
+    int r = M, c = N, n = 0, status = MZ_OK;
+    const int limit = M + N;
+    while (r > 0 || c > 0) {
+        if (r < 0 || c < 0 || n >= limit) { status = MZ_E_TRACEBACK; break; }
+        unsigned stb;
+        if (r == 0) {
+            stb = MZ_FI << 4;                              // row 0 bytes, mz_yama.c:92
+        } else if (mode == MZ_MODE_WF64) {
+            const int t = r + c;
+            stb = (tbw[(t >> 2) * WAVE + ((r - 1) & (WAVE - 1))] >> (8 * (t & 3))) & 0xff;
+        } else {
+            const int s = (r - 1) >> 6, l = (r - 1) & (WAVE - 1);
+            const int clo = (int)tbw[2 * s];
+            const long long base = (long long)tbw[2 * s + 1];
+            const int tau = c - clo + l;
+            stb = (tbw[base + (long long)(tau >> 2) * WAVE + l] >> (8 * (tau & 3))) & 0xff;
+        }
+        ops[n++] = (uint8_t)node;
+        if (node == MZ_FI)      { c -= 1;         node = (stb >> 4) & 3; }
+        else if (node == MZ_FD) { r -= 1;         node = (stb >> 2) & 3; }
+        else if (node == MZ_FC) { r -= 1; c -= 1; node = stb & 3; }
+        else { status = MZ_E_TRACEBACK; break; }
+    }
+    if (status == MZ_OK && (r != 0 || c != 0)) status = MZ_E_TRACEBACK;
+    b.om[p] = n;
+    if (status != MZ_OK) b.status[p] = status;
+}
+
+// ------------------------------------------------------------------------------------------
+// emit (mz_yama.c:293-313 + new_col :39-47): one wave per pair, 64 output columns per
+// iteration; column m takes A[i] or dashes on top of B[j] or dashes, where (i, j) are the
+// running counts of A- and B-advancing ops up to m.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK) return;
+    const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p], n = b.om[p];
+    const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
+    const uint8_t *ops = b.script + b.offScript[p];
+    uint8_t *out = b.out + b.offOut[p];
+    const unsigned long long below = (lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL);
+    int ia = 0, jb = 0;                                     // columns of A / B consumed so far
+    for (int base = 0; base < n; base += WAVE) {
+        const int m = base + lane;
+        const bool live = m < n;
+        const int op = live ? ops[n - 1 - m] : MZ_FI;
+        const bool adA = live && op != MZ_FI, adB = live && op != MZ_FD;
+        const unsigned long long mA = __ballot(adA), mB = __ballot(adB);
+        const int i = ia + __popcll(mA & below);            // 1-based column of A (if adA)
+        const int j = jb + __popcll(mB & below);
+        if (live) {
+            uint8_t *col = out + (long long)m * (K + L);
+            const uint8_t *ca = A + (long long)(i - 1) * K, *cb = B + (long long)(j - 1) * L;
+            for (int k = 0; k < K; ++k) col[k] = adA ? ca[k] : (uint8_t)'-';
+            for (int k = 0; k < L; ++k) col[K + k] = adB ? cb[k] : (uint8_t)'-';
+        }
+        ia += __popcll(mA);
+        jb += __popcll(mB);
+    }
+    if (lane == 0 && (ia != M || jb != N)) b.status[p] = MZ_E_EMIT;   // mz_yama.c:310-312
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI launchers
+// ------------------------------------------------------------------------------------------
+static char g_err[256];
+static int fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+#define CK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_, what); } while (0)
+
+extern "C" const char *mzk_last_error(void) { return g_err; }
+
+extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
+{
+    ScoreConst h;
+    for (int i = 0; i < 36; ++i) h.S6[i] = m->S6[i];
+    h.go = m->gap_open;
+    h.ge = m->gap_extend;
+    CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
+    CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
+    return 0;
+}
+
+extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_plan, dim3(b->n), dim3(WAVE), 0, s, *b);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, *b);
+    hipLaunchKernelGGL(k_fit, dim3((b->n + 255) / 256), dim3(256), 0, s, *b);
+    CK(hipGetLastError(), "plan launch");
+    return 0;
+}
+
+extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_dp_wf64, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    CK(hipGetLastError(), "dp launch");
+    return 0;
+}
+
+extern "C" int mzk_walk(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_walk, dim3((b->n + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    CK(hipGetLastError(), "walk launch");
+    return 0;
+}
+
+extern "C" int mzk_emit(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_emit, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    CK(hipGetLastError(), "emit launch");
+    return 0;
+}

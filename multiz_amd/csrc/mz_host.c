@@ -1,0 +1,444 @@
+/* mz_host.c -- C host side of libmzamd.so: device context, score-model hand-over, the
+ * host-buffer batch entry point and the reference-signature yama() built on it.
+ *
+ * Host code stays C (as the reference is); the HIP kernels are reached through the mzk_*
+ * launchers of mz_device.hip.  There is no CPU implementation of the DP in this library: when
+ * no HIP device is usable every entry point fails (yama(): prints and exit(1)s, like any other
+ * fatal condition of the reference, util.c:21-30).
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mz_device.h"
+#include "../../include/mz_scores.h"
+#include "../../include/mz_yama.h"
+
+/* ------------------------------------------------------------------ error plumbing */
+
+static char g_err[512];
+char *argv0;                               /* reference util.c:4; drivers set it in main() */
+
+const char *mz_last_error(void) { return g_err; }
+
+static int set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIPCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return set_err("%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+/* same shape as the reference's fatalf(): "<argv0 basename>: message\n", exit(1) */
+int mz_scores_explicit;                  /* set by mz_set_scores(), cleared by init_scores70/85() */
+
+__attribute__((noreturn)) void mz_fatalf(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    fflush(stdout);
+    if (argv0) {
+        const char *p = strrchr(argv0, '/');
+        fprintf(stderr, "%s: ", p ? p + 1 : argv0);
+    }
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+    exit(1);
+}
+
+/* ------------------------------------------------------------------ context */
+
+typedef struct gbuf { void *p; size_t cap; } gbuf;
+
+static struct {
+    int ready;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[5];
+    /* last score tables handed to the device */
+    int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
+    /* grow-only buffers of the host-buffer path */
+    gbuf h_in, d_in, d_plan, d_tb, d_script, d_out, h_res;
+} G;
+
+static int dev_reserve(gbuf *b, size_t need)
+{
+    if (need <= b->cap) return 0;
+    if (b->p) { HIPCK(hipFree(b->p)); b->p = NULL; b->cap = 0; }
+    need = need + need / 4 + 4096;
+    HIPCK(hipMalloc(&b->p, need));
+    b->cap = need;
+    return 0;
+}
+static int host_reserve(gbuf *b, size_t need)
+{
+    if (need <= b->cap) return 0;
+    if (b->p) { HIPCK(hipHostFree(b->p)); b->p = NULL; b->cap = 0; }
+    need = need + need / 4 + 4096;
+    HIPCK(hipHostMalloc(&b->p, need, hipHostMallocDefault));
+    b->cap = need;
+    return 0;
+}
+
+void *mz_stream(void) { return G.ready ? (void *)G.stream : NULL; }
+
+int mz_init(int device)
+{
+    int count = 0, i;
+    if (G.ready && G.device == device) return 0;
+    if (G.ready) mz_finalize();
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err("no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= count)
+        return set_err("HIP device %d out of range (%d present)", device, count);
+    HIPCK(hipSetDevice(device));
+    HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+    for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
+    G.device = device;
+    G.ready = 1;
+    G.scores_ok = 0;
+    G.ss_seen = NULL;
+    return 0;
+}
+
+void mz_finalize(void)
+{
+    int i;
+    gbuf *d[] = { &G.d_in, &G.d_plan, &G.d_tb, &G.d_script, &G.d_out };
+    if (!G.ready) return;
+    hipStreamSynchronize(G.stream);
+    for (i = 0; i < 5; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+    if (G.h_in.p)  { hipHostFree(G.h_in.p);  G.h_in.p = NULL;  G.h_in.cap = 0; }
+    if (G.h_res.p) { hipHostFree(G.h_res.p); G.h_res.p = NULL; G.h_res.cap = 0; }
+    for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
+    hipStreamDestroy(G.stream);
+    G.ready = 0;
+}
+
+static int ensure_init(void)
+{
+    const char *e;
+    if (G.ready) return 0;
+    e = getenv("MZ_DEVICE");
+    return mz_init(e ? atoi(e) : 0);
+}
+
+/* ------------------------------------------------------------------ scores */
+
+static int class_of(int ch)
+{
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case '-': return 4;
+    default:  return 5;
+    }
+}
+
+/* ss as 128 row pointers or flat; returns 0 and fills the model when the tables have the
+ * class structure the kernels rely on */
+static int model_from_tables(int **rows, const int *flat, const int *g16, int ext, mz_score_model *m)
+{
+    static const unsigned char rep[6] = { 'A', 'C', 'G', 'T', '-', 'N' };
+    int a, b, x;
+#define SSAT(i, j) (rows ? rows[i][j] : flat[(i) * 128 + (j)])
+    for (a = 0; a < 6; ++a)
+        for (b = 0; b < 6; ++b)
+            m->S6[a * 6 + b] = SSAT(rep[a], rep[b]);
+    for (a = 0; a < 128; ++a)
+        for (b = 0; b < 128; ++b)
+            if (SSAT(a, b) != m->S6[class_of(a) * 6 + class_of(b)])
+                return set_err("substitution table is not constant on the byte classes {A,C,G,T,-,other} at (%d,%d)", a, b);
+#undef SSAT
+    m->gap_open = g16[1];
+    for (x = 0; x < 16; ++x) {
+        int s = (x >> 3) & 1, t = (x >> 2) & 1, u = (x >> 1) & 1, v = x & 1;
+        int want = (u != v && !(s == u && t == v)) ? m->gap_open : 0;
+        if (g16[x] != want)
+            return set_err("gap-open table entry %d is %d, expected %d (quasi-natural structure)", x, g16[x], want);
+    }
+    m->gap_extend = ext;
+    for (a = 0; a < 36; ++a)
+        if (m->S6[a] < -258 || m->S6[a] > 258)      /* 127 rows * |score| must fit the int16 dot-product operand */
+            return set_err("substitution score %d too large for the packed int16 row vector", m->S6[a]);
+    if (m->gap_open < 0 || m->gap_open >= (1 << 15) || ext < 0 || ext >= (1 << 15))
+        return set_err("gap penalties out of range (open %d, extend %d)", m->gap_open, ext);
+    return 0;
+}
+
+int mz_set_scores(const int *ss_flat, const int *gop16, int ext)
+{
+    mz_score_model m;
+    if (ensure_init()) return -1;
+    if (model_from_tables(NULL, ss_flat, gop16, ext, &m)) return -1;
+    if (mzk_upload_scores(&m, G.stream)) return set_err("%s", mzk_last_error());
+    G.scores_ok = 1;
+    G.ss_seen = NULL;
+    mz_scores_explicit = 1;                /* keep them until init_scores70/85() is called again */
+    return 0;
+}
+
+/* hand the reference-style globals (ss, gop, gap_extend) to the device if they changed */
+static int sync_global_scores(void)
+{
+    mz_score_model m;
+    if (mz_scores_explicit && G.scores_ok) return 0;   /* tables given through mz_set_scores() */
+    if (ss == NULL || gop == NULL)
+        init_scores70();                   /* batch API default: HOXD70, as multiz.c:257 */
+    if (G.scores_ok && G.ss_seen == ss && G.gop_seen == gop && G.ge_seen == gap_extend) return 0;
+    if (model_from_tables(ss, NULL, gop, gap_extend, &m)) return -1;
+    if (mzk_upload_scores(&m, G.stream)) return set_err("%s", mzk_last_error());
+    G.ss_seen = ss; G.gop_seen = gop; G.ge_seen = gap_extend; G.scores_ok = 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ device-resident API */
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t mz_dev_plan_bytes(int n)
+{
+    size_t s = 0, N = (size_t)(n > 0 ? n : 1);
+    s += 3 * al256(4 * N);                 /* status, badrow, mode */
+    s += 7 * al256(8 * N);                 /* cells, 3 sizes, 3 offsets */
+    s += al256(8 * 4);                     /* totals */
+    s += al256(4 * N) + al256(12 * N);     /* om, final3 */
+    return s;
+}
+
+void mz_dev_carve(mz_dev_batch *b, void *mem)
+{
+    char *p = (char *)mem;
+    size_t N = (size_t)(b->n > 0 ? b->n : 1);
+#define TAKE(field, type, bytes) do { b->field = (type)p; p += al256(bytes); } while (0)
+    TAKE(status, int32_t *, 4 * N); TAKE(badrow, int32_t *, 4 * N); TAKE(mode, int32_t *, 4 * N);
+    TAKE(cells, int64_t *, 8 * N);
+    TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N);
+    TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N);
+    TAKE(totals, int64_t *, 32);
+    TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
+#undef TAKE
+}
+
+static void *pick_stream(void *s) { return s ? s : (void *)G.stream; }
+
+int mz_dev_plan(const mz_dev_batch *b, void *stream)
+{
+    if (ensure_init() || sync_global_scores()) return -1;
+    return mzk_plan(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+}
+int mz_dev_dp(const mz_dev_batch *b, void *stream)
+{
+    if (ensure_init() || sync_global_scores()) return -1;
+    return mzk_dp(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+}
+int mz_dev_walk(const mz_dev_batch *b, void *stream)
+{
+    if (ensure_init()) return -1;
+    return mzk_walk(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+}
+int mz_dev_emit(const mz_dev_batch *b, void *stream)
+{
+    if (ensure_init()) return -1;
+    return mzk_emit(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+}
+
+int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
+{
+    hipStream_t s;
+    int i;
+    if (ensure_init() || sync_global_scores()) return -1;
+    s = (hipStream_t)pick_stream(stream);
+    if (ms) HIPCK(hipEventRecord(G.ev[0], s));
+    if (mzk_plan(b, s)) return set_err("%s", mzk_last_error());
+    if (ms) HIPCK(hipEventRecord(G.ev[1], s));
+    if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
+    if (ms) HIPCK(hipEventRecord(G.ev[2], s));
+    if (mzk_walk(b, s)) return set_err("%s", mzk_last_error());
+    if (ms) HIPCK(hipEventRecord(G.ev[3], s));
+    if (mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+    if (ms) {
+        HIPCK(hipEventRecord(G.ev[4], s));
+        HIPCK(hipEventSynchronize(G.ev[4]));
+        for (i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&ms[i], G.ev[i], G.ev[i + 1]));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ host-buffer batch */
+
+int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
+{
+    mz_dev_batch b;
+    size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
+    char *h, *d;
+    int32_t *hK, *hL, *hM, *hN, *hLB, *hRB;
+    int64_t *hoA, *hoB, *hoBand, totals[4];
+    uint8_t *hA, *hB;
+    int p, failed = 0;
+
+    if (n <= 0) return 0;
+    if (ensure_init() || sync_global_scores()) return -1;
+
+    for (p = 0; p < n; ++p) {
+        const mz_job *j = &jobs[p];
+        int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
+        bytesA += ok ? (size_t)j->K * j->M : 0;
+        bytesB += ok ? (size_t)j->L * j->N : 0;
+        nband += ok ? (size_t)j->M + 1 : 1;
+    }
+    /* one pinned staging block: [K L M N](int32 x n) [offA offB offBand](int64 x n) LB RB A B */
+    hdr = al256(4 * (size_t)n) * 4 + al256(8 * (size_t)n) * 3;
+    in_bytes = hdr + 2 * al256(4 * nband) + al256(bytesA) + al256(bytesB);
+    if (host_reserve(&G.h_in, in_bytes) || dev_reserve(&G.d_in, in_bytes)) return -1;
+    h = (char *)G.h_in.p; d = (char *)G.d_in.p;
+
+    memset(&b, 0, sizeof b);
+    b.n = n;
+#define SLICE(hptr, type, field, bytes) do { hptr = (type *)h; b.field = (const type *)d; \
+        h += al256(bytes); d += al256(bytes); } while (0)
+    SLICE(hK, int32_t, K, 4 * (size_t)n); SLICE(hL, int32_t, L, 4 * (size_t)n);
+    SLICE(hM, int32_t, M, 4 * (size_t)n); SLICE(hN, int32_t, N, 4 * (size_t)n);
+    SLICE(hoA, int64_t, offA, 8 * (size_t)n); SLICE(hoB, int64_t, offB, 8 * (size_t)n);
+    SLICE(hoBand, int64_t, offBand, 8 * (size_t)n);
+    SLICE(hLB, int32_t, poolLB, 4 * nband); SLICE(hRB, int32_t, poolRB, 4 * nband);
+    SLICE(hA, uint8_t, poolA, bytesA); SLICE(hB, uint8_t, poolB, bytesB);
+#undef SLICE
+    {
+        size_t oa = 0, ob = 0, oband = 0;
+        for (p = 0; p < n; ++p) {
+            const mz_job *j = &jobs[p];
+            int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
+            hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
+            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband;
+            if (ok) {
+                memcpy(hA + oa, j->A, (size_t)j->K * j->M);
+                memcpy(hB + ob, j->B, (size_t)j->L * j->N);
+                memcpy(hLB + oband, j->LB, 4 * ((size_t)j->M + 1));
+                memcpy(hRB + oband, j->RB, 4 * ((size_t)j->M + 1));
+                oa += (size_t)j->K * j->M; ob += (size_t)j->L * j->N; oband += (size_t)j->M + 1;
+            } else {
+                hLB[oband] = hRB[oband] = 0; oband += 1;
+            }
+        }
+    }
+    HIPCK(hipMemcpyAsync(G.d_in.p, G.h_in.p, in_bytes, hipMemcpyHostToDevice, G.stream));
+
+    if (dev_reserve(&G.d_plan, mz_dev_plan_bytes(n))) return -1;
+    mz_dev_carve(&b, G.d_plan.p);
+    b.capTb = b.capScript = b.capOut = INT64_MAX;        /* sizes are not known yet */
+    if (mzk_plan(&b, G.stream)) return set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, G.stream));
+    HIPCK(hipStreamSynchronize(G.stream));
+
+    if (dev_reserve(&G.d_tb, 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script, (size_t)totals[1] + 256) ||
+        dev_reserve(&G.d_out, (size_t)totals[2] + 256))
+        return -1;
+    b.tbw = (uint32_t *)G.d_tb.p; b.script = (uint8_t *)G.d_script.p; b.out = (uint8_t *)G.d_out.p;
+    b.capTb = (int64_t)(G.d_tb.cap / 4); b.capScript = (int64_t)G.d_script.cap; b.capOut = (int64_t)G.d_out.cap;
+
+    if (mzk_dp(&b, G.stream) || mzk_walk(&b, G.stream) || mzk_emit(&b, G.stream))
+        return set_err("%s", mzk_last_error());
+
+    /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */
+    res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256((size_t)totals[2]);
+    if (host_reserve(&G.h_res, res_bytes)) return -1;
+    {
+        char *r = (char *)G.h_res.p;
+        int32_t *rs = (int32_t *)r;                         r += al256(4 * (size_t)n);
+        int32_t *rb = (int32_t *)r;                         r += al256(4 * (size_t)n);
+        int32_t *ro = (int32_t *)r;                         r += al256(4 * (size_t)n);
+        int32_t *rf = (int32_t *)r;                         r += al256(12 * (size_t)n);
+        int64_t *roff = (int64_t *)r;                       r += al256(8 * (size_t)n);
+        uint8_t *rout = (uint8_t *)r;
+        HIPCK(hipMemcpyAsync(rs, b.status, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
+        HIPCK(hipMemcpyAsync(rb, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
+        HIPCK(hipMemcpyAsync(ro, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
+        HIPCK(hipMemcpyAsync(rf, b.final3, 12 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
+        HIPCK(hipMemcpyAsync(roff, b.offOut, 8 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
+        if (totals[2] > 0)
+            HIPCK(hipMemcpyAsync(rout, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, G.stream));
+        HIPCK(hipStreamSynchronize(G.stream));
+        for (p = 0; p < n; ++p) {
+            mz_out *o = &outs[p];
+            o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
+            o->score[0] = o->score[1] = o->score[2] = 0;
+            if (rs[p] != MZ_OK) { failed++; continue; }
+            o->OM = ro[p];
+            o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
+            {
+                size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
+                o->cols = (unsigned char *)malloc(nb ? nb : 1);
+                if (!o->cols) return set_err("out of memory for %zu output bytes", nb);
+                memcpy(o->cols, rout + roff[p], nb);
+            }
+        }
+    }
+    return failed;
+}
+
+/* ------------------------------------------------------------------ yama(): a batch of one */
+
+/* messages of reference mz_yama.c:59,64,68,70,275,308 */
+__attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o)
+{
+    int need = j->N < 10 ? j->N : 10, r = o->badrow;
+    switch (o->status) {
+    case MZ_E_TERMINATION:
+        mz_fatalf("LB and RB not terminated properly: %d %d %d", j->LB[0], j->RB[j->M], j->N);
+    case MZ_E_NARROW:
+        mz_fatalf("RB[%d] - LB[%d] < %d, %d %d %d", r, r, need, j->RB[r], j->LB[r], j->N);
+    case MZ_E_LB_MONO:  mz_fatalf("LB not monotonic");
+    case MZ_E_RB_MONO:  mz_fatalf("RB not monotonic");
+    case MZ_E_TRACEBACK: mz_fatalf("Error generating edit script.");
+    case MZ_E_EMIT:     mz_fatalf("new_align: M=%d, N=%d, M_new=%d\n", j->M, j->N, o->OM);
+    case MZ_E_ROWS:     mz_fatalf("yama(gfx950): K=%d, L=%d outside the supported 1..127 rows per block", j->K, j->L);
+    case MZ_E_SHAPE:    mz_fatalf("yama(gfx950): empty block (M=%d, N=%d)", j->M, j->N);
+    case MZ_E_RANGE:    mz_fatalf("yama(gfx950): K*L*(M+N) = %d*%d*%d would overflow the 32-bit scores", j->K, j->L, j->M + j->N);
+    default:            mz_fatalf("yama(gfx950): device status %d", o->status);
+    }
+}
+
+void yama(uchar **A, int K, int M, uchar **B, int L, int N, int *LB, int *RB, uchar ***OAL, int *OM)
+{
+    mz_job j;
+    mz_out o;
+    uchar *ca, *cb, **al;
+    int i, rc;
+
+    if (K < 1 || L < 1 || M < 1 || N < 1)
+        mz_fatalf("yama(gfx950): empty block (K=%d, L=%d, M=%d, N=%d)", K, L, M, N);
+    /* the reference only promises 1-based column pointers (mz_yama.h:6-9); gather them */
+    ca = (uchar *)malloc((size_t)K * M);
+    cb = (uchar *)malloc((size_t)L * N);
+    if (!ca || !cb) mz_fatalf("Ran out of memory trying to allocate %lu.", (unsigned long)((size_t)K * M + (size_t)L * N));
+    for (i = 1; i <= M; ++i) memcpy(ca + (size_t)(i - 1) * K, A[i], (size_t)K);
+    for (i = 1; i <= N; ++i) memcpy(cb + (size_t)(i - 1) * L, B[i], (size_t)L);
+    j.K = K; j.L = L; j.M = M; j.N = N; j.A = ca; j.B = cb; j.LB = LB; j.RB = RB;
+
+    rc = mz_yama_batch(1, &j, &o);
+    if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+    if (o.status != MZ_OK) mz_fatal_status(&j, &o);
+    free(ca); free(cb);
+
+    /* two malloc blocks, freed by the caller as free(OAL[1]); free(OAL+1); (mz_yama.h:17-18) */
+    al = (uchar **)malloc((size_t)(o.OM > 0 ? o.OM : 1) * sizeof(uchar *));
+    if (!al) mz_fatalf("Ran out of memory trying to allocate %lu.", (unsigned long)(o.OM * sizeof(uchar *)));
+    al -= 1;
+    al[1] = o.cols;
+    for (i = 2; i <= o.OM; ++i) al[i] = al[i - 1] + (K + L);
+    *OAL = al;
+    *OM = o.OM;
+}
