@@ -1,0 +1,113 @@
+/* mz_synth.c -- synthetic block-pair batches for the benchmark and the large-size tests
+ * (SURVEY.md section 8d).  Not part of the reference; it only produces inputs in the packed
+ * layout of include/mz_amd.h.
+ *
+ * Generator: xorshift64, base seed 88172645463325252; pair p of a batch uses its own stream
+ * seeded from (seed, p) so that batches can be generated in shards (one per rank) and stay
+ * identical to the unsharded batch.
+ *   A: M columns of K bytes; a byte is '-' with probability 0.08, else uniform over ACGT;
+ *      every column keeps at least one non-dash.  5 % of the columns carry lowercase / N bytes.
+ *   B: column j <= M copies A[j][k mod K], is substituted with probability 0.10, then dashed
+ *      with probability 0.08 (>= 1 non-dash per column); columns j > M are random.
+ *   band "diag": LB[i] = RB[i] = floor(i*N/M), LB[0] = 0, then smooth(LB, RB, M, N, radius).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/mz_amd.h"
+#include "../../include/mz_preyama.h"
+
+typedef struct { uint64_t s; } rng_t;
+
+static uint64_t xs64(rng_t *r)
+{
+    uint64_t x = r->s;
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return r->s = x;
+}
+static void rng_seed(rng_t *r, uint64_t seed, uint64_t stream)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (stream + 1);      /* splitmix64 scramble */
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    r->s = z ? z : 88172645463325252ULL;
+    xs64(r); xs64(r);
+}
+static unsigned below(rng_t *r, unsigned n) { return (unsigned)((xs64(r) >> 11) % n); }
+static int chance(rng_t *r, unsigned per_mille) { return below(r, 1000) < per_mille; }
+
+/* shapes of pair p: rows fixed, columns uniform in [lo, hi] */
+void mz_synth_shapes(int n, uint64_t seed, int64_t first_pair, int K, int L, int mlo, int mhi,
+                     int32_t *aK, int32_t *aL, int32_t *aM, int32_t *aN,
+                     int64_t *offA, int64_t *offB, int64_t *offBand, int64_t totals[3])
+{
+    int64_t oa = 0, ob = 0, oband = 0;
+    int p;
+    for (p = 0; p < n; ++p) {
+        rng_t r;
+        rng_seed(&r, seed, (uint64_t)(first_pair + p));
+        aK[p] = K; aL[p] = L;
+        aM[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        aN[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        offA[p] = oa; offB[p] = ob; offBand[p] = oband;
+        oa += (int64_t)aK[p] * aM[p]; ob += (int64_t)aL[p] * aN[p]; oband += aM[p] + 1;
+    }
+    totals[0] = oa; totals[1] = ob; totals[2] = oband;
+}
+
+static unsigned char base_byte(rng_t *r, int odd)
+{
+    static const char acgt[4] = { 'A', 'C', 'G', 'T' };
+    static const char other[6] = { 'a', 'c', 'g', 't', 'N', 'n' };
+    if (odd && chance(r, 500)) return (unsigned char)other[below(r, 6)];
+    return (unsigned char)acgt[below(r, 4)];
+}
+
+void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius,
+                   const int32_t *aK, const int32_t *aL, const int32_t *aM, const int32_t *aN,
+                   const int64_t *offA, const int64_t *offB, const int64_t *offBand,
+                   uint8_t *poolA, uint8_t *poolB, int32_t *poolLB, int32_t *poolRB)
+{
+    int p;
+    for (p = 0; p < n; ++p) {
+        const int K = aK[p], L = aL[p], M = aM[p], N = aN[p];
+        uint8_t *A = poolA + offA[p], *B = poolB + offB[p];
+        int32_t *LB = poolLB + offBand[p], *RB = poolRB + offBand[p];
+        rng_t r;
+        int i, k;
+
+        rng_seed(&r, seed ^ 0xA5A5A5A5ULL, (uint64_t)(first_pair + p));
+        for (i = 0; i < M; ++i) {
+            const int odd = chance(&r, 50);
+            int nd = 0;
+            for (k = 0; k < K; ++k) {
+                unsigned char ch = chance(&r, 80) ? '-' : base_byte(&r, odd);
+                A[(size_t)i * K + k] = ch;
+                nd += ch != '-';
+            }
+            if (!nd) A[(size_t)i * K + below(&r, (unsigned)K)] = base_byte(&r, 0);
+        }
+        for (i = 0; i < N; ++i) {
+            const int odd = chance(&r, 50);
+            int nd = 0;
+            for (k = 0; k < L; ++k) {
+                unsigned char ch;
+                if (i < M) {
+                    ch = A[(size_t)i * K + (k % K)];
+                    if (ch == '-' || chance(&r, 100)) ch = base_byte(&r, odd);
+                } else {
+                    ch = base_byte(&r, odd);
+                }
+                if (chance(&r, 80)) ch = '-';
+                B[(size_t)i * L + k] = ch;
+                nd += ch != '-';
+            }
+            if (!nd) B[(size_t)i * L + below(&r, (unsigned)L)] = base_byte(&r, 0);
+        }
+        for (i = 0; i <= M; ++i)
+            LB[i] = RB[i] = (int32_t)(((int64_t)i * N) / M);
+        LB[0] = 0;
+        smooth(LB, RB, M, N, radius);
+    }
+}

@@ -1,0 +1,68 @@
+"""Synthetic block-pair batches in the packed layout of include/mz_amd.h.
+Thin binding of mz_synth_shapes()/mz_synth_fill() in libmzamd.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .api import lib
+
+BASE_SEED = 88172645463325252
+
+# BASELINE.json configs -> (K, L, columns lo, columns hi, pairs, radius)
+CONFIGS = {
+    "c1": dict(K=2, L=1, mlo=180, mhi=220, pairs=100, radius=30),
+    "c2": dict(K=2, L=2, mlo=900, mhi=1100, pairs=50000, radius=30),
+    "c3": dict(K=10, L=10, mlo=1800, mhi=2200, pairs=5000, radius=30),
+    "c5": dict(K=2, L=2, mlo=95000, mhi=105000, pairs=1000, radius=30),
+}
+
+
+def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, seed: int = BASE_SEED,
+               first_pair: int = 0) -> dict:
+    l = lib()
+    aK, aL, aM, aN = (np.zeros(n, dtype=np.int32) for _ in range(4))
+    oA, oB, oBand = (np.zeros(n, dtype=np.int64) for _ in range(3))
+    tot = (C.c_int64 * 3)()
+    l.mz_synth_shapes.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
+    l.mz_synth_shapes(n, seed, first_pair, K, L, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
+                      oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
+    poolA = np.zeros(max(tot[0], 1), dtype=np.uint8)
+    poolB = np.zeros(max(tot[1], 1), dtype=np.uint8)
+    poolLB = np.zeros(max(tot[2], 1), dtype=np.int32)
+    poolRB = np.zeros(max(tot[2], 1), dtype=np.int32)
+    l.mz_synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int] + [C.c_void_p] * 11
+    l.mz_synth_fill(n, seed, first_pair, radius, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
+                    oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data,
+                    poolA.ctypes.data, poolB.ctypes.data, poolLB.ctypes.data, poolRB.ctypes.data)
+    return dict(K=aK, L=aL, M=aM, N=aN, offA=oA, offB=oB, offBand=oBand,
+                poolA=poolA, poolB=poolB, poolLB=poolLB, poolRB=poolRB)
+
+
+def pair_of(batch: dict, i: int):
+    K, L, M, N = (int(batch[k][i]) for k in ("K", "L", "M", "N"))
+    a0, b0, d0 = int(batch["offA"][i]), int(batch["offB"][i]), int(batch["offBand"][i])
+    A = batch["poolA"][a0: a0 + K * M].reshape(M, K)
+    B = batch["poolB"][b0: b0 + L * N].reshape(N, L)
+    return A, B, batch["poolLB"][d0: d0 + M + 1], batch["poolRB"][d0: d0 + M + 1]
+
+
+def subset(batch: dict, idx) -> dict:
+    """re-pack the chosen pairs into a new batch (used for the CPU-baseline sample)"""
+    idx = np.asarray(idx)
+    out = {k: batch[k][idx].copy() for k in ("K", "L", "M", "N")}
+    pa, pb, plb, prb, oa, ob, od = [], [], [], [], [], [], []
+    a = b = d = 0
+    for i in idx:
+        A, B, LB, RB = pair_of(batch, int(i))
+        oa.append(a); ob.append(b); od.append(d)
+        pa.append(A.ravel()); pb.append(B.ravel()); plb.append(LB); prb.append(RB)
+        a += A.size; b += B.size; d += LB.size
+    out.update(offA=np.array(oa, dtype=np.int64), offB=np.array(ob, dtype=np.int64), offBand=np.array(od, dtype=np.int64),
+               poolA=np.concatenate(pa), poolB=np.concatenate(pb), poolLB=np.concatenate(plb), poolRB=np.concatenate(prb))
+    return out
+
+
+def band_cells(batch: dict) -> int:
+    return int((batch["poolRB"].astype(np.int64) - batch["poolLB"].astype(np.int64) + 1)[: int(batch["offBand"][-1]) + int(batch["M"][-1]) + 1].sum())

@@ -34,7 +34,7 @@ def build(force: bool = False) -> None:
     """compile liboracle.so (and oracle/_ref when /root/reference is present)"""
     if force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
-        for f in ("yama_oracle.c", "yama_profile_oracle.c", "oracle.h")
+        for f in ("yama_oracle.c", "yama_profile_oracle.c", "ref_batch.c", "oracle.h")
     ):
         subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and not os.path.exists(REF_PATH):
@@ -149,6 +149,40 @@ def fnv1a(data: bytes, h: int = 0) -> int:
         h ^= b
         h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+def fnv1a_np(arr: np.ndarray, h: int = 0) -> int:
+    """FNV-1a 64 over a contiguous byte array, in C (mzo_fnv1a)"""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    f = lib().mzo_fnv1a
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
+    return int(f(arr.ctypes.data, arr.size, h))
+
+
+def _batch_args(batch: dict):
+    arrs = [np.ascontiguousarray(batch[k], dtype=np.int32) for k in ("K", "L", "M", "N")]
+    offs = [np.ascontiguousarray(batch[k], dtype=np.int64) for k in ("offA", "offB", "offBand")]
+    pools = [np.ascontiguousarray(batch["poolA"], dtype=np.uint8), np.ascontiguousarray(batch["poolB"], dtype=np.uint8),
+             np.ascontiguousarray(batch["poolLB"], dtype=np.int32), np.ascontiguousarray(batch["poolRB"], dtype=np.int32)]
+    return arrs + offs + pools
+
+
+def ref_batch(batch: dict, threads: int = 1, path: str = REF_PATH):
+    """the compiled reference's own yama() over a packed batch (OpenMP, one pair per thread).
+    Returns (om, hash, cells, n_rejected)."""
+    n = len(batch["K"])
+    om = np.zeros(n, dtype=np.int32)
+    hs = np.zeros(n, dtype=np.uint64)
+    cells = C.c_int64(0)
+    keep = _batch_args(batch)
+    f = lib().mzo_ref_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    bad = f(path.encode(), n, *[a.ctypes.data for a in keep], threads, om.ctypes.data, hs.ctypes.data, C.byref(cells))
+    if bad < 0:
+        raise RuntimeError(f"cannot load the compiled reference {path}")
+    return om, hs, cells.value, bad
 
 
 def yama_batch(batch: dict, sc: Optional[Scores] = None, variant: int = 0, threads: int = 1):

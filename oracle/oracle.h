@@ -19,6 +19,7 @@
 #ifndef MZ_ORACLE_H
 #define MZ_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -32,6 +33,9 @@ extern "C" {
 #define MZO_FC 0
 #define MZO_FI 1
 #define MZO_FD 2
+
+/* bump arena for per-thread scratch (NULL = plain malloc/free) */
+typedef struct mzo_arena { char *base; size_t cap, used; } mzo_arena;
 
 typedef struct mzo_scores {
     int ss[128][128];   /* reference mz_scores.c:34-54  */

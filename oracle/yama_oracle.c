@@ -22,6 +22,30 @@
 #endif
 #include "oracle.h"
 
+/* ------------------------------------------------------------------ scratch memory
+ * A bump arena so that the batch driver can reuse one block per thread instead of paying
+ * malloc/free (and the mm system calls behind them) once per block pair. NULL arena = malloc. */
+void *mzo__alloc(mzo_arena *ar, size_t bytes, int zero)
+{
+    void *p;
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (ar == NULL) return zero ? calloc(bytes ? bytes : 64, 1) : malloc(bytes ? bytes : 64);
+    if (ar->used + bytes > ar->cap) return NULL;
+    p = ar->base + ar->used;
+    ar->used += bytes;
+    if (zero) memset(p, 0, bytes);
+    return p;
+}
+void mzo__free(mzo_arena *ar, void *p) { if (ar == NULL) free(p); }
+
+/* bytes of scratch one pair needs (both restatements), generously rounded */
+size_t mzo__scratch_bytes(int K, int L, int M, int N, int64_t cells)
+{
+    size_t m = (size_t)M + 2, n = (size_t)N + 2;
+    return m * K + n * L + (size_t)cells + 8 * m + 12 * n + (m + n) + (m + n) * (size_t)(K + L)
+           + 72 * (m + n) + 64 * 16;
+}
+
 /* ------------------------------------------------------------------ score tables */
 
 static void fill_scores(mzo_scores *sc, const int sub[4][4], int filler, int open_, int ext)
@@ -132,6 +156,12 @@ void mzo_smooth(int *LB, int *RB, int M, int N, int radius)
 }
 
 typedef struct { int32_t C, D, I; } tri;
+int mzo__faithful(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+                  const int *LB, const int *RB, const mzo_scores *sc,
+                  uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out);
+int mzo__profile(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+                 const int *LB, const int *RB, const mzo_scores *sc,
+                 uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out);
 static const tri TRI_NEG = { MZO_NEG, MZO_NEG, MZO_NEG };
 
 /* three-way choice with the interior tie order: C-pred wins ties, then D only if
@@ -162,11 +192,11 @@ static int32_t gap_sum(const mzo_scores *sc, const uint8_t *s, const uint8_t *t,
 
 /* ------------------------------------------------------------------ traceback + emit
  * shared by both restatements (they differ only in how a cell's sums are evaluated) */
-int mzo__trace_emit(const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+int mzo__trace_emit(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
                     const int *LB, const uint8_t *tb, const int64_t *rowoff,
                     tri last, uint8_t *out, int *OM)
 {
-    uint8_t *ops = (uint8_t *)malloc((size_t)(M + N) + 1);
+    uint8_t *ops = (uint8_t *)mzo__alloc(ar, (size_t)(M + N) + 1, 0);
     int r = M, c = N, n = 0, i, j, m, k;
     unsigned node;
 
@@ -177,15 +207,15 @@ int mzo__trace_emit(const uint8_t *A, int K, int M, const uint8_t *B, int L, int
 
     while (r > 0 || c > 0) {
         unsigned st;
-        if (r < 0 || c < 0 || n >= M + N) { free(ops); return MZO_E_TRACEBACK; }
+        if (r < 0 || c < 0 || n >= M + N) { mzo__free(ar, ops); return MZO_E_TRACEBACK; }
         st = tb[rowoff[r] + (c - LB[r])];
         ops[n++] = (uint8_t)node;
         if (node == MZO_FI)      { c--;      node = (st >> 4) & 3; }
         else if (node == MZO_FD) { r--;      node = (st >> 2) & 3; }
         else if (node == MZO_FC) { r--; c--; node = st & 3; }
-        else { free(ops); return MZO_E_TRACEBACK; }
+        else { mzo__free(ar, ops); return MZO_E_TRACEBACK; }
     }
-    if (r != 0 || c != 0) { free(ops); return MZO_E_TRACEBACK; }
+    if (r != 0 || c != 0) { mzo__free(ar, ops); return MZO_E_TRACEBACK; }
 
     *OM = n;
     i = j = m = 0;
@@ -199,7 +229,7 @@ int mzo__trace_emit(const uint8_t *A, int K, int M, const uint8_t *B, int L, int
             memcpy(col, A + (size_t)i * K, K); memset(col + K, '-', L); ++i;
         }
     }
-    free(ops);
+    mzo__free(ar, ops);
     return (i == M && j == N) ? MZO_OK : MZO_E_EMIT;
 }
 
@@ -207,6 +237,13 @@ int mzo__trace_emit(const uint8_t *A, int K, int M, const uint8_t *B, int L, int
 int mzo_yama_faithful(const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
                       const int *LB, const int *RB, const mzo_scores *sc,
                       uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out)
+{
+    return mzo__faithful(NULL, A, K, M, B, L, N, LB, RB, sc, out, OM, final3, tb_out);
+}
+
+int mzo__faithful(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+                  const int *LB, const int *RB, const mzo_scores *sc,
+                  uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out)
 {
     int64_t cells, *rowoff;
     uint8_t *tb, *dashA, *dashB, *tp;
@@ -220,16 +257,16 @@ int mzo_yama_faithful(const uint8_t *A, int K, int M, const uint8_t *B, int L, i
     /* dash flags; index 0 is an all-zero sentinel column so that "previous column of
      * column 1" reads as non-dash -- that is what the r>1 / c>1 tests in
      * mz_yama.c:128,174,211 amount to */
-    dashA = (uint8_t *)calloc((size_t)(M + 1) * K, 1);
-    dashB = (uint8_t *)calloc((size_t)(N + 1) * L, 1);
+    dashA = (uint8_t *)mzo__alloc(ar, (size_t)(M + 1) * K, 1);
+    dashB = (uint8_t *)mzo__alloc(ar, (size_t)(N + 1) * L, 1);
     for (r = 1; r <= M; ++r)
         for (i = 0; i < K; ++i) dashA[(size_t)r*K + i] = (A[(size_t)(r-1)*K + i] == '-');
     for (c = 1; c <= N; ++c)
         for (j = 0; j < L; ++j) dashB[(size_t)c*L + j] = (B[(size_t)(c-1)*L + j] == '-');
 
-    tb = tb_out ? tb_out : (uint8_t *)malloc((size_t)cells);
-    rowoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(M + 1));
-    dp = (tri *)malloc(sizeof(tri) * (size_t)(N + 1));
+    tb = tb_out ? tb_out : (uint8_t *)mzo__alloc(ar, (size_t)cells, 0);
+    rowoff = (int64_t *)mzo__alloc(ar, sizeof(int64_t) * (size_t)(M + 1), 0);
+    dp = (tri *)mzo__alloc(ar, sizeof(tri) * (size_t)(N + 1), 0);
 
     /* row 0: only insertions; extension charged, never an open (mz_yama.c:83-94) */
     tp = tb;
@@ -316,10 +353,10 @@ int mzo_yama_faithful(const uint8_t *A, int K, int M, const uint8_t *B, int L, i
     }
 
     if (final3) { final3[0] = left.C; final3[1] = left.D; final3[2] = left.I; }
-    rc = mzo__trace_emit(A, K, M, B, L, N, LB, tb, rowoff, left, out, OM);
+    rc = mzo__trace_emit(ar, A, K, M, B, L, N, LB, tb, rowoff, left, out, OM);
 
-    free(dp); free(rowoff); free(dashA); free(dashB);
-    if (!tb_out) free(tb);
+    mzo__free(ar, dp); mzo__free(ar, rowoff); mzo__free(ar, dashA); mzo__free(ar, dashB);
+    if (!tb_out) mzo__free(ar, tb);
     return rc;
 }
 
@@ -332,36 +369,52 @@ int mzo_yama_batch(int n, const int *K, const int *L, const int *M, const int *N
 {
     int bad = 0;
     int64_t total = 0;
+    size_t need = 0;
     int p;
 
+    for (p = 0; p < n; ++p) {          /* scratch for the largest pair (full-grid bound on cells is too big: use the band) */
+        int64_t cells = 0;
+        size_t b;
+        if (mzo_yama_check(M[p], N[p], poolLB + offBand[p], poolRB + offBand[p], &cells, NULL)) cells = 0;
+        b = mzo__scratch_bytes(K[p], L[p], M[p], N[p], cells);
+        if (b > need) need = b;
+    }
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #else
     (void)threads;
 #endif
-#pragma omp parallel for schedule(dynamic, 1) reduction(+:bad, total)
-    for (p = 0; p < n; ++p) {
-        uint8_t *out = (uint8_t *)malloc((size_t)(M[p] + N[p]) * (size_t)(K[p] + L[p]) + 1);
-        int64_t cells = 0;
-        int m_new = 0, rc;
-        if (variant == 0)
-            rc = mzo_yama_faithful(poolA + offA[p], K[p], M[p], poolB + offB[p], L[p], N[p],
+#pragma omp parallel reduction(+:bad, total)
+    {
+        mzo_arena ar;
+        ar.base = (char *)malloc(need + 4096);
+        ar.cap = need + 4096;
+#pragma omp for schedule(dynamic, 1)
+        for (p = 0; p < n; ++p) {
+            uint8_t *out;
+            int64_t cells = 0;
+            int m_new = 0, rc;
+            ar.used = 0;
+            out = (uint8_t *)mzo__alloc(&ar, (size_t)(M[p] + N[p]) * (size_t)(K[p] + L[p]) + 1, 0);
+            if (variant == 0)
+                rc = mzo__faithful(&ar, poolA + offA[p], K[p], M[p], poolB + offB[p], L[p], N[p],
                                    poolLB + offBand[p], poolRB + offBand[p], sc, out, &m_new, NULL, NULL);
-        else
-            rc = mzo_yama_profile(poolA + offA[p], K[p], M[p], poolB + offB[p], L[p], N[p],
+            else
+                rc = mzo__profile(&ar, poolA + offA[p], K[p], M[p], poolB + offB[p], L[p], N[p],
                                   poolLB + offBand[p], poolRB + offBand[p], sc, out, &m_new, NULL, NULL);
-        if (rc) {
-            bad++;
-            om[p] = -rc;
-            hash[p] = 0;
-        } else {
-            uint64_t h = mzo_fnv1a((const uint8_t *)&m_new, 4, 0);
-            om[p] = m_new;
-            hash[p] = mzo_fnv1a(out, (int64_t)m_new * (K[p] + L[p]), h);
-            mzo_yama_check(M[p], N[p], poolLB + offBand[p], poolRB + offBand[p], &cells, NULL);
-            total += cells;
+            if (rc) {
+                bad++;
+                om[p] = -rc;
+                hash[p] = 0;
+            } else {
+                uint64_t h = mzo_fnv1a((const uint8_t *)&m_new, 4, 0);
+                om[p] = m_new;
+                hash[p] = mzo_fnv1a(out, (int64_t)m_new * (K[p] + L[p]), h);
+                mzo_yama_check(M[p], N[p], poolLB + offBand[p], poolRB + offBand[p], &cells, NULL);
+                total += cells;
+            }
         }
-        free(out);
+        free(ar.base);
     }
     if (cells_done) *cells_done = total;
     return bad;

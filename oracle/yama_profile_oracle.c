@@ -23,7 +23,9 @@
 typedef struct { int32_t C, D, I; } tri;
 static const tri TRI_NEG = { MZO_NEG, MZO_NEG, MZO_NEG };
 
-int mzo__trace_emit(const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+void *mzo__alloc(mzo_arena *ar, size_t bytes, int zero);
+void mzo__free(mzo_arena *ar, void *p);
+int mzo__trace_emit(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
                     const int *LB, const uint8_t *tb, const int64_t *rowoff,
                     tri last, uint8_t *out, int *OM);
 
@@ -97,9 +99,20 @@ static inline int32_t choose(int32_t x, int32_t y, int32_t z, unsigned *flag)
     return z;
 }
 
+int mzo__profile(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+                 const int *LB, const int *RB, const mzo_scores *sc,
+                 uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out);
+
 int mzo_yama_profile(const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
                      const int *LB, const int *RB, const mzo_scores *sc,
                      uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out)
+{
+    return mzo__profile(NULL, A, K, M, B, L, N, LB, RB, sc, out, OM, final3, tb_out);
+}
+
+int mzo__profile(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B, int L, int N,
+                 const int *LB, const int *RB, const mzo_scores *sc,
+                 uint8_t *out, int *OM, int32_t *final3, uint8_t *tb_out)
 {
     int S6[6][6], go, rc, r, c, a, b;
     const int ge = sc->gap_extend;
@@ -112,8 +125,8 @@ int mzo_yama_profile(const uint8_t *A, int K, int M, const uint8_t *B, int L, in
     rc = mzo_yama_check(M, N, LB, RB, &cells, NULL);
     if (rc) return rc;
 
-    PA = (prof *)malloc(sizeof(prof) * (size_t)(M + 1));
-    PB = (prof *)malloc(sizeof(prof) * (size_t)(N + 1));
+    PA = (prof *)mzo__alloc(ar, sizeof(prof) * (size_t)(M + 1), 0);
+    PB = (prof *)mzo__alloc(ar, sizeof(prof) * (size_t)(N + 1), 0);
     build_profiles(A, K, M, PA);
     build_profiles(B, L, N, PB);
     for (r = 1; r <= M; ++r)
@@ -123,9 +136,9 @@ int mzo_yama_profile(const uint8_t *A, int K, int M, const uint8_t *B, int L, in
             PA[r].w[b] = w;
         }
 
-    tb = tb_out ? tb_out : (uint8_t *)malloc((size_t)cells);
-    rowoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(M + 1));
-    dp = (tri *)malloc(sizeof(tri) * (size_t)(N + 1));
+    tb = tb_out ? tb_out : (uint8_t *)mzo__alloc(ar, (size_t)cells, 0);
+    rowoff = (int64_t *)mzo__alloc(ar, sizeof(int64_t) * (size_t)(M + 1), 0);
+    dp = (tri *)mzo__alloc(ar, sizeof(tri) * (size_t)(N + 1), 0);
 
     tp = tb;
     rowoff[0] = 0;
@@ -199,9 +212,9 @@ int mzo_yama_profile(const uint8_t *A, int K, int M, const uint8_t *B, int L, in
     }
 
     if (final3) { final3[0] = left.C; final3[1] = left.D; final3[2] = left.I; }
-    rc = mzo__trace_emit(A, K, M, B, L, N, LB, tb, rowoff, left, out, OM);
+    rc = mzo__trace_emit(ar, A, K, M, B, L, N, LB, tb, rowoff, left, out, OM);
 
-    free(dp); free(rowoff); free(PA); free(PB);
-    if (!tb_out) free(tb);
+    mzo__free(ar, dp); mzo__free(ar, rowoff); mzo__free(ar, PA); mzo__free(ar, PB);
+    if (!tb_out) mzo__free(ar, tb);
     return rc;
 }
