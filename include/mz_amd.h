@@ -59,7 +59,14 @@ enum {
     MZ_E_WORKSPACE = 19    /* workspace too small for this batch (caller must re-plan) */
 };
 
-enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1 };
+/* which DP kernel the plan picked for a pair:
+ *   EXACT : anti-diagonal wavefront, every guard of mz_yama.c evaluated literally (any legal band
+ *           whose rows leave their lane in time: RB[r] - LB[r+64] <= 62)
+ *   STRIP : strip-mined fallback for wider bands
+ *   FAST  : same wavefront for well-formed pairs -- connected band (LB[r] <= RB[r-1]) and scores
+ *           below 2^29 -- where guards that can only touch unreachable (sentinel) states are
+ *           dropped; outputs are identical ("fast path equivalence") */
+enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2 };
 
 typedef struct mz_dev_batch {
     int32_t n;
@@ -74,6 +81,8 @@ typedef struct mz_dev_batch {
     int32_t *badrow;       /* row index for the error message     */
     int32_t *mode;         /* MZ_MODE_*                           */
     int64_t *cells;        /* tback_size, reference mz_yama.c:60-66 */
+    int32_t *edgeLo;       /* last step with a cell in column <= 1   (fast kernel phases) */
+    int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut;      /* per-pair sizes (dwords, bytes, bytes) */
     int64_t *offTb, *offScript, *offOut;   /* exclusive prefix sums of the above    */
     int64_t *totals;       /* [0..2] totals of the three, [3] = number of failed pairs */
@@ -90,6 +99,7 @@ typedef struct mz_score_model {
     int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */
     int32_t gap_open;      /* the single non-zero value of gop[] (mz_scores.c:78-79)              */
     int32_t gap_extend;
+    int32_t g1, g2;        /* gap_open = g1*g2 with both <= 258 (int16 dot-product operands); 0 = none */
 } mz_score_model;
 
 

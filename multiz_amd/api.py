@@ -38,7 +38,7 @@ class Out(C.Structure):
 class DevBatchC(C.Structure):
     _fields_ = [("n", C.c_int32), ("pad_", C.c_int32)] + \
         [(k, C.c_void_p) for k in ("K", "L", "M", "N", "offA", "offB", "offBand", "poolA", "poolB", "poolLB", "poolRB",
-                                   "status", "badrow", "mode", "cells", "szTb", "szScript", "szOut",
+                                   "status", "badrow", "mode", "cells", "edgeLo", "edgeHi", "szTb", "szScript", "szOut",
                                    "offTb", "offScript", "offOut", "totals", "tbw", "script", "out")] + \
         [("capTb", C.c_int64), ("capScript", C.c_int64), ("capOut", C.c_int64), ("om", C.c_void_p), ("final3", C.c_void_p)]
 

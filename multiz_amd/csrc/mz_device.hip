@@ -27,7 +27,7 @@
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
 
-struct ScoreConst { int S6[36]; int go; int ge; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -57,7 +57,7 @@ __device__ __forceinline__ int dot2(int a, int b, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
 }
 // lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
-__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x13C, 0xF, 0xF, false); }
+__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
     const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p];
-    int status = MZ_OK, badrow = -1, mode = MZ_MODE_WF64;
+    int status = MZ_OK, badrow = -1, mode = MZ_MODE_WF64, edgeLo = 0, edgeHi = 0;
     long long cells = 0, szTb = 0;
 
     if (K < 1 || K > 127 || L < 1 || L > 127) status = MZ_E_ROWS;
@@ -92,7 +92,8 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
         else {
             const int need = N < 10 ? N : 10;
             int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
-            int wf_ok = 1;
+            int wf_ok = 1, conn = 1;
+            int rL = 0, rN = M;             // last row with LB[r] <= 1, first row with RB[r] == N
             for (int r = lane; r <= M; r += WAVE) {
                 const int lo = LB[r], hi = RB[r];
                 if (hi - lo < need) key = min(key, (r << 2) | 0);
@@ -102,7 +103,13 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 // a lane must have left row r before row r+64 (same lane) and its right
                 // neighbour's row r+65 need it: RB[r] - LB[r+64] <= 62
                 if (r + WAVE <= M && hi - LB[r + WAVE] > 62) wf_ok = 0;
+                if (r > 0 && lo > RB[r-1]) conn = 0;          // row r would not touch row r-1's band
+                if (lo <= 1) rL = max(rL, r);
+                if (hi == N) rN = min(rN, r);
             }
+            conn = wave_min(conn);
+            rL = -wave_min(-rL);
+            rN = wave_min(rN);
             key = wave_min(key);
             wf_ok = wave_min(wf_ok);
             cells = wave_sum64(cells);
@@ -110,7 +117,12 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 badrow = key >> 2;
                 status = (key & 3) == 0 ? MZ_E_NARROW : (key & 3) == 1 ? MZ_E_LB_MONO : MZ_E_RB_MONO;
             } else if (wf_ok) {
-                mode = MZ_MODE_WF64;
+                // fast kernel: connected band + every reachable score above -2^29 (so that sentinel
+                // states, which sit at about -2^30, can never win a comparison) + factorable gap_open
+                const bool small = (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 29);
+                mode = (conn && small && c_sc.g1 > 0) ? MZ_MODE_FAST : MZ_MODE_WF64;
+                edgeLo = rL + 1;
+                edgeHi = rN + N;
                 szTb = (long long)(((M + N) >> 2) + 1) * WAVE;
             } else {
                 mode = MZ_MODE_STRIP;
@@ -133,6 +145,8 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
         b.status[p] = status;
         b.badrow[p] = badrow;
         b.mode[p] = mode;
+        b.edgeLo[p] = edgeLo;
+        b.edgeHi[p] = edgeHi;
         b.cells[p] = ok ? cells : 0;
         b.szTb[p] = ok ? szTb : 0;
         b.szScript[p] = ok ? (((long long)M + N + 3) & ~3LL) : 0;
@@ -479,6 +493,288 @@ __global__ __launch_bounds__(WAVE) void k_dp_wf64(mz_dev_batch b)
 }
 
 // ------------------------------------------------------------------------------------------
+// fast DP kernel (MZ_MODE_FAST)
+//
+// Same wavefront as k_dp_wf64, for pairs the plan proved well-formed:
+//   (1) the band is connected: LB[r] <= RB[r-1] for every row, so every in-band grid point has at
+//       least one state reachable from (0,0);
+//   (2) K*L*(open+extend+258)*(M+N+2) < 2^29, so every reachable state scores above -2^29.
+// A state is unreachable only when its predecessor POINT lies outside the band (or is a row-0
+// C/D state); the reference gives those states NEG or NEG minus/plus one step's terms, i.e. a
+// value near -2^30, and no chain of them can form because a predecessor point inside the band
+// always contributes a reachable state.  Every guard of mz_yama.c that is false only when the
+// predecessor state is such a sentinel (all LB[r-1]/LB[r-2]/LB[r] tests and the bare "row > 1"
+// tests) therefore only perturbs a value that loses every comparison it takes part in, and
+// reachable values -- hence the traceback along the optimal path and the merged columns -- are
+// unchanged.  The guards that do touch reachable states are kept: no gap-open when entering
+// column 1 (C), none in column 0 or N (D), none on row M (I) -- the first two in the "edge"
+// phases of the step loop only, the last through zeroed row vectors.
+//
+// Arithmetic: gap_open = g1*g2; row vectors carry g1, column vectors carry -g2, both as int16
+// pairs, so that "x -= gap_open * (bilinear count form)" is one or two v_dot2c_i32_i16 with the
+// running value as accumulator.
+// ------------------------------------------------------------------------------------------
+#define FRING 128                 // ring entries; six dword arrays (structure of arrays: conflict-free reads)
+
+struct FastRow {
+    int lo, hi;
+    int pC1x, pC2x, pC1y, pC2z;   // C-state row vectors
+    int pI1, pI2x, pI2z;          // I-state row vectors (zero on row M)
+    int pD1;                      // D-state x row vector
+    int cD;                       // gap_open * nA * L      (D.x constant part and D.z penalty)
+    int penDy;                    // gap_open * L * (nA - PA00)
+    int extD;                     // gap_extend * L * nA
+    int w01, w23, w45;
+};
+
+__device__ __forceinline__ void fast_stage_rows(int blk, int lane, const PairCtx &J, int *recs)
+{
+    const int rr = blk * WAVE + lane + 1;
+    int4 *d = (int4 *)(recs + (((blk & 1) * WAVE) + lane) * REC_DW);
+    if (rr > J.M) {
+        d[0] = make_int4(MZ_BIG, -1, 0, 0); d[1] = make_int4(0, 0, 0, 0);
+        d[2] = make_int4(0, 0, 0, 0);       d[3] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    const int K = J.K, L = J.L;
+    const uint8_t *col = J.A + (long long)(rr - 1) * K;
+    unsigned cnt = 0;
+    int dA = 0, a00 = 0, a11 = 0, other = 0;
+    for (int i = 0; i < K; ++i) {
+        const unsigned ch = col[i];
+        const bool dash = ch == '-';
+        const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
+        const int cl = byte_class(ch);
+        cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+        other += cl == 5;
+        dA += dash;
+        a00 += (!dash) & (!pdash);
+        a11 += dash & pdash;
+    }
+    const int nA = K - dA;
+    int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
+    int w[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
+        w[l] = acc;
+    }
+    const int go = c_sc.go, g1 = c_sc.g1;
+    const bool last = rr >= J.M;                      // row M: trailing end-gaps open for free
+    d[0] = make_int4(J.LB[rr], J.RB[rr], pack2(nA * g1, dA * g1), pack2(-a00 * g1, -a11 * g1));
+    d[1] = make_int4(pack2((nA - a00) * g1, dA * g1), pack2(0, -dA * g1),
+                     last ? 0 : pack2(0, K * g1), last ? 0 : pack2(0, -dA * g1));
+    d[2] = make_int4(last ? 0 : pack2(0, -K * g1), pack2(-a00 * g1, 0), go * nA * L, go * L * (nA - a00));
+    d[3] = make_int4(c_sc.ge * L * nA, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+}
+
+__device__ __forceinline__ void fast_load_rec(FastRow &R, const int *src)
+{
+    const int4 *s = (const int4 *)src;
+    const int4 a = s[0], b = s[1], c = s[2], d = s[3];
+    R.lo = a.x; R.hi = a.y; R.pC1x = a.z; R.pC2x = a.w;
+    R.pC1y = b.x; R.pC2z = b.y; R.pI1 = b.z; R.pI2x = b.w;
+    R.pI2z = c.x; R.pD1 = c.y; R.cD = c.z; R.penDy = c.w;
+    R.extD = d.x; R.w01 = d.y; R.w23 = d.z; R.w45 = d.w;
+}
+
+// ring[f * FRING + (col & (FRING-1))], f = 0..5: v1=(-g2*dB,-g2*nB)  v2=(-g2*PB11,-g2*PB00)
+// cnt01 cnt23 cnt45  extI = gap_extend*K*nB
+__device__ __forceinline__ void fast_stage_bcols(int first, int lane, const PairCtx &J, int *ring)
+{
+    const int cc = first + lane;
+    int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+    if (cc >= 1 && cc <= J.N) {
+        const int L = J.L, g2 = c_sc.g2;
+        const uint8_t *col = J.B + (long long)(cc - 1) * L;
+        unsigned cnt = 0;
+        int dB = 0, b00 = 0, b11 = 0, other = 0;
+        for (int j = 0; j < L; ++j) {
+            const unsigned ch = col[j];
+            const bool dash = ch == '-';
+            const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
+            const int cl = byte_class(ch);
+            cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+            other += cl == 5;
+            dB += dash;
+            b00 += (!dash) & (!pdash);
+            b11 += dash & pdash;
+        }
+        const int nB = L - dB;
+        e0 = pack2(-g2 * dB, -g2 * nB);
+        e1 = pack2(-g2 * b11, -g2 * b00);
+        e2 = pack2(cnt & 0xff, (cnt >> 8) & 0xff);
+        e3 = pack2((cnt >> 16) & 0xff, cnt >> 24);
+        e4 = pack2(dB, other);
+        e5 = c_sc.ge * J.K * nB;
+    }
+    const int i = cc & (FRING - 1);
+    ring[i] = e0; ring[FRING + i] = e1; ring[2 * FRING + i] = e2;
+    ring[3 * FRING + i] = e3; ring[4 * FRING + i] = e4; ring[5 * FRING + i] = e5;
+}
+
+// one cell; EDGE = this step may contain cells in column 0, 1 or N
+template <bool EDGE>
+__device__ __forceinline__ Tri fast_cell(const FastRow &R, int c, int N, const int *ring, Tri left, Tri up, Tri dg, int &tbyte)
+{
+    const int i = c & (FRING - 1);
+    const int v1 = ring[i], v2 = ring[FRING + i];
+    const int c01 = ring[2 * FRING + i], c23 = ring[3 * FRING + i], c45 = ring[4 * FRING + i], extI = ring[5 * FRING + i];
+    Tri o;
+    int fi, fc, fd, x, y, z;
+
+    // I: x -= go*(K*nB - dA*PB00), y -= go*K*nB, z -= go*K*(nB - PB00)   (row vectors zero on row M)
+    x = dot2(R.pI2x, v2, dot2(R.pI1, v1, left.C));
+    y = dot2(R.pI1, v1, left.D);
+    z = dot2(R.pI2z, v2, dot2(R.pI1, v1, left.I));
+    o.I = pick(x, y, z, MZ_FD << 4, MZ_FI << 4, fi) - extI;
+
+    // C
+    x = dot2(R.pC2x, v2, dot2(R.pC1x, v1, dg.C));
+    y = dot2(R.pC1y, v1, dg.D);
+    z = dot2(R.pC2z, v2, dot2(R.pC1x, v1, dg.I));
+    if (EDGE) {                                   // no gap-open when entering column 1 (mz_yama.c:173)
+        const bool g = c > 1;
+        x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
+    }
+    x = pick(x, y, z, MZ_FD, MZ_FI, fc);
+    o.C = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, x)));
+
+    // D
+    x = dot2(R.pD1, v1, up.C - R.cD);
+    y = up.D - R.penDy;
+    z = up.I - R.cD;
+    if (EDGE) {                                   // none in the first or last column (mz_yama.c:211)
+        const bool g = (c > 0) & (c < N);
+        x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
+    }
+    o.D = pick(x, y, z, MZ_FD << 2, MZ_FI << 2, fd) - R.extD;
+
+    tbyte = fc | fd | fi;
+    return o;
+}
+
+struct FastState {
+    FastRow R;
+    Tri st, up, dg;
+    int r;
+    unsigned tbword;
+    int rlo, lfin, tfin, cst;
+};
+
+template <bool EDGE>
+__device__ __forceinline__ void fast_steps(FastState &S, int t0, int t1, int lane, const PairCtx &J,
+                                           int *s_rec, int *s_ring, uint32_t *tbw)
+{
+    const int M = J.M, N = J.N;
+    // wave-uniform control state lives in SGPRs
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    t1 = __builtin_amdgcn_readfirstlane(t1);
+    S.rlo = __builtin_amdgcn_readfirstlane(S.rlo);
+    S.lfin = __builtin_amdgcn_readfirstlane(S.lfin);
+    S.tfin = __builtin_amdgcn_readfirstlane(S.tfin);
+    S.cst = __builtin_amdgcn_readfirstlane(S.cst);
+    for (int t = t0; t <= t1; ++t) {
+        S.dg = S.up;
+        S.up.C = ror1(S.st.C); S.up.D = ror1(S.st.D); S.up.I = ror1(S.st.I);
+
+        if (t > S.tfin) {                              // oldest row finished at step t-1
+            const int rn = S.rlo + WAVE;
+            if (lane == S.lfin) {
+                S.r = rn;
+                fast_load_rec(S.R, s_rec + ((((rn - 1) >> 6) & 1) * WAVE + lane) * REC_DW);
+                S.st.C = S.st.D = S.st.I = MZ_NEG;
+            }
+            if (S.lfin == 0) {
+                fast_stage_rows(((rn - 1) >> 6) + 1, lane, J, s_rec);
+                __syncthreads();
+            }
+            S.rlo += 1;
+            S.lfin = (S.lfin + 1) & (WAVE - 1);
+            S.tfin = S.rlo > M ? MZ_BIG : S.rlo + __builtin_amdgcn_readlane(S.R.hi, S.lfin);
+        }
+        if (t - S.rlo > S.cst) {
+            fast_stage_bcols(S.cst + 1, lane, J, s_ring);
+            S.cst += WAVE;
+            __syncthreads();
+        }
+
+        const int c = t - S.r;
+        int tbyte;
+        const Tri nw = fast_cell<EDGE>(S.R, c, N, s_ring, S.st, S.up, S.dg, tbyte);
+        const bool active = (c >= S.R.lo) & (c <= S.R.hi);
+        S.st.C = active ? nw.C : MZ_NEG;
+        S.st.D = active ? nw.D : MZ_NEG;
+        S.st.I = active ? nw.I : MZ_NEG;
+        if (EDGE && S.rlo == 0 && lane == WAVE - 1) { S.st.C = MZ_NEG; S.st.D = MZ_NEG; }   // row 0
+
+        S.tbword = __builtin_amdgcn_alignbyte(tbyte, S.tbword, 1);
+        if ((t & 3) == 3) tbw[(t >> 2) * WAVE + lane] = S.tbword;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
+{
+    __shared__ __attribute__((aligned(16))) int s_rec[2 * WAVE * REC_DW];
+    __shared__ __attribute__((aligned(16))) int s_ring[6 * FRING];
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_FAST) return;
+
+    PairCtx J;
+    J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
+    J.A = b.poolA + b.offA[p]; J.B = b.poolB + b.offB[p];
+    J.LB = b.poolLB + b.offBand[p]; J.RB = b.poolRB + b.offBand[p];
+    const int M = J.M, N = J.N;
+    uint32_t *tbw = b.tbw + b.offTb[p];
+
+    fast_stage_rows(0, lane, J, s_rec);
+    fast_stage_rows(1, lane, J, s_rec);
+    fast_stage_bcols(0, lane, J, s_ring);            // columns 0..63 (column 0 = zero entry)
+    fast_stage_bcols(WAVE, lane, J, s_ring);         // columns 64..127
+    __syncthreads();
+
+    FastState S;
+    S.cst = 2 * WAVE - 1;
+    S.st.C = S.st.D = S.st.I = MZ_NEG;
+    if (lane == WAVE - 1) {                           // row 0 (mz_yama.c:83-94)
+        S.r = 0;
+        S.R.lo = 0; S.R.hi = J.RB[0];
+        S.R.pC1x = S.R.pC2x = S.R.pC1y = S.R.pC2z = S.R.pI1 = S.R.pI2x = S.R.pI2z = S.R.pD1 = 0;
+        S.R.cD = S.R.penDy = S.R.extD = 0; S.R.w01 = S.R.w23 = S.R.w45 = 0;
+        S.st.C = S.st.D = S.st.I = 0;                 // grid point (0,0)
+    } else {
+        S.r = lane + 1;
+        fast_load_rec(S.R, s_rec + lane * REC_DW);
+    }
+    S.rlo = 0; S.lfin = WAVE - 1;
+    S.tfin = __builtin_amdgcn_readlane(S.R.hi, WAVE - 1);
+    S.up.C = S.up.D = S.up.I = MZ_NEG;
+    S.dg = S.up;
+    S.tbword = 0;
+
+    // three phases: steps that may touch column 0/1 (and row 0), the interior, steps that may touch column N
+    const int Tend = M + N;
+    int eLo = max(b.edgeLo[p], J.RB[0] + 1);          // row 0 is live until step RB[0]
+    int eHi = b.edgeHi[p];
+    eLo = min(eLo, Tend);
+    eHi = max(eHi, eLo + 1);
+    fast_steps<true>(S, 1, eLo, lane, J, s_rec, s_ring, tbw);
+    fast_steps<false>(S, eLo + 1, min(eHi - 1, Tend), lane, J, s_rec, s_ring, tbw);
+    fast_steps<true>(S, max(eHi, eLo + 1), Tend, lane, J, s_rec, s_ring, tbw);
+
+    if ((Tend & 3) != 3)
+        tbw[(Tend >> 2) * WAVE + lane] = S.tbword >> (8 * (3 - (Tend & 3)));
+    if (lane == ((M - 1) & (WAVE - 1))) {
+        b.final3[3 * p + 0] = S.st.C;
+        b.final3[3 * p + 1] = S.st.D;
+        b.final3[3 * p + 2] = S.st.I;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
@@ -501,7 +797,7 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
         unsigned stb;
         if (r == 0) {
             stb = MZ_FI << 4;                              // row 0 bytes, mz_yama.c:92
-        } else if (mode == MZ_MODE_WF64) {
+        } else if (mode != MZ_MODE_STRIP) {
             const int t = r + c;
             stb = (tbw[(t >> 2) * WAVE + ((r - 1) & (WAVE - 1))] >> (8 * (t & 3))) & 0xff;
         } else {
@@ -576,6 +872,8 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     for (int i = 0; i < 36; ++i) h.S6[i] = m->S6[i];
     h.go = m->gap_open;
     h.ge = m->gap_extend;
+    h.g1 = m->g1;
+    h.g2 = m->g2;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
     return 0;
@@ -595,6 +893,7 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
 extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)
 {
     if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_dp_fast, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_dp_wf64, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
     CK(hipGetLastError(), "dp launch");
     return 0;

@@ -170,6 +170,14 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
             return set_err("gap-open table entry %d is %d, expected %d (quasi-natural structure)", x, g16[x], want);
     }
     m->gap_extend = ext;
+    /* gap_open = g1*g2, both small enough that 127*g fits an int16 dot-product operand; the fast
+     * kernel needs it (MZ_NO_FAST=1 in the environment disables that kernel: exact kernel only) */
+    m->g1 = m->g2 = 0;
+    if (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0) {
+        if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
+        else for (x = 258; x >= 1; --x)
+            if (m->gap_open % x == 0 && m->gap_open / x <= 258) { m->g1 = x; m->g2 = m->gap_open / x; break; }
+    }
     for (a = 0; a < 36; ++a)
         if (m->S6[a] < -258 || m->S6[a] > 258)      /* 127 rows * |score| must fit the int16 dot-product operand */
             return set_err("substitution score %d too large for the packed int16 row vector", m->S6[a]);
@@ -211,7 +219,7 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t mz_dev_plan_bytes(int n)
 {
     size_t s = 0, N = (size_t)(n > 0 ? n : 1);
-    s += 3 * al256(4 * N);                 /* status, badrow, mode */
+    s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
     s += 7 * al256(8 * N);                 /* cells, 3 sizes, 3 offsets */
     s += al256(8 * 4);                     /* totals */
     s += al256(4 * N) + al256(12 * N);     /* om, final3 */
@@ -224,6 +232,7 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     size_t N = (size_t)(b->n > 0 ? b->n : 1);
 #define TAKE(field, type, bytes) do { b->field = (type)p; p += al256(bytes); } while (0)
     TAKE(status, int32_t *, 4 * N); TAKE(badrow, int32_t *, 4 * N); TAKE(mode, int32_t *, 4 * N);
+    TAKE(edgeLo, int32_t *, 4 * N); TAKE(edgeHi, int32_t *, 4 * N);
     TAKE(cells, int64_t *, 8 * N);
     TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N);
     TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N);
