@@ -119,6 +119,10 @@ void *mz_stream(void);
  * quasi-natural structure -- true of both reference tables. */
 int  mz_set_scores(const int *ss_flat, const int *gop16, int gap_extend);
 
+/* 0: run every pair on the exact kernels (all guards of mz_yama.c evaluated literally); 1 (default):
+ * let the plan pick the fast kernel for well-formed pairs.  Outputs are identical either way. */
+void mz_enable_fast(int on);
+
 /* ---------------------------------------------------------------- host-buffer batch API */
 
 typedef struct mz_job {

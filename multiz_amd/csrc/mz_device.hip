@@ -127,7 +127,8 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
             } else {
                 mode = MZ_MODE_STRIP;
                 // strips of 64 rows; strip s sweeps columns LB[first]..RB[last] with a 64-step skew.
-                // layout: [2*S header dwords rounded up to 64] + per strip ceil(steps/4)*64 dwords
+                // layout: [2*S header dwords rounded up to 64] [2 boundary rows of 3*(N+1) dwords, rounded]
+                //         + per strip ceil(steps/4)*64 dwords
                 const int S = (M + WAVE - 1) / WAVE;
                 long long acc = 0;
                 for (int s = lane; s < S; s += WAVE) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                     acc += (long long)((steps + 3) >> 2) * WAVE;
                 }
                 acc = wave_sum64(acc);
-                szTb = acc + (((2LL * S) + WAVE - 1) / WAVE) * WAVE;
+                szTb = acc + (((2LL * S) + WAVE - 1) / WAVE) * WAVE + ((6LL * (N + 1) + WAVE - 1) / WAVE) * WAVE;
             }
         }
     }
@@ -775,6 +776,153 @@ __global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
 }
 
 // ------------------------------------------------------------------------------------------
+// strip-mined DP kernel (MZ_MODE_STRIP): any legal band.
+//
+// Rows are processed 64 at a time (lane <-> row of the strip); a strip sweeps the columns
+// LB[first row] .. RB[last row] with the usual one-step skew between lanes.  The row above the
+// strip is read from a boundary row in global memory (64 columns per coalesced load, handed to
+// lane 0 one column per step), the strip's last row is collected the same way and written back
+// for the next strip.  Arithmetic is the exact cell() of k_dp_wf64.  Slower than the rolling
+// wavefront for narrow bands (fill/drain per strip), efficient for wide ones.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_dp_strip(mz_dev_batch b)
+{
+    __shared__ __attribute__((aligned(16))) int  s_rec[2 * WAVE * REC_DW];
+    __shared__ __attribute__((aligned(16))) int4 s_ring[BRING];
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_STRIP) return;
+
+    PairCtx J;
+    J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
+    J.A = b.poolA + b.offA[p]; J.B = b.poolB + b.offB[p];
+    J.LB = b.poolLB + b.offBand[p]; J.RB = b.poolRB + b.offBand[p];
+    const int M = J.M, N = J.N;
+    const int go = c_sc.go, ge = c_sc.ge;
+    const int pkKy = pack4(0, J.K, 0, 0), pkKz = pack4(0, J.K, 0, -J.K);
+    const int S = (M + WAVE - 1) / WAVE;
+    uint32_t *tbw = b.tbw + b.offTb[p];
+    const long long hdrDw = ((2LL * S + WAVE - 1) / WAVE) * WAVE;
+    const long long bndDw = ((6LL * (N + 1) + WAVE - 1) / WAVE) * WAVE;
+    int *bnd = (int *)(tbw + hdrDw);                 // two rows x {C[N+1], D[N+1], I[N+1]}
+    long long dataOff = hdrDw + bndDw;
+    const int NP = N + 1;
+
+    // ---- row 0 (mz_yama.c:83-94) into boundary row 0: C = D = NEG, I = running sum of -nB(c)*K*ge
+    {
+        int *r0 = bnd;
+        int carry = 0;
+        const int hi0 = J.RB[0];
+        for (int c0 = 0; c0 <= hi0; c0 += WAVE) {
+            const int c = c0 + lane;
+            int v = 0;
+            if (c >= 1 && c <= hi0) {
+                const uint8_t *col = J.B + (long long)(c - 1) * J.L;
+                int nb = 0;
+                for (int j = 0; j < J.L; ++j) nb += col[j] != '-';
+                v = -nb * J.K * ge;
+            }
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) { const int u = __shfl_up(v, o); if (lane >= o) v += u; }
+            v += carry;
+            if (c <= hi0) {
+                r0[c] = c == 0 ? 0 : MZ_NEG; r0[NP + c] = c == 0 ? 0 : MZ_NEG; r0[2 * NP + c] = v;
+            }
+            carry = __shfl(v, WAVE - 1);
+        }
+    }
+    __threadfence();
+
+    Tri st = { MZ_NEG, MZ_NEG, MZ_NEG };
+    for (int s = 0; s < S; ++s) {
+        const int first = s * WAVE + 1, last = min(first + WAVE - 1, M), nr = last - first + 1;
+        const int clo = J.LB[first], chi = J.RB[last];
+        const int pLB = J.LB[first - 1], pRB = J.RB[first - 1];
+        const int *prev = bnd + (s & 1) * 3 * NP;
+        int *next = bnd + ((s + 1) & 1) * 3 * NP;
+        const int nsteps = chi - clo + nr;            // tau = 0 .. nsteps-1
+        if (lane == 0) { tbw[2 * s] = (uint32_t)clo; tbw[2 * s + 1] = (uint32_t)dataOff; }
+        uint32_t *tbs = tbw + dataOff;
+        dataOff += (long long)((nsteps + 3) >> 2) * WAVE;
+
+        stage_rows(s, lane, J, s_rec);
+        int staged = (clo >> 6) << 6;                 // B columns are staged in aligned blocks of 64
+        stage_bcols(staged, lane, J, s_ring);         // (column 0 and columns > N get the zero entry)
+        staged += WAVE;
+        __syncthreads();
+        RowRegs R;
+        load_rec(R, s_rec + (((s & 1) * WAVE) + lane) * REC_DW);
+        const int r = first + lane;
+
+        st.C = st.D = st.I = MZ_NEG;
+        Tri up = { MZ_NEG, MZ_NEG, MZ_NEG }, dg;
+        // lane 0's diagonal predecessor of its first cell: P(first-1, clo-1)
+        if (lane == 0 && clo - 1 >= pLB && clo - 1 <= pRB && clo >= 1) {
+            up.C = prev[clo - 1]; up.D = prev[NP + clo - 1]; up.I = prev[2 * NP + clo - 1];
+        }
+        // hand that value over as "state of the lane before lane 0": emulate by keeping it in `up`
+        // and skipping the first rotate for lane 0 (see below).
+        int pc = MZ_NEG, pd = MZ_NEG, pi = MZ_NEG;    // 64 columns of the row above the strip
+        int cc = MZ_NEG, cd = MZ_NEG, ci = MZ_NEG;    // 64 collected columns of the strip's last row
+        unsigned tbword = 0;
+
+        for (int tau = 0; tau < nsteps; ++tau) {
+            if ((tau & (WAVE - 1)) == 0) {            // next 64 columns of the boundary row
+                const int c = clo + tau + lane;
+                const bool ok = c >= pLB && c <= pRB && c <= N;
+                pc = ok ? prev[c] : MZ_NEG; pd = ok ? prev[NP + c] : MZ_NEG; pi = ok ? prev[2 * NP + c] : MZ_NEG;
+            }
+            if (clo + tau >= staged) {                // lane 0 is about to need column `staged`
+                stage_bcols(staged, lane, J, s_ring);
+                staged += WAVE;
+                __syncthreads();
+            }
+            dg = up;
+            up.C = ror1(st.C); up.D = ror1(st.D); up.I = ror1(st.I);
+            {
+                const int k = tau & (WAVE - 1);
+                const int uc = __builtin_amdgcn_readlane(pc, k), ud = __builtin_amdgcn_readlane(pd, k),
+                          ui = __builtin_amdgcn_readlane(pi, k);
+                if (lane == 0) { up.C = uc; up.D = ud; up.I = ui; }
+            }
+            const int c = clo + tau - lane;
+            const int4 q = s_ring[c & (BRING - 1)];
+            int tbyte;
+            const Tri nw = cell(R, c, N, q, st, up, dg, pkKy, pkKz, go, ge, tbyte);
+            const bool active = (r <= M) & (c >= R.lo) & (c <= R.hi);
+            st.C = active ? nw.C : MZ_NEG;
+            st.D = active ? nw.D : MZ_NEG;
+            st.I = active ? nw.I : MZ_NEG;
+
+            tbword = __builtin_amdgcn_alignbyte(tbyte, tbword, 1);
+            if ((tau & 3) == 3) tbs[(tau >> 2) * WAVE + lane] = tbword;
+
+            // collect the last row of the strip: at step tau it is at column clo + tau - (nr-1)
+            const int kcol = tau - (nr - 1);
+            if (kcol >= 0) {
+                const int lc = __builtin_amdgcn_readlane(st.C, nr - 1), ld = __builtin_amdgcn_readlane(st.D, nr - 1),
+                          li = __builtin_amdgcn_readlane(st.I, nr - 1);
+                if (lane == (kcol & (WAVE - 1))) { cc = lc; cd = ld; ci = li; }
+                if ((kcol & (WAVE - 1)) == WAVE - 1 || tau == nsteps - 1) {
+                    const int cbase = clo + (kcol & ~(WAVE - 1));
+                    const int c2 = cbase + lane;
+                    if (lane <= (kcol & (WAVE - 1)) && c2 <= N) { next[c2] = cc; next[NP + c2] = cd; next[2 * NP + c2] = ci; }
+                }
+            }
+        }
+        if ((nsteps & 3) != 0)
+            tbs[((nsteps - 1) >> 2) * WAVE + lane] = tbword >> (8 * (4 - (nsteps & 3)));
+        __threadfence();                              // boundary row visible to the next strip's loads
+        __syncthreads();
+    }
+    if (lane == ((M - 1) & (WAVE - 1))) {
+        b.final3[3 * p + 0] = st.C;
+        b.final3[3 * p + 1] = st.D;
+        b.final3[3 * p + 2] = st.I;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
@@ -895,6 +1043,7 @@ extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)
     if (b->n <= 0) return 0;
     hipLaunchKernelGGL(k_dp_fast, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_dp_wf64, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_dp_strip, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }

@@ -135,6 +135,8 @@ static int ensure_init(void)
 
 /* ------------------------------------------------------------------ scores */
 
+static int g_no_fast;                      /* mz_enable_fast(0): exact kernels only */
+
 static int class_of(int ch)
 {
     switch (ch) {
@@ -173,7 +175,7 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     /* gap_open = g1*g2, both small enough that 127*g fits an int16 dot-product operand; the fast
      * kernel needs it (MZ_NO_FAST=1 in the environment disables that kernel: exact kernel only) */
     m->g1 = m->g2 = 0;
-    if (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0) {
+    if (!g_no_fast && (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0)) {
         if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
         else for (x = 258; x >= 1; --x)
             if (m->gap_open % x == 0 && m->gap_open / x <= 258) { m->g1 = x; m->g2 = m->gap_open / x; break; }
@@ -196,6 +198,15 @@ int mz_set_scores(const int *ss_flat, const int *gop16, int ext)
     G.ss_seen = NULL;
     mz_scores_explicit = 1;                /* keep them until init_scores70/85() is called again */
     return 0;
+}
+
+/* Switch the fast DP kernel off (exact kernels only) or back on; used by the parity tests to
+ * exercise both kernels on the same inputs.  Takes effect with the next call. */
+void mz_enable_fast(int on)
+{
+    g_no_fast = !on;
+    G.scores_ok = 0;                       /* force the score model (which carries g1,g2) to be re-sent */
+    mz_scores_explicit = 0;
 }
 
 /* hand the reference-style globals (ss, gop, gap_extend) to the device if they changed */

@@ -1,0 +1,190 @@
+/* mz_maf.c -- the few MAF block helpers that pre_yama()/mafBuild() lean on, restated so that
+ * libmzamd.so is self-contained (reference maf.c:251-377,437-451; multi_util.c:570-645,889-906).
+ * An executable that also links the reference's own maf.o / multi_util.o keeps using those
+ * (its definitions take precedence over a shared library's).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/maf.h"
+#include "../../include/mz_scores.h"
+
+__attribute__((noreturn)) void mz_fatalf(const char *fmt, ...);
+
+int row2 = 0;      /* reference multi_util.c:24: "only print blocks with >= 2 rows" switch of the drivers */
+
+static void *xmalloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) mz_fatalf("Ran out of memory trying to allocate %lu.", (unsigned long)n);
+    return p;
+}
+
+static char *dup_or_null(const char *s)
+{
+    char *p;
+    if (!s) return NULL;
+    p = (char *)xmalloc(strlen(s) + 1);
+    return strcpy(p, s);
+}
+
+/* a fresh row with the bookkeeping fields of t and no text yet (reference maf.c:437-451) */
+struct mafComp *mafCpyComp(struct mafComp *t)
+{
+    struct mafComp *c = (struct mafComp *)xmalloc(sizeof *c);
+    memset(c, 0, sizeof *c);
+    c->src = dup_or_null(t->src);
+    c->name = dup_or_null(t->name);
+    c->contig = dup_or_null(t->contig);
+    c->srcSize = t->srcSize;
+    c->start = t->start;
+    c->size = t->size;
+    c->strand = t->strand;
+    c->paralog = t->paralog;
+    return c;
+}
+
+void mafCompFree(struct mafComp **pc)
+{
+    struct mafComp *c = *pc;
+    if (!c) return;
+    free(c->src); free(c->text); free(c->contig); free(c->name); free(c->mafPosMap);
+    free(c);
+    *pc = NULL;
+}
+
+void mafAliFree(struct mafAli **pa)
+{
+    struct mafComp *c, *nx;
+    if (!pa || !*pa) return;
+    for (c = (*pa)->components; c; c = nx) { nx = c->next; mafCompFree(&c); }
+    free(*pa);
+    *pa = NULL;
+}
+
+static int digits10(int x)
+{
+    int n = 1;
+    if (x < 0) mz_fatalf("digitsBaseTen: negative argument %d", x);
+    while (x >= 10) { x /= 10; ++n; }
+    return n;
+}
+
+/* the source name as the reference re-assembles it for printing (multi_util.c:889-906,
+ * maf.c:283-288): <part before the first '.'> '.' <rest>; the rest is dropped when it is empty
+ * or equal to the first part (so "x.x" prints as "x") */
+static void printable_src(const char *src, char *out, size_t cap)
+{
+    const char *dot = strchr(src, '.');
+    size_t n = dot ? (size_t)(dot - src) : strlen(src);
+    const char *rest = (dot && dot[1] != '\0') ? dot + 1 : NULL;
+    if (n >= cap) n = cap - 1;
+    memcpy(out, src, n);
+    out[n] = '\0';
+    if (rest && strcmp(out, rest) != 0)
+        snprintf(out + n, cap - n, ".%s", rest);
+}
+
+/* one block in MAF text, column-aligned the way the reference writer does it (maf.c:251-294) */
+void mafWrite(FILE *f, struct mafAli *a)
+{
+    struct mafComp *c;
+    int wsrc = 0, wstart = 0, wsize = 0, wsrcsize = 0, row = 0;
+    char name[512];
+
+    fputs("a", f);
+    if (a->score != MIN_INT) fprintf(f, " score=%3.1f", a->score);
+    for (c = a->components; c; c = c->next, ++row) {
+        if (c->paralog == 'a') fprintf(f, " amplifier=%d", row);
+        else if (c->paralog == 'c') fprintf(f, " copy=%d", row);
+        else if (c->paralog != 's') mz_fatalf("Wrong character: \'%c\'", c->paralog);
+    }
+    fputc('\n', f);
+    for (c = a->components; c; c = c->next) {
+        int n = (int)strlen(c->src);
+        if (n > wsrc) wsrc = n;
+        if ((n = digits10(c->start)) > wstart) wstart = n;
+        if ((n = digits10(c->size)) > wsize) wsize = n;
+        if ((n = digits10(c->srcSize)) > wsrcsize) wsrcsize = n;
+    }
+    for (c = a->components; c; c = c->next) {
+        printable_src(c->src, name, sizeof name);
+        fprintf(f, "s %-*s %*d %*d %c %*d %s\n", wsrc, name, wstart, c->start, wsize, c->size,
+                c->strand, wsrcsize, c->srcSize, c->text);
+    }
+    fputc('\n', f);
+}
+
+/* column (0-based) of sequence position pos in row c (reference multi_util.c:633-645) */
+int mafPos2Col(struct mafComp *c, int pos, int textSize)
+{
+    int col, p = c->start - 1;
+    if (pos < c->start || pos >= c->start + c->size)
+        mz_fatalf("mafPos2Col: %d not in %d-%d", pos, c->start, c->start + c->size - 1);
+    for (col = 0; col < textSize; ++col)
+        if (c->text[col] != '-' && ++p == pos) break;
+    return col;
+}
+
+/* squeeze out columns that are '-' in every row, in place (reference maf.c:357-382) */
+struct mafAli *mafColDashRm(struct mafAli *a)
+{
+    struct mafComp *c;
+    int keep = 0, col;
+    if (!a) return NULL;
+    for (col = 0; col < a->textSize; ++col) {
+        for (c = a->components; c; c = c->next)
+            if (c->text[col] != '-') break;
+        if (!c) continue;
+        if (keep < col)
+            for (c = a->components; c; c = c->next) c->text[keep] = c->text[col];
+        ++keep;
+    }
+    if (keep < a->textSize) {
+        a->textSize = keep;
+        for (c = a->components; c; c = c->next) c->text[keep] = '\0';
+    }
+    return a;
+}
+
+/* columns cbeg..cend of a block as a block of its own: rows without a base are dropped, starts are
+ * advanced past the bases to the left, all-dash columns squeezed out, score recomputed
+ * (reference multi_util.c:570-618) */
+struct mafAli *make_part_ali_col(struct mafAli *ali, int cbeg, int cend)
+{
+    const int width = cend - cbeg + 1;
+    struct mafAli *out;
+    struct mafComp *c, *nc, *tail = NULL;
+
+    if (width == 0) return NULL;
+    out = (struct mafAli *)xmalloc(sizeof *out);
+    memset(out, 0, sizeof *out);
+    out->textSize = width;
+    out->score = mafScoreRange(ali, cbeg, width);        /* also the reference's range check */
+    for (c = ali->components; c; c = c->next) {
+        int before = 0, bases = 0, i;
+        for (i = 0; i < cbeg; ++i) before += c->text[i] != '-';
+        for (i = cbeg; i <= cend; ++i) bases += c->text[i] != '-';
+        if (bases == 0) continue;
+        nc = mafCpyComp(c);
+        nc->start = c->start + before;
+        nc->size = bases;
+        nc->text = (char *)xmalloc((size_t)width + 1);
+        memcpy(nc->text, c->text + cbeg, (size_t)width);
+        nc->text[width] = '\0';
+        if (tail) tail->next = nc; else out->components = nc;
+        tail = nc;
+    }
+    if (!out->components) { mafAliFree(&out); return NULL; }
+    out = mafColDashRm(out);
+    out->score = mafScoreRange(out, 0, out->textSize);
+    return out;
+}
+
+int print_part_ali_col(struct mafAli *ali, int cbeg, int cend, FILE *fp)
+{
+    struct mafAli *part = make_part_ali_col(ali, cbeg, cend);
+    if (part && (row2 == 0 || part->components->next != NULL)) mafWrite(fp, part);
+    mafAliFree(&part);
+    return 0;
+}

@@ -5,6 +5,9 @@
 #include <stdlib.h>
 #include "../../include/mz_preyama.h"
 
+/* the reference's 1-based arrays are freed as free(X + 1): gcc cannot see that X + 1 is the malloc()ed address */
+#pragma GCC diagnostic ignored "-Wfree-nonheap-object"
+
 /* Turn the raw per-row column range implied by the shared reference row into a legal DP band
  * (reference mz_preyama.c:17-35): make LB a running maximum and RB a running minimum from the
  * right, then widen both by rad = min(M, radius) rows/columns. */
@@ -35,4 +38,253 @@ void smooth(int *LB, int *RB, int M, int N, int radius)
         RB[i] = a > RB[i + rad] ? a : RB[i + rad];
     }
     for (; i <= M; ++i) RB[i] = N;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * pre_yama() and its helpers.  Data structures are the reference's (1-based arrays of column
+ * pointers over one contiguous buffer) because yama(), rmColDash(), mapping() and mafBuild() are
+ * link-visible with exactly those conventions.
+ * ------------------------------------------------------------------------------------------------ */
+#include <string.h>
+#include "../../include/mz_scores.h"
+
+__attribute__((noreturn)) void mz_fatalf(const char *fmt, ...);
+
+static void *xmalloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) mz_fatalf("Ran out of memory trying to allocate %lu.", (unsigned long)n);
+    return p;
+}
+
+/* 1-based column pointers over `cols` contiguous columns of `rows` bytes.  One spare byte follows
+ * the data and holds a non-dash: see the note on mapping() in pre_yama(). */
+static uchar **cols_new(int cols, int rows)
+{
+    uchar **X = (uchar **)xmalloc((size_t)(cols > 0 ? cols : 1) * sizeof(uchar *)) - 1;
+    int i;
+    X[1] = (uchar *)xmalloc((size_t)cols * rows + 1);
+    X[1][(size_t)cols * rows] = 'N';
+    for (i = 2; i <= cols; ++i) X[i] = X[i-1] + rows;
+    return X;
+}
+static void cols_free(uchar **X) { free(X[1]); free(X + 1); }
+
+/* Turn yama()'s merged columns back into a block (reference mz_preyama.c:38-81): row i of the new
+ * block takes its bookkeeping from the i-th row of a2, continuing into a3 (from a3's second row
+ * unless top != 0); rows left without a base are dropped; the block is rescored. */
+struct mafAli *mafBuild(uchar **A_new, int nrow, int ncol, struct mafAli *a2, int cbeg2,
+                        struct mafAli *a3, int cbeg3, int top)
+{
+    struct mafAli *blk = (struct mafAli *)xmalloc(sizeof *blk);
+    struct mafComp *src = a2->components, *tail = NULL, *nc;
+    int skip = cbeg2, i, j;
+
+    memset(blk, 0, sizeof *blk);
+    blk->textSize = ncol;
+    for (i = 0; i < nrow; ++i, src = src->next) {
+        int start;
+        if (src == NULL) {                         /* rows of the first block exhausted */
+            src = top == 0 ? a3->components->next : a3->components;
+            skip = cbeg3;
+        }
+        for (start = src->start, j = 0; j < skip; ++j)
+            start += src->text[j] != '-';          /* bases of this row left of the slice */
+        nc = mafCpyComp(src);
+        nc->start = start;
+        nc->size = 0;
+        nc->text = (char *)xmalloc((size_t)ncol + 1);
+        for (j = 0; j < ncol; ++j) {
+            nc->text[j] = (char)A_new[j + 1][i];
+            nc->size += nc->text[j] != '-';
+        }
+        nc->text[ncol] = '\0';
+        if (nc->size == 0) { mafCompFree(&nc); continue; }
+        if (tail) tail->next = nc; else blk->components = nc;
+        tail = nc;
+    }
+    if (!blk->components) { free(blk); return NULL; }
+    blk->score = mafScoreRange(blk, 0, ncol);
+    return blk;
+}
+
+/* Delete the columns of X (1-based, `row` bytes each) that are all dashes, compacting in place;
+ * *N becomes the new column count.  Returns map[1..oldN]: new index, or -1 if removed
+ * (reference mz_preyama.c:87-108). */
+int *rmColDash(uchar **X, int *N, int row)
+{
+    const int n = *N;
+    int *map = (int *)xmalloc(((size_t)n + 1) * sizeof(int));
+    int i, j, kept = 0;
+
+    for (i = 1; i <= n; ++i) {
+        for (j = 0; j < row && X[i][j] == '-'; ++j)
+            ;
+        if (j == row) { map[i] = -1; continue; }
+        ++kept;
+        if (kept != i) memcpy(X[kept], X[i], (size_t)row);
+        map[i] = kept;
+    }
+    *N = kept;
+    return map;
+}
+
+/* Pair up, in order, the columns of A (rows a_row1..a_row2, columns a_col1..a_col2) that are not
+ * all-dash with the likewise non-all-dash columns of B; map[column of A] = column of B, -1 for
+ * skipped columns (reference mz_preyama.c:111-148; indices into the result are A's own column
+ * numbers, which the callers always start at 1). */
+int *mapping(uchar **A, int a_row1, int a_row2, int a_col1, int a_col2,
+             uchar **B, int b_row1, int b_row2, int b_col1, int b_col2)
+{
+    int *map, i, k, j, l;
+
+    if (a_row2 - a_row1 != b_row2 - b_row1)
+        mz_fatalf("not equal rows:!\n");
+    map = (int *)xmalloc(((size_t)(a_col2 - a_col1) + 2) * sizeof(int));
+    for (i = a_col1; i <= a_col2; ++i) map[i - a_col1 + 1] = -1;
+
+    i = a_col1; k = b_col1;
+    while (i <= a_col2 && k <= b_col2) {
+        int a_live = 0, b_live = 0;
+        for (; i <= a_col2; ++i) {                 /* next column of A with a base in the row range */
+            for (j = a_row1; j <= a_row2 && A[i][j] == '-'; ++j)
+                ;
+            if (j <= a_row2) { a_live = 1; break; }
+        }
+        for (; k <= b_col2; ++k) {
+            for (l = b_row1; l <= b_row2 && B[k][l] == '-'; ++l)
+                ;
+            if (l <= b_row2) { b_live = 1; break; }
+        }
+        if (a_live && b_live) map[i] = k;
+        ++i; ++k;
+    }
+    return map;
+}
+
+/* fold the (row of first block -> column of second block) correspondences into raw bounds:
+ * 0 / hi_unset mean "not set yet", exactly as the reference encodes it (mz_preyama.c:252-255) */
+static void bound_note(int *LB, int *RB, int row, int col, int hi_unset)
+{
+    if (LB[row] == 0 || LB[row] > col) LB[row] = col;
+    if (RB[row] == hi_unset || RB[row] < col) RB[row] = col;
+}
+
+struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int v, FILE *fpw2)
+{
+    struct mafComp *c;
+    struct mafAli *result;
+    uchar **A, **B, **merged;
+    int K = 0, L = 0, M, N, M_all, N_all, M_new, i, j, r;
+    int cbeg1, cend1, cbeg2, cend2;
+    int *map1, *map2, *LB, *RB;
+
+    for (c = a1->components; c; c = c->next) ++K;
+    for (c = a2->components->next; c; c = c->next) ++L;     /* a2's top row only guides */
+
+    cbeg1 = mafPos2Col(a1->components, beg, a1->textSize);
+    cend1 = mafPos2Col(a1->components, end, a1->textSize);
+    cbeg2 = mafPos2Col(a2->components, beg, a2->textSize);
+    cend2 = mafPos2Col(a2->components, end, a2->textSize);
+    M = M_all = cend1 - cbeg1 + 1;
+    N = N_all = cend2 - cbeg2 + 1;
+
+    /* second block without its reference row, column-major, all-dash columns removed */
+    B = cols_new(N, L);
+    for (i = 1; i <= N; ++i)
+        for (r = 0, c = a2->components->next; r < L; ++r, c = c->next)
+            B[i][r] = (uchar)c->text[cbeg2 + i - 1];
+    map2 = rmColDash(B, &N, L);
+    if (N < 1) { cols_free(B); free(map2); return NULL; }
+
+    if (v == 0) --K;                                          /* a1's reference row is aligned later */
+    if (K == 0) {
+        if (fpw2) print_part_ali_col(a2, cbeg2, cend2, fpw2);
+        cols_free(B); free(map2);
+        return NULL;
+    }
+    A = cols_new(M, K);
+    for (i = 1; i <= M; ++i)
+        for (r = 0, c = v == 0 ? a1->components->next : a1->components; r < K; ++r, c = c->next)
+            A[i][r] = (uchar)c->text[cbeg1 + i - 1];
+    if (v == 0) {
+        map1 = rmColDash(A, &M, K);
+        if (M < 1) { cols_free(A); cols_free(B); free(map1); free(map2); return NULL; }
+    } else {
+        map1 = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+        for (i = 1; i <= M; ++i) map1[i] = i;
+    }
+
+    /* band from the shared reference row: walk both copies of it base by base */
+    LB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    RB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    for (i = 0; i <= M; ++i) { LB[i] = 0; RB[i] = N; }
+    for (i = cbeg1, j = cbeg2; i <= cend1; ++i, ++j) {
+        int ra, cb;
+        while (a1->components->text[i] == '-') ++i;
+        while (a2->components->text[j] == '-') ++j;
+        ra = map1[i - cbeg1 + 1];
+        cb = map2[j - cbeg2 + 1];
+        if (ra != -1 && cb != -1) bound_note(LB, RB, ra, cb, N);
+    }
+    smooth(LB, RB, M, N, radius);
+    yama(A, K, M, B, L, N, LB, RB, &merged, &M_new);
+    free(LB); free(RB);
+
+    if (v == 1) {
+        result = mafBuild(merged, K + L, M_new, a1, cbeg1, a2, cbeg2, 0);
+    } else {
+        /* second stage: align a1's reference row (dashes squeezed out) against the merged block.
+         * Its band is the union of two estimates: where a1's other rows went (via map1 o map4a) and
+         * where a2's rows went (via map2 o map4b). */
+        uchar **ref1 = cols_new(M_all, 1), **ref2 = cols_new(N_all, 1), **merged2;
+        int *m3a, *m4a, *m3b, *m4b, *LBa, *RBa, *LBb, *RBb;
+        int M3 = M_all, N3 = N_all;
+
+        for (i = 1; i <= M_all; ++i) ref1[i][0] = (uchar)a1->components->text[cbeg1 + i - 1];
+        m3a = rmColDash(ref1, &M3, 1);
+        /* NOTE (reference mz_preyama.c:279): rows 1..K are scanned although A now has rows 0..K-1, so
+         * "row K" of a column is really row 0 of the next column (and, for the last column, the byte
+         * after the data: a stale pre-compaction byte, or the spare non-dash of cols_new()).  The
+         * reference's outputs depend on it; reproduced literally. */
+        m4a = mapping(A, 1, K, 1, M, merged, 0, K - 1, 1, M_new);
+        LBa = (int *)xmalloc(((size_t)M3 + 1) * sizeof(int));
+        RBa = (int *)xmalloc(((size_t)M3 + 1) * sizeof(int));
+        for (i = 0; i <= M3; ++i) { LBa[i] = 0; RBa[i] = M_new; }
+        for (i = 1; i <= M_all; ++i) {
+            int t1 = m3a[i], t2;
+            if (map1[i] == -1) continue;
+            t2 = m4a[map1[i]];
+            if (t1 != -1 && t2 != -1) bound_note(LBa, RBa, t1, t2, M_new);
+        }
+        smooth(LBa, RBa, M3, M_new, radius);
+        free(m3a); free(m4a);
+
+        for (i = 1; i <= N_all; ++i) ref2[i][0] = (uchar)a2->components->text[cbeg2 + i - 1];
+        m3b = rmColDash(ref2, &N3, 1);
+        m4b = mapping(B, 0, L - 1, 1, N, merged, K, K + L - 1, 1, M_new);
+        LBb = (int *)xmalloc(((size_t)N3 + 1) * sizeof(int));
+        RBb = (int *)xmalloc(((size_t)N3 + 1) * sizeof(int));
+        for (i = 0; i <= N3; ++i) { LBb[i] = 0; RBb[i] = M_new; }
+        for (i = 1; i <= N_all; ++i) {
+            /* NOTE (reference mz_preyama.c:318-326): map2[i] is not tested for -1 here, so a removed
+             * a2 column reads the word in front of the map; on glibc/x86-64 that is the upper half of
+             * the chunk header, i.e. 0.  Reproduced as the value 0. */
+            int t1 = m3b[i], t2 = map2[i] == -1 ? 0 : m4b[map2[i]];
+            if (t1 != -1 && t2 != -1) bound_note(LBb, RBb, t1, t2, M_new);
+        }
+        smooth(LBb, RBb, N3, M_new, radius);
+        if (M3 != N3) mz_fatalf("M3 not equals N3!!\n");
+        for (i = 0; i <= M3; ++i) {
+            if (LBa[i] < LBb[i]) LBb[i] = LBa[i];
+            if (RBa[i] > RBb[i]) RBb[i] = RBa[i];
+        }
+        yama(ref1, 1, M3, merged, K + L, M_new, LBb, RBb, &merged2, &M_new);
+        result = mafBuild(merged2, K + L + 1, M_new, a1, cbeg1, a2, cbeg2, 0);
+        free(m3b); free(m4b); free(LBa); free(RBa); free(LBb); free(RBb);
+        cols_free(ref1); cols_free(ref2); cols_free(merged2);
+    }
+    cols_free(A); cols_free(B); cols_free(merged);
+    free(map1); free(map2);
+    return result;
 }

@@ -236,7 +236,7 @@ class Row:
     srcSize: int
     text: str
     name: str = ""
-    paralog: str = "o"
+    paralog: str = "s"          # 's'ingleton, the reader's default (maf.c:178)
 
 
 @dataclass
@@ -266,7 +266,10 @@ def block_to_c(b: Block, keep: _Keep) -> MafAli:
         c.text = C.cast(tbuf, C.c_void_p)
         c.src = C.cast(sbuf, C.c_char_p)
         c.name = C.cast(nbuf, C.c_char_p)
-        c.contig = None
+        _nm, _, _rest = r.src.partition(".")
+        cbuf = C.create_string_buffer((_rest or _nm).encode("ascii"))      # parseSrcName2 (multi_util.c:909-925)
+        keep.objs.append(cbuf)
+        c.contig = C.cast(cbuf, C.c_char_p)
         c.mafPosMap = None
         c.srcSize, c.start, c.size = r.srcSize, r.start, r.size
         c.nameID = 0
@@ -296,7 +299,7 @@ def block_from_c(p) -> Optional[Block]:
         text = C.string_at(c.text).decode("ascii")
         rows.append(Row(src=c.src.decode("ascii"), start=c.start, size=c.size, strand=c.strand.decode("ascii"),
                         srcSize=c.srcSize, text=text, name=(c.name or b"").decode("ascii"),
-                        paralog=(c.paralog or b"o").decode("ascii") if c.paralog != b"\x00" else "o"))
+                        paralog=c.paralog.decode("ascii") if c.paralog not in (b"", b"\x00") else "s"))
         cp = c.next
     return Block(rows=rows, score=a.score)
 
@@ -370,3 +373,265 @@ class Reference:
 
 def have_reference() -> bool:
     return os.path.exists(REF_PATH)
+
+
+# --------------------------------------------------------------------------------------
+# pre_yama() restated in Python (reference mz_preyama.c:17-359, mz_scores.c:124-152,
+# multi_util.c:570-645).  Small blocks only; the DP itself goes to the C oracle.
+# --------------------------------------------------------------------------------------
+
+DASH = ord("-")
+
+
+def _ss_table(sc: Scores) -> np.ndarray:
+    return np.ctypeslib.as_array(sc.ss).reshape(128, 128).copy()
+
+
+def score_range(b: Block, start: int, size: int, sc: Optional[Scores] = None) -> float:
+    """mafScoreRange (mz_scores.c:124-152): all unordered row pairs, substitution minus gap-open"""
+    sc = sc or scores70()
+    ss = _ss_table(sc)
+    gop = np.array(list(sc.gop), dtype=np.int64)
+    rows = [np.frombuffer(r.text.encode("ascii"), dtype=np.uint8) for r in b.rows]
+    total = 0
+    for p in range(len(rows)):
+        for q in range(p + 1, len(rows)):
+            x, y = rows[p][start:start + size].astype(np.int64), rows[q][start:start + size].astype(np.int64)
+            total += int(ss[x, y].sum())
+            lo = max(start, 1)
+            if start + size > lo:
+                cx, cy = rows[p][lo:start + size] == DASH, rows[q][lo:start + size] == DASH
+                px, py = rows[p][lo - 1:start + size - 1] == DASH, rows[q][lo - 1:start + size - 1] == DASH
+                idx = (px.astype(np.int64) << 3) | (py.astype(np.int64) << 2) | (cx.astype(np.int64) << 1) | cy.astype(np.int64)
+                total -= int(gop[idx].sum())
+    return float(total)
+
+
+def pos2col(r: Row, pos: int, text_size: int) -> int:
+    if pos < r.start or pos >= r.start + r.size:
+        raise ValueError(f"mafPos2Col: {pos} not in {r.start}-{r.start + r.size - 1}")
+    p = r.start - 1
+    for col in range(text_size):
+        if r.text[col] != "-":
+            p += 1
+            if p == pos:
+                return col
+    return text_size
+
+
+class _Cols:
+    """1-based columns over one flat buffer (+ one spare non-dash byte), as the reference lays them out"""
+
+    def __init__(self, ncols: int, nrows: int):
+        self.rows, self.n = nrows, ncols
+        self.buf = bytearray(ncols * nrows + 1)
+        self.buf[ncols * nrows] = ord("N")
+
+    def at(self, col: int, row: int) -> int:          # row may run past nrows-1: next column's bytes
+        return self.buf[(col - 1) * self.rows + row]
+
+    def set(self, col, row, v):
+        self.buf[(col - 1) * self.rows + row] = v
+
+    def col(self, c) -> bytes:
+        return bytes(self.buf[(c - 1) * self.rows: c * self.rows])
+
+    def as_array(self, ncols) -> np.ndarray:
+        return np.frombuffer(bytes(self.buf[: ncols * self.rows]), dtype=np.uint8).reshape(ncols, self.rows)
+
+
+def _rm_col_dash(X: _Cols, n: int):
+    """rmColDash (mz_preyama.c:87-108): compact in place, return (map[0..n], new n)"""
+    mp = [-1] * (n + 1)
+    kept = 0
+    for i in range(1, n + 1):
+        if all(X.at(i, j) == DASH for j in range(X.rows)):
+            continue
+        kept += 1
+        if kept != i:
+            for j in range(X.rows):
+                X.set(kept, j, X.at(i, j))
+        mp[i] = kept
+    return mp, kept
+
+
+def _mapping(Aat, a_r1, a_r2, a_c1, a_c2, Bat, b_r1, b_r2, b_c1, b_c2):
+    """mapping (mz_preyama.c:111-148); Aat/Bat are (col,row)->byte accessors"""
+    mp = {i: -1 for i in range(a_c1, a_c2 + 1)}
+    i, k = a_c1, b_c1
+    while i <= a_c2 and k <= b_c2:
+        a_live = b_live = False
+        while i <= a_c2:
+            if any(Aat(i, j) != DASH for j in range(a_r1, a_r2 + 1)):
+                a_live = True
+                break
+            i += 1
+        while k <= b_c2:
+            if any(Bat(k, l) != DASH for l in range(b_r1, b_r2 + 1)):
+                b_live = True
+                break
+            k += 1
+        if a_live and b_live:
+            mp[i] = k
+        i += 1
+        k += 1
+    return mp
+
+
+def _note(LB, RB, row, col, unset_hi):
+    if LB[row] == 0 or LB[row] > col:
+        LB[row] = col
+    if RB[row] == unset_hi or RB[row] < col:
+        RB[row] = col
+
+
+def _build(cols: np.ndarray, a1: Block, cbeg1: int, a2: Block, cbeg2: int, sc) -> Optional[Block]:
+    """mafBuild with top == 0 (mz_preyama.c:38-81)"""
+    ncol, nrow = cols.shape
+    srcs = [(r, cbeg1) for r in a1.rows] + [(r, cbeg2) for r in a2.rows[1:]]
+    out = []
+    for i in range(nrow):
+        src, skip = srcs[i]
+        text = bytes(cols[:, i]).decode("ascii")
+        size = sum(ch != "-" for ch in text)
+        if size == 0:
+            continue
+        start = src.start + sum(ch != "-" for ch in src.text[:skip])
+        out.append(Row(src=src.src, start=start, size=size, strand=src.strand, srcSize=src.srcSize, text=text,
+                       name=src.name, paralog=src.paralog))
+    if not out:
+        return None
+    b = Block(rows=out)
+    b.score = score_range(b, 0, ncol, sc)
+    return b
+
+
+def part_ali_col(b: Block, cbeg: int, cend: int, sc=None) -> Optional[Block]:
+    """make_part_ali_col (multi_util.c:570-618)"""
+    if cend - cbeg + 1 == 0:
+        return None
+    rows = []
+    for r in b.rows:
+        seg = r.text[cbeg:cend + 1]
+        bases = sum(ch != "-" for ch in seg)
+        if bases == 0:
+            continue
+        rows.append(Row(src=r.src, start=r.start + sum(ch != "-" for ch in r.text[:cbeg]), size=bases, strand=r.strand,
+                        srcSize=r.srcSize, text=seg, name=r.name, paralog=r.paralog))
+    if not rows:
+        return None
+    keep = [j for j in range(cend - cbeg + 1) if any(r.text[j] != "-" for r in rows)]
+    for r in rows:
+        r.text = "".join(r.text[j] for j in keep)
+    out = Block(rows=rows)
+    out.score = score_range(out, 0, len(keep), sc)
+    return out
+
+
+def pre_yama(a1: Block, a2: Block, beg: int, end: int, radius: int, v: int, sc: Optional[Scores] = None,
+             yama_fn=None):
+    """Returns (merged block or None, side block or None); the side block is what the reference
+    writes to fpw2 when v == 0 and a1 has nothing but its reference row (mz_preyama.c:193-201).
+    yama_fn(A, B, LB, RB) -> YamaResult lets a test substitute the implementation under test."""
+    sc = sc or scores70()
+    yfn = yama_fn or (lambda A, B, LB, RB: yama(A, B, LB, RB, sc=sc))
+    K, L = len(a1.rows), len(a2.rows) - 1
+    ts1, ts2 = a1.textSize, a2.textSize
+    cbeg1, cend1 = pos2col(a1.rows[0], beg, ts1), pos2col(a1.rows[0], end, ts1)
+    cbeg2, cend2 = pos2col(a2.rows[0], beg, ts2), pos2col(a2.rows[0], end, ts2)
+    M = M_all = cend1 - cbeg1 + 1
+    N = N_all = cend2 - cbeg2 + 1
+
+    B = _Cols(N, L)
+    for i in range(1, N + 1):
+        for r in range(L):
+            B.set(i, r, ord(a2.rows[r + 1].text[cbeg2 + i - 1]))
+    map2, N = _rm_col_dash(B, N)
+    if N < 1:
+        return None, None
+    if v == 0:
+        K -= 1
+    if K == 0:
+        return None, part_ali_col(a2, cbeg2, cend2, sc)
+    first = 1 if v == 0 else 0
+    A = _Cols(M, K)
+    for i in range(1, M + 1):
+        for r in range(K):
+            A.set(i, r, ord(a1.rows[first + r].text[cbeg1 + i - 1]))
+    if v == 0:
+        map1, M = _rm_col_dash(A, M)
+        if M < 1:
+            return None, None
+    else:
+        map1 = list(range(M + 1))
+
+    LB, RB = [0] * (M + 1), [N] * (M + 1)
+    t1, t2 = a1.rows[0].text, a2.rows[0].text
+    i, j = cbeg1, cbeg2
+    while i <= cend1:
+        while t1[i] == "-":
+            i += 1
+        while t2[j] == "-":
+            j += 1
+        ra, cb = map1[i - cbeg1 + 1], map2[j - cbeg2 + 1]
+        if ra != -1 and cb != -1:
+            _note(LB, RB, ra, cb, N)
+        i += 1
+        j += 1
+    LB, RB = smooth(LB, RB, M, N, radius)
+    res = yfn(A.as_array(M), B.as_array(N), LB, RB)
+    if res.rc:
+        raise RuntimeError(f"yama rejected the band: {ERRORS.get(res.rc, res.rc)}")
+    merged, M_new = res.cols, res.OM
+    if v == 1:
+        return _build(merged, a1, cbeg1, a2, cbeg2, sc), None
+
+    # ---- v == 0: align a1's reference row against the merged block
+    ref1 = _Cols(M_all, 1)
+    for i in range(1, M_all + 1):
+        ref1.set(i, 0, ord(t1[cbeg1 + i - 1]))
+    m3a, M3 = _rm_col_dash(ref1, M_all)
+    mat = lambda c, r: int(merged[c - 1, r])          # noqa: E731
+    # rows 1..K of a K-row matrix: the reference's off-by-one (mz_preyama.c:279), reproduced
+    m4a = _mapping(A.at, 1, K, 1, M, mat, 0, K - 1, 1, M_new)
+    LBa, RBa = [0] * (M3 + 1), [M_new] * (M3 + 1)
+    for i in range(1, M_all + 1):
+        if map1[i] == -1:
+            continue
+        a, b_ = m3a[i], m4a[map1[i]]
+        if a != -1 and b_ != -1:
+            _note(LBa, RBa, a, b_, M_new)
+    LBa, RBa = smooth(LBa, RBa, M3, M_new, radius)
+
+    ref2 = _Cols(N_all, 1)
+    for i in range(1, N_all + 1):
+        ref2.set(i, 0, ord(t2[cbeg2 + i - 1]))
+    m3b, N3 = _rm_col_dash(ref2, N_all)
+    m4b = _mapping(B.at, 0, L - 1, 1, N, mat, K, K + L - 1, 1, M_new)
+    LBb, RBb = [0] * (N3 + 1), [M_new] * (N3 + 1)
+    for i in range(1, N_all + 1):
+        a = m3b[i]
+        b_ = 0 if map2[i] == -1 else m4b[map2[i]]   # map4[-1] reads 0 on glibc (mz_preyama.c:318-326)
+        if a != -1 and b_ != -1:
+            _note(LBb, RBb, a, b_, M_new)
+    LBb, RBb = smooth(LBb, RBb, N3, M_new, radius)
+    if M3 != N3:
+        raise RuntimeError("M3 not equals N3!!")
+    LBf = np.minimum(LBa, LBb)
+    RBf = np.maximum(RBa, RBb)
+    res2 = yfn(ref1.as_array(M3), merged, LBf, RBf)
+    if res2.rc:
+        raise RuntimeError(f"second yama rejected the band: {ERRORS.get(res2.rc, res2.rc)}")
+    return _build(res2.cols, a1, cbeg1, a2, cbeg2, sc), None
+
+
+def format_block(b: Block) -> str:
+    """mafWrite (maf.c:251-294)"""
+    out = ["a" + ("" if b.score == float(-(1 << 31)) else f" score={b.score:3.1f}")]
+    w = [max(len(r.src) for r in b.rows), max(len(str(r.start)) for r in b.rows),
+         max(len(str(r.size)) for r in b.rows), max(len(str(r.srcSize)) for r in b.rows)]
+    for r in b.rows:
+        name, _, rest = r.src.partition(".")
+        shown = name if (not rest or rest == name) else f"{name}.{rest}"
+        out.append(f"s {shown:<{w[0]}} {r.start:>{w[1]}} {r.size:>{w[2]}} {r.strand} {r.srcSize:>{w[3]}} {r.text}")
+    return "\n".join(out) + "\n\n"

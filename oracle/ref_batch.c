@@ -16,6 +16,8 @@
 #endif
 #include "oracle.h"
 
+#pragma GCC diagnostic ignored "-Wfree-nonheap-object"   /* 1-based arrays: free(X + 1) */
+
 typedef void (*yama_fn)(unsigned char **A, int K, int M, unsigned char **B, int L, int N,
                         int *LB, int *RB, unsigned char ***OAL, int *OM);
 

@@ -73,3 +73,57 @@ def make_pair(rng, K, L, M, N, R=30, band="diag", smooth_fn=None, dash=0.08, odd
     if smooth_fn is not None and band != "full":
         LB, RB = smooth_fn(LB, RB, M, N, R)
     return A, B, LB, RB
+
+
+# ------------------------------------------------------------------ MAF block pairs for pre_yama
+
+def _mutate(rng, base: int) -> int:
+    return int(ACGT[rng.integers(0, 4)]) if rng.random() < 0.12 else base
+
+
+def random_maf_block(rng, ref: np.ndarray, s: int, e: int, nrows: int, tag: str, pins=0.04, pdel=0.05, lower=0.03):
+    """a block whose top row is ref[s:e] on 'ref.chr1' plus nrows-1 noisy species rows"""
+    from oracle.mzoracle import Block, Row
+    cols = []                                    # list of per-row bytes
+    for p in range(s, e):
+        if p > s and rng.random() < pins:        # columns where the reference row has a dash
+            for _ in range(int(rng.integers(1, 4))):
+                col = [DASHB] + [int(ACGT[rng.integers(0, 4)]) if rng.random() < 0.7 else DASHB for _ in range(nrows - 1)]
+                if all(c == DASHB for c in col[1:]) and nrows > 1:
+                    col[1 + int(rng.integers(0, nrows - 1))] = int(ACGT[rng.integers(0, 4)])
+                if nrows > 1:
+                    cols.append(col)
+        col = [int(ref[p])] + [DASHB if rng.random() < pdel else _mutate(rng, int(ref[p])) for _ in range(nrows - 1)]
+        cols.append(col)
+    arr = np.array(cols, dtype=np.uint8)          # (columns, rows)
+    if lower > 0:
+        m = (rng.random(arr.shape) < lower) & (arr != DASHB)
+        m[:, 0] = False                           # keep the shared reference row byte-identical in both blocks
+        arr = np.where(m, arr | 0x20, arr).astype(np.uint8)
+    rows = []
+    for r in range(nrows):
+        text = bytes(arr[:, r]).decode("ascii")
+        size = sum(ch != "-" for ch in text)
+        if r == 0:
+            rows.append(Row(src="ref.chr1", start=s, size=size, strand="+", srcSize=len(ref) + 1000, text=text))
+        else:
+            if size == 0:                         # a MAF row must hold at least one base
+                text = "A" + text[1:] if text[0] == "-" else text
+                arr[0, r] = ord(text[0]); size = sum(ch != "-" for ch in text)
+            st = int(rng.integers(0, 5000))
+            rows.append(Row(src=f"{tag}{r}.chr{r}", start=st, size=size, strand="+-"[int(rng.integers(0, 2))], srcSize=st + size + 77, text=text))
+    return Block(rows=rows)
+
+
+DASHB = ord("-")
+
+
+def random_block_pair(rng, n1: int, n2: int, length: int = 150):
+    """two blocks sharing part of their reference row; returns (a1, a2, beg, end)"""
+    ref = ACGT[rng.integers(0, 4, size=length + 200)]
+    s1, s2 = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+    e1, e2 = s1 + int(rng.integers(length // 2, length)), s2 + int(rng.integers(length // 2, length))
+    a1 = random_maf_block(rng, ref, s1, e1, n1, "x")
+    a2 = random_maf_block(rng, ref, s2, e2, n2, "y")
+    beg, end = max(s1, s2), min(e1, e2) - 1
+    return a1, a2, beg, end

@@ -1,0 +1,204 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libmzamd.so), against the CPU oracle
+and the committed golden vectors.  Integer/byte work: the bar is bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import inputs
+from oracle import mzoracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mz():
+    import multiz_amd as m
+    m.api.init(0)
+    yield m
+    m.lib().mz_enable_fast(1)
+
+
+def _check(res, pairs, tags=None, exact_scores=True):
+    for i, ((A, B, LB, RB), r) in enumerate(zip(pairs, res)):
+        tag = tags[i] if tags else i
+        want = mo.yama(A, B, LB, RB, variant="profile")
+        assert want.rc == 0
+        assert r.status == 0, (tag, r.status)
+        assert r.OM == want.OM, tag
+        assert np.array_equal(r.cols, want.cols), tag
+        # (C,D,I) at (M,N): the fast kernel may hold a different value in an UNREACHABLE state
+        # (about -2^30 either way); reachable ones and the winner must agree
+        if exact_scores:
+            assert np.array_equal(r.score, want.final), tag
+        else:
+            assert r.score.max() == want.final.max(), tag
+            live = want.final > -(1 << 29)
+            assert np.array_equal(r.score[live], want.final[live]), tag
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+def test_golden_vectors(mz, golden, fast):
+    mz.lib().mz_enable_fast(fast)
+    pairs = [(c["A"], c["B"], c["LB"], c["RB"]) for c in golden]
+    res = mz.yama_batch(pairs)
+    for c, r in zip(golden, res):
+        assert r.status == 0, c["tag"]
+        assert r.OM == c["OM"], c["tag"]
+        assert np.array_equal(r.cols, c["cols"]), c["tag"]
+    _check(res, pairs, [c["tag"] for c in golden], exact_scores=(fast == 0))
+
+
+def _random_pairs(seed, n, kmax=8, mmax=420):
+    rng = np.random.default_rng(seed)
+    pairs = []
+    while len(pairs) < n:
+        K, L = int(rng.integers(1, kmax + 1)), int(rng.integers(1, kmax + 1))
+        M, N = int(rng.integers(1, mmax)), int(rng.integers(1, mmax))
+        R = int(rng.choice([10, 12, 30, 50, 100]))
+        band = str(rng.choice(["diag", "diag", "wander", "full"]))
+        A, B, LB, RB = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth,
+                                        dash=float(rng.choice([0.0, 0.08, 0.35])), odd=float(rng.choice([0.0, 0.05, 0.6])))
+        if mo.check(M, N, LB, RB)[0] == 0 and (band != "full" or M * N < 40000):
+            pairs.append((A, B, LB, RB))
+    return pairs
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+def test_random_pairs_one_batch(mz, fast):
+    mz.lib().mz_enable_fast(fast)
+    pairs = _random_pairs(2026 + fast, 400)
+    _check(mz.yama_batch(pairs), pairs, exact_scores=(fast == 0))
+
+
+def test_many_rows(mz):
+    # deep sum-of-pairs: 10+10 and lopsided row counts up to the int8 counter limit
+    rng = np.random.default_rng(9)
+    pairs = []
+    for K, L, M, N in ((10, 10, 300, 310), (29, 1, 150, 160), (1, 29, 150, 140), (40, 37, 90, 100), (127, 3, 60, 64), (3, 127, 64, 60)):
+        pairs.append(inputs.make_pair(rng, K, L, M, N, 30, "diag", mo.smooth))
+    for fast in (1, 0):
+        mz.lib().mz_enable_fast(fast)
+        _check(mz.yama_batch(pairs), pairs, exact_scores=(fast == 0))
+
+
+def test_hoxd85_tables(mz):
+    # the caller switches tables with init_scores85() (mz_scores.c:109-122); gap_open 600 = 24*25
+    rng = np.random.default_rng(85)
+    pairs = _random_pairs(85, 60, kmax=4, mmax=200)
+    try:
+        mz.set_scores_hoxd85()
+        res = mz.yama_batch(pairs)
+        sc = mo.scores85()
+        for (A, B, LB, RB), r in zip(pairs, res):
+            want = mo.yama(A, B, LB, RB, sc=sc)
+            assert r.status == 0 and r.OM == want.OM and np.array_equal(r.cols, want.cols)
+    finally:
+        mz.set_scores_hoxd70()
+    del rng
+
+
+def test_invalid_bands_are_reported(mz):
+    # reference mz_yama.c:58-71: each violated precondition -> its own status (the yama() wrapper turns
+    # these into the reference's message + exit(1)); valid neighbours in the same batch still run
+    rng = np.random.default_rng(4)
+    good = inputs.make_pair(rng, 2, 2, 60, 64, 30, "diag", mo.smooth)
+    A, B, LB, RB = good
+    cases = []
+    l = LB.copy(); l[0] = 1; cases.append((A, B, l, RB))
+    r = RB.copy(); r[-1] -= 1; cases.append((A, B, LB, r))
+    r = RB.copy(); r[20] = LB[20] + 3; cases.append((A, B, LB, r))
+    l = LB.copy(); l[40] = l[39] - 1 if l[39] > 0 else 0; l[41:] = np.maximum(l[41:], 0); l[39] = l[40] + 2; cases.append((A, B, l, RB))
+    r = RB.copy(); r[30] = r[29] - 1; cases.append((A, B, LB, r))
+    res = mz.yama_batch([good] + cases + [good])
+    assert res[0].status == 0 and res[-1].status == 0 and np.array_equal(res[0].cols, res[-1].cols)
+    for (a, b, l, r), got in zip(cases, res[1:-1]):
+        rc, _, bad = mo.check(a.shape[0], b.shape[0], l, r)
+        assert rc != 0 and got.status == rc, (rc, got.status)
+        if rc == 2:
+            assert got.badrow == bad
+    # row-count limits of this build are reported, not mis-computed
+    big = inputs.make_pair(rng, 130, 2, 20, 20, 30, "diag", mo.smooth)
+    assert mz.yama_batch([big])[0].status == 16
+
+
+def test_yama_dropin_signature(mz):
+    # the reference-signature entry point itself: 1-based column pointer arrays in, two malloc blocks out
+    lib = mz.lib()
+    rng = np.random.default_rng(12)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for _ in range(5):
+        A, B, LB, RB = inputs.make_pair(rng, 3, 2, int(rng.integers(30, 200)), int(rng.integers(30, 200)), 30, "diag", mo.smooth)
+        (M, K), (N, L) = A.shape, B.shape
+        pa, pb = (C.c_void_p * (M + 1))(), (C.c_void_p * (N + 1))()
+        for i in range(1, M + 1):
+            pa[i] = A.ctypes.data + (i - 1) * K
+        for i in range(1, N + 1):
+            pb[i] = B.ctypes.data + (i - 1) * L
+        oal, om = C.POINTER(C.c_void_p)(), C.c_int(0)
+        lb, rb = LB.astype(np.int32), RB.astype(np.int32)
+        lib.yama(pa, C.c_int(K), C.c_int(M), pb, C.c_int(L), C.c_int(N), C.c_void_p(lb.ctypes.data),
+                 C.c_void_p(rb.ctypes.data), C.byref(oal), C.byref(om))
+        want = mo.yama(A, B, LB, RB)
+        got = np.frombuffer(C.string_at(oal[1], om.value * (K + L)), dtype=np.uint8).reshape(om.value, K + L)
+        assert om.value == want.OM and np.array_equal(got, want.cols)
+        libc.free(C.c_void_p(oal[1]))                                         # free(OAL[1]); free(OAL+1);
+        libc.free(C.c_void_p(C.addressof(oal.contents) + C.sizeof(C.c_void_p)))
+
+
+def _hash(cols, om):
+    return mo.fnv1a_np(cols, mo.fnv1a_np(np.array([om], dtype=np.int32).view(np.uint8)))
+
+
+@pytest.mark.parametrize("cfg,pairs", [("c2", 3000), ("c3", 120)])
+def test_config_sized_batches_device_resident(mz, cfg, pairs):
+    # BASELINE.json shapes through the device-resident API (what bench.py times): every pair against the
+    # oracle by hash of (OM, merged columns), plus the size-independent properties of the merge
+    from multiz_amd import synth
+    c = synth.CONFIGS[cfg]
+    batch = synth.make_batch(pairs, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=7)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=8)
+    assert bad == 0 and cells == int(res["cells"].sum())
+    host_out = db.out.cpu().numpy()
+    for i in range(pairs):
+        K, L, M, N = (int(batch[k][i]) for k in ("K", "L", "M", "N"))
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == om[i] and max(M, N) <= m_ <= M + N
+        g = host_out[o0: o0 + m_ * (K + L)]
+        assert _hash(g, m_) == int(hs[i]), i
+    # round trip on a few: dropping the inserted (all-dash) half-columns gives back A and B
+    for i in range(0, pairs, max(1, pairs // 20)):
+        A, B, _, _ = synth.pair_of(batch, i)
+        K, L = A.shape[1], B.shape[1]
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        g = host_out[o0: o0 + m_ * (K + L)].reshape(m_, K + L)
+        top, bot = g[:, :K], g[:, K:]
+        assert np.array_equal(top[~(top == 45).all(axis=1)], A)
+        assert np.array_equal(bot[~(bot == 45).all(axis=1)], B)
+
+
+def test_long_block_regime(mz):
+    # configs[4] shape (R=30, ~100k x 100k columns): traceback spills to HBM (6 MB per pair)
+    from multiz_amd import synth
+    batch = synth.make_batch(3, 2, 2, 95000, 105000, 30, first_pair=3)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=3)
+    host_out = db.out.cpu().numpy()
+    for i in range(3):
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == om[i] and _hash(host_out[o0: o0 + m_ * 4], m_) == int(hs[i])
+
+
+def test_empty_and_tiny_batches(mz):
+    assert mz.yama_batch([]) == []
+    A = np.frombuffer(b"A", dtype=np.uint8).reshape(1, 1)
+    r = mz.yama_one(A, A, np.array([0, 0], dtype=np.int32), np.array([1, 1], dtype=np.int32))
+    assert r.status == 0 and r.OM == 1 and bytes(r.cols.ravel()) == b"AA"
