@@ -51,6 +51,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (there is no fallback path)")
+        try:
+            # torch ships its own libamdhip64; load it first so that this library binds to the same
+            # HIP runtime instead of bringing /opt/rocm's copy into the process as a second one
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mz_last_error.restype = C.c_char_p
         _lib.mz_init.argtypes = [C.c_int]
