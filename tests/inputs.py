@@ -127,3 +127,25 @@ def random_block_pair(rng, n1: int, n2: int, length: int = 150):
     a2 = random_maf_block(rng, ref, s2, e2, n2, "y")
     beg, end = max(s1, s2), min(e1, e2) - 1
     return a1, a2, beg, end
+
+
+def random_maf_file(rng, ref: np.ndarray, nblocks: int, nrows: int, tag: str, stride: int = 260, blen=(120, 250)):
+    """single-coverage list of blocks along ref (what multiz expects of each input file)"""
+    blocks = []
+    for k in range(nblocks):
+        s = k * stride + int(rng.integers(0, 40))
+        e = min(s + int(rng.integers(*blen)), (k + 1) * stride - 1, len(ref))
+        if e - s < 30:
+            continue
+        blocks.append(random_maf_block(rng, ref, s, e, nrows, tag))
+    return blocks
+
+
+def write_maf(path: str, blocks) -> None:
+    from oracle.mzoracle import format_block, score_range
+    with open(path, "w") as f:
+        f.write("##maf version=1 scoring=blastz\n")
+        for b in blocks:
+            b.score = score_range(b, 0, b.textSize)
+            f.write(format_block(b))
+        f.write("##eof maf\n")
