@@ -66,7 +66,7 @@ enum {
  *   FAST  : same wavefront for well-formed pairs -- connected band (LB[r] <= RB[r-1]) and scores
  *           below 2^29 -- where guards that can only touch unreachable (sentinel) states are
  *           dropped; outputs are identical ("fast path equivalence") */
-enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2 };
+enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 /* FAST with tag-encoded picks */ };
 
 typedef struct mz_dev_batch {
     int32_t n;

@@ -27,7 +27,7 @@
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
 
-struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -121,9 +121,14 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 // states, which sit at about -2^30, can never win a comparison) + factorable gap_open
                 const bool small = (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 29);
                 mode = (conn && small && c_sc.g1 > 0) ? MZ_MODE_FAST : MZ_MODE_WF64;
+                // tagged variant: one more bit of headroom, doubled int16 vectors must still fit
+                if (mode == MZ_MODE_FAST && c_sc.tag_ok &&
+                    (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 28) &&
+                    2 * K * (c_sc.maxS + c_sc.go) <= 32767)
+                    mode = MZ_MODE_FASTT;
                 edgeLo = rL + 1;
-                edgeHi = rN + N;
-                szTb = (long long)(((M + N) >> 2) + 1) * WAVE;
+                edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
+                szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
             } else {
                 mode = MZ_MODE_STRIP;
                 // strips of 64 rows; strip s sweeps columns LB[first]..RB[last] with a 64-step skew.
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(WAVE) void k_dp_wf64(mz_dev_batch b)
 }
 
 // ------------------------------------------------------------------------------------------
-// fast DP kernel (MZ_MODE_FAST)
+// fast DP kernels (MZ_MODE_FAST, MZ_MODE_FASTT)
 //
 // Same wavefront as k_dp_wf64, for pairs the plan proved well-formed:
 //   (1) the band is connected: LB[r] <= RB[r-1] for every row, so every in-band grid point has at
@@ -514,8 +519,17 @@ __global__ __launch_bounds__(WAVE) void k_dp_wf64(mz_dev_batch b)
 // Arithmetic: gap_open = g1*g2; row vectors carry g1, column vectors carry -g2, both as int16
 // pairs, so that "x -= gap_open * (bilinear count form)" is one or two v_dot2c_i32_i16 with the
 // running value as accumulator.
+//
+// TAG variant (MZ_MODE_FASTT, needs scores below 2^28 and K*max|score|*2 < 2^15): every state is
+// held as 4*value + tag with tag(C)=2, tag(I)=1, tag(D)=0.  A candidate inherits the tag of the
+// state it comes from, so m = max3(x,y,z) resolves the reference's tie order by itself (C wins
+// ties; D beats I only if strictly greater, mz_yama.c:138-154) and m&3 IS the traceback flag:
+// three instructions per pick instead of five, and no flag merge.  All increments are
+// multiples of 4 (row vectors carry 2*g1, column vectors -2*g2, score vectors and counts 2x).
+// The traceback byte then holds tags, which k_walk maps back (node = 2 - tag).
 // ------------------------------------------------------------------------------------------
 #define FRING 128                 // ring entries; six dword arrays (structure of arrays: conflict-free reads)
+#define NEGT (-1610612736)        // TAG variant sentinel: -(3 << 29), a multiple of 4
 
 struct FastRow {
     int lo, hi;
@@ -525,16 +539,18 @@ struct FastRow {
     int cD;                       // gap_open * nA * L      (D.x constant part and D.z penalty)
     int penDy;                    // gap_open * L * (nA - PA00)
     int extD;                     // gap_extend * L * nA
+    int cDe, penDye;              // cD + extD, penDy + extD (interior steps fold the extension in)
     int w01, w23, w45;
 };
 
+template <bool TAG>
 __device__ __forceinline__ void fast_stage_rows(int blk, int lane, const PairCtx &J, int *recs)
 {
     const int rr = blk * WAVE + lane + 1;
     int4 *d = (int4 *)(recs + (((blk & 1) * WAVE) + lane) * REC_DW);
     if (rr > J.M) {
-        d[0] = make_int4(MZ_BIG, -1, 0, 0); d[1] = make_int4(0, 0, 0, 0);
-        d[2] = make_int4(0, 0, 0, 0);       d[3] = make_int4(0, 0, 0, 0);
+        d[0] = make_int4(MZ_BIG, MZ_BIG, 0, 0); d[1] = make_int4(0, 0, 0, 0);   // never active: lo == hi == BIG
+        d[2] = make_int4(0, 0, 0, 0);           d[3] = make_int4(0, 0, 0, 0);
         return;
     }
     const int K = J.K, L = J.L;
@@ -560,15 +576,16 @@ __device__ __forceinline__ void fast_stage_rows(int blk, int lane, const PairCtx
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
-        w[l] = acc;
+        w[l] = TAG ? 2 * acc : acc;
     }
-    const int go = c_sc.go, g1 = c_sc.g1;
+    const int V = TAG ? 4 : 1;                        // value scale
+    const int go = c_sc.go, g1 = TAG ? 2 * c_sc.g1 : c_sc.g1;
     const bool last = rr >= J.M;                      // row M: trailing end-gaps open for free
     d[0] = make_int4(J.LB[rr], J.RB[rr], pack2(nA * g1, dA * g1), pack2(-a00 * g1, -a11 * g1));
     d[1] = make_int4(pack2((nA - a00) * g1, dA * g1), pack2(0, -dA * g1),
                      last ? 0 : pack2(0, K * g1), last ? 0 : pack2(0, -dA * g1));
-    d[2] = make_int4(last ? 0 : pack2(0, -K * g1), pack2(-a00 * g1, 0), go * nA * L, go * L * (nA - a00));
-    d[3] = make_int4(c_sc.ge * L * nA, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+    d[2] = make_int4(last ? 0 : pack2(0, -K * g1), pack2(-a00 * g1, 0), V * go * nA * L, V * go * L * (nA - a00));
+    d[3] = make_int4(V * c_sc.ge * L * nA, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
 }
 
 __device__ __forceinline__ void fast_load_rec(FastRow &R, const int *src)
@@ -579,16 +596,18 @@ __device__ __forceinline__ void fast_load_rec(FastRow &R, const int *src)
     R.pC1y = b.x; R.pC2z = b.y; R.pI1 = b.z; R.pI2x = b.w;
     R.pI2z = c.x; R.pD1 = c.y; R.cD = c.z; R.penDy = c.w;
     R.extD = d.x; R.w01 = d.y; R.w23 = d.z; R.w45 = d.w;
+    R.cDe = c.z + d.x; R.penDye = c.w + d.x;
 }
 
 // ring[f * FRING + (col & (FRING-1))], f = 0..5: v1=(-g2*dB,-g2*nB)  v2=(-g2*PB11,-g2*PB00)
-// cnt01 cnt23 cnt45  extI = gap_extend*K*nB
+// cnt01 cnt23 cnt45  extI = gap_extend*K*nB          (TAG: g2, counts doubled; extI times 4)
+template <bool TAG>
 __device__ __forceinline__ void fast_stage_bcols(int first, int lane, const PairCtx &J, int *ring)
 {
     const int cc = first + lane;
     int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
     if (cc >= 1 && cc <= J.N) {
-        const int L = J.L, g2 = c_sc.g2;
+        const int L = J.L, g2 = TAG ? 2 * c_sc.g2 : c_sc.g2, cm = TAG ? 2 : 1;
         const uint8_t *col = J.B + (long long)(cc - 1) * L;
         unsigned cnt = 0;
         int dB = 0, b00 = 0, b11 = 0, other = 0;
@@ -606,10 +625,10 @@ __device__ __forceinline__ void fast_stage_bcols(int first, int lane, const Pair
         const int nB = L - dB;
         e0 = pack2(-g2 * dB, -g2 * nB);
         e1 = pack2(-g2 * b11, -g2 * b00);
-        e2 = pack2(cnt & 0xff, (cnt >> 8) & 0xff);
-        e3 = pack2((cnt >> 16) & 0xff, cnt >> 24);
-        e4 = pack2(dB, other);
-        e5 = c_sc.ge * J.K * nB;
+        e2 = pack2(cm * (cnt & 0xff), cm * ((cnt >> 8) & 0xff));
+        e3 = pack2(cm * ((cnt >> 16) & 0xff), cm * (cnt >> 24));
+        e4 = pack2(cm * dB, cm * other);
+        e5 = (TAG ? 4 : 1) * c_sc.ge * J.K * nB;
     }
     const int i = cc & (FRING - 1);
     ring[i] = e0; ring[FRING + i] = e1; ring[2 * FRING + i] = e2;
@@ -617,20 +636,22 @@ __device__ __forceinline__ void fast_stage_bcols(int first, int lane, const Pair
 }
 
 // one cell; EDGE = this step may contain cells in column 0, 1 or N
-template <bool EDGE>
+template <bool EDGE, bool TAG>
 __device__ __forceinline__ Tri fast_cell(const FastRow &R, int c, int N, const int *ring, Tri left, Tri up, Tri dg, int &tbyte)
 {
     const int i = c & (FRING - 1);
     const int v1 = ring[i], v2 = ring[FRING + i];
     const int c01 = ring[2 * FRING + i], c23 = ring[3 * FRING + i], c45 = ring[4 * FRING + i], extI = ring[5 * FRING + i];
     Tri o;
-    int fi, fc, fd, x, y, z;
+    int x, y, z;
 
     // I: x -= go*(K*nB - dA*PB00), y -= go*K*nB, z -= go*K*(nB - PB00)   (row vectors zero on row M)
     x = dot2(R.pI2x, v2, dot2(R.pI1, v1, left.C));
     y = dot2(R.pI1, v1, left.D);
     z = dot2(R.pI2z, v2, dot2(R.pI1, v1, left.I));
-    o.I = pick(x, y, z, MZ_FD << 4, MZ_FI << 4, fi) - extI;
+    int fi;
+    if (TAG) { fi = max(max(x, y), z); o.I = ((fi & ~3) | 1) - extI; }
+    else       o.I = pick(x, y, z, MZ_FD << 4, MZ_FI << 4, fi) - extI;
 
     // C
     x = dot2(R.pC2x, v2, dot2(R.pC1x, v1, dg.C));
@@ -640,20 +661,35 @@ __device__ __forceinline__ Tri fast_cell(const FastRow &R, int c, int N, const i
         const bool g = c > 1;
         x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
     }
-    x = pick(x, y, z, MZ_FD, MZ_FI, fc);
+    int fc;
+    if (TAG) { fc = max(max(x, y), z); x = (fc & ~3) | 2; }
+    else       x = pick(x, y, z, MZ_FD, MZ_FI, fc);
     o.C = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, x)));
 
-    // D
-    x = dot2(R.pD1, v1, up.C - R.cD);
-    y = up.D - R.penDy;
-    z = up.I - R.cD;
-    if (EDGE) {                                   // none in the first or last column (mz_yama.c:211)
+    // D: gap_extend*L*nA is folded into the three penalties away from the edges
+    int fd;
+    if (EDGE) {                                   // no gap-open in the first or last column (mz_yama.c:211)
         const bool g = (c > 0) & (c < N);
+        x = dot2(R.pD1, v1, up.C - R.cD);
+        y = up.D - R.penDy;
+        z = up.I - R.cD;
         x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
+        if (TAG) { fd = max(max(x, y), z); o.D = (fd & ~3) - R.extD; }
+        else       o.D = pick(x, y, z, MZ_FD << 2, MZ_FI << 2, fd) - R.extD;
+    } else {
+        x = dot2(R.pD1, v1, up.C - R.cDe);
+        y = up.D - R.penDye;
+        z = up.I - R.cDe;
+        if (TAG) { fd = max(max(x, y), z); o.D = fd & ~3; }
+        else       o.D = pick(x, y, z, MZ_FD << 2, MZ_FI << 2, fd);
     }
-    o.D = pick(x, y, z, MZ_FD << 2, MZ_FI << 2, fd) - R.extD;
 
-    tbyte = fc | fd | fi;
+    if (TAG) {
+        // bits 0-1 tag(C pick), 2-3 tag(D pick), 4-5 tag(I pick); bits 6-7 are don't-care
+        tbyte = (fc & 3) | ((fd & 3) << 2) | (fi << 4);
+    } else {
+        tbyte = fc | fd | fi;
+    }
     return o;
 }
 
@@ -665,11 +701,12 @@ struct FastState {
     int rlo, lfin, tfin, cst;
 };
 
-template <bool EDGE>
+template <bool EDGE, bool TAG>
 __device__ __forceinline__ void fast_steps(FastState &S, int t0, int t1, int lane, const PairCtx &J,
                                            int *s_rec, int *s_ring, uint32_t *tbw)
 {
     const int M = J.M, N = J.N;
+    const int negC = TAG ? NEGT + 2 : MZ_NEG, negD = TAG ? NEGT : MZ_NEG, negI = TAG ? NEGT + 1 : MZ_NEG;
     // wave-uniform control state lives in SGPRs
     t0 = __builtin_amdgcn_readfirstlane(t0);
     t1 = __builtin_amdgcn_readfirstlane(t1);
@@ -686,10 +723,10 @@ __device__ __forceinline__ void fast_steps(FastState &S, int t0, int t1, int lan
             if (lane == S.lfin) {
                 S.r = rn;
                 fast_load_rec(S.R, s_rec + ((((rn - 1) >> 6) & 1) * WAVE + lane) * REC_DW);
-                S.st.C = S.st.D = S.st.I = MZ_NEG;
+                S.st.C = negC; S.st.D = negD; S.st.I = negI;
             }
             if (S.lfin == 0) {
-                fast_stage_rows(((rn - 1) >> 6) + 1, lane, J, s_rec);
+                fast_stage_rows<TAG>(((rn - 1) >> 6) + 1, lane, J, s_rec);
                 __syncthreads();
             }
             S.rlo += 1;
@@ -697,33 +734,28 @@ __device__ __forceinline__ void fast_steps(FastState &S, int t0, int t1, int lan
             S.tfin = S.rlo > M ? MZ_BIG : S.rlo + __builtin_amdgcn_readlane(S.R.hi, S.lfin);
         }
         if (t - S.rlo > S.cst) {
-            fast_stage_bcols(S.cst + 1, lane, J, s_ring);
+            fast_stage_bcols<TAG>(S.cst + 1, lane, J, s_ring);
             S.cst += WAVE;
             __syncthreads();
         }
 
         const int c = t - S.r;
         int tbyte;
-        const Tri nw = fast_cell<EDGE>(S.R, c, N, s_ring, S.st, S.up, S.dg, tbyte);
-        const bool active = (c >= S.R.lo) & (c <= S.R.hi);
-        S.st.C = active ? nw.C : MZ_NEG;
-        S.st.D = active ? nw.D : MZ_NEG;
-        S.st.I = active ? nw.I : MZ_NEG;
-        if (EDGE && S.rlo == 0 && lane == WAVE - 1) { S.st.C = MZ_NEG; S.st.D = MZ_NEG; }   // row 0
+        const Tri nw = fast_cell<EDGE, TAG>(S.R, c, N, s_ring, S.st, S.up, S.dg, tbyte);
+        const bool active = (unsigned)(c - S.R.lo) <= (unsigned)(S.R.hi - S.R.lo);
+        S.st.C = active ? nw.C : negC;
+        S.st.D = active ? nw.D : negD;
+        S.st.I = active ? nw.I : negI;
+        if (EDGE && S.rlo == 0 && lane == WAVE - 1) { S.st.C = negC; S.st.D = negD; }   // row 0
 
         S.tbword = __builtin_amdgcn_alignbyte(tbyte, S.tbword, 1);
         if ((t & 3) == 3) tbw[(t >> 2) * WAVE + lane] = S.tbword;
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
+template <bool TAG>
+__device__ __forceinline__ void dp_fast_body(const mz_dev_batch &b, int p, int lane, int *s_rec, int *s_ring)
 {
-    __shared__ __attribute__((aligned(16))) int s_rec[2 * WAVE * REC_DW];
-    __shared__ __attribute__((aligned(16))) int s_ring[6 * FRING];
-
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_FAST) return;
-
     PairCtx J;
     J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
     J.A = b.poolA + b.offA[p]; J.B = b.poolB + b.offB[p];
@@ -731,28 +763,28 @@ __global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
     const int M = J.M, N = J.N;
     uint32_t *tbw = b.tbw + b.offTb[p];
 
-    fast_stage_rows(0, lane, J, s_rec);
-    fast_stage_rows(1, lane, J, s_rec);
-    fast_stage_bcols(0, lane, J, s_ring);            // columns 0..63 (column 0 = zero entry)
-    fast_stage_bcols(WAVE, lane, J, s_ring);         // columns 64..127
+    fast_stage_rows<TAG>(0, lane, J, s_rec);
+    fast_stage_rows<TAG>(1, lane, J, s_rec);
+    fast_stage_bcols<TAG>(0, lane, J, s_ring);       // columns 0..63 (column 0 = zero entry)
+    fast_stage_bcols<TAG>(WAVE, lane, J, s_ring);    // columns 64..127
     __syncthreads();
 
     FastState S;
     S.cst = 2 * WAVE - 1;
-    S.st.C = S.st.D = S.st.I = MZ_NEG;
+    S.st.C = TAG ? NEGT + 2 : MZ_NEG; S.st.D = TAG ? NEGT : MZ_NEG; S.st.I = TAG ? NEGT + 1 : MZ_NEG;
     if (lane == WAVE - 1) {                           // row 0 (mz_yama.c:83-94)
         S.r = 0;
         S.R.lo = 0; S.R.hi = J.RB[0];
         S.R.pC1x = S.R.pC2x = S.R.pC1y = S.R.pC2z = S.R.pI1 = S.R.pI2x = S.R.pI2z = S.R.pD1 = 0;
-        S.R.cD = S.R.penDy = S.R.extD = 0; S.R.w01 = S.R.w23 = S.R.w45 = 0;
-        S.st.C = S.st.D = S.st.I = 0;                 // grid point (0,0)
+        S.R.cD = S.R.penDy = S.R.extD = S.R.cDe = S.R.penDye = 0; S.R.w01 = S.R.w23 = S.R.w45 = 0;
+        S.st.C = TAG ? 2 : 0; S.st.D = 0; S.st.I = TAG ? 1 : 0;      // grid point (0,0): value 0
     } else {
         S.r = lane + 1;
         fast_load_rec(S.R, s_rec + lane * REC_DW);
     }
     S.rlo = 0; S.lfin = WAVE - 1;
     S.tfin = __builtin_amdgcn_readlane(S.R.hi, WAVE - 1);
-    S.up.C = S.up.D = S.up.I = MZ_NEG;
+    S.up.C = TAG ? NEGT + 2 : MZ_NEG; S.up.D = TAG ? NEGT : MZ_NEG; S.up.I = TAG ? NEGT + 1 : MZ_NEG;
     S.dg = S.up;
     S.tbword = 0;
 
@@ -762,17 +794,334 @@ __global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
     int eHi = b.edgeHi[p];
     eLo = min(eLo, Tend);
     eHi = max(eHi, eLo + 1);
-    fast_steps<true>(S, 1, eLo, lane, J, s_rec, s_ring, tbw);
-    fast_steps<false>(S, eLo + 1, min(eHi - 1, Tend), lane, J, s_rec, s_ring, tbw);
-    fast_steps<true>(S, max(eHi, eLo + 1), Tend, lane, J, s_rec, s_ring, tbw);
+    fast_steps<true, TAG>(S, 1, eLo, lane, J, s_rec, s_ring, tbw);
+    fast_steps<false, TAG>(S, eLo + 1, min(eHi - 1, Tend), lane, J, s_rec, s_ring, tbw);
+    fast_steps<true, TAG>(S, max(eHi, eLo + 1), Tend, lane, J, s_rec, s_ring, tbw);
 
     if ((Tend & 3) != 3)
         tbw[(Tend >> 2) * WAVE + lane] = S.tbword >> (8 * (3 - (Tend & 3)));
-    if (lane == ((M - 1) & (WAVE - 1))) {
-        b.final3[3 * p + 0] = S.st.C;
-        b.final3[3 * p + 1] = S.st.D;
-        b.final3[3 * p + 2] = S.st.I;
+    if (lane == ((M - 1) & (WAVE - 1))) {             // (C,D,I) at (M,N), unscaled
+        b.final3[3 * p + 0] = TAG ? S.st.C >> 2 : S.st.C;
+        b.final3[3 * p + 1] = TAG ? S.st.D >> 2 : S.st.D;
+        b.final3[3 * p + 2] = TAG ? S.st.I >> 2 : S.st.I;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// tagged fast kernel body (MZ_MODE_FASTT) -- the tuned form of the fast kernel.
+//
+// On gfx950 every integer / dot / select VALU instruction of this loop occupies its SIMD for 4
+// cycles and one wave per SIMD already saturates that pipe (measured: identical kernel time at
+// 1, 2 and 3.5 waves per SIMD), so the step is built to minimise VALU instructions:
+//  * states are 4*value + tag (tag C=2, I=1, D=0): one v_max3 resolves the reference's tie
+//    order and its low two bits are the traceback flag;
+//  * the flags of the three picks go into three 2-bit streams with one v_alignbit each and are
+//    stored every 16 steps (layout: tbw[((t>>4)*3 + s)*64 + lane], s = 0 C, 1 D, 2 I picks);
+//  * nB = L - dB is eliminated: column vectors uA = -2*g2*(dB, PB00), uB = -2*g2*(PB11, 0); the
+//    constant parts of the penalties (4*go*K*L for I, 4*go*dA*L for C) are folded into the ring's
+//    extension term and into the score row vector (sum of the class counts is L);
+//  * gap_extend*L*nA is folded into the D penalties; the column counter is kept times 4 so that
+//    it is the ring byte offset; the step loop is unrolled by two so that the "row above, one
+//    step ago" registers alternate roles instead of being copied.
+// Steps that can touch column 0/1/N, row 0 or row M run the EDGE form, which undoes the folds
+// where the reference charges no gap-open.
+// ------------------------------------------------------------------------------------------
+#define TREC 20                   // dwords per staged row record
+
+struct TagRow {
+    int lo4, wid4;                // 4*LB[r], 4*(RB[r]-LB[r])
+    int rIx, rIy, rIz;            // I-state row vectors against uA (zero on row M)
+    int rCxA, rCxB, rCy, rCz;     // C-state row vectors
+    int rDx;                      // D-state x row vector against uA
+    int cDe, penDye;              // 4*(go*nA*L + ge*L*nA), 4*(go*L*(nA-PA00) + ge*L*nA)
+    int w01, w23, w45;            // 2*(w[k] - go*dA)
+    int kC, extD, kIfix;          // EDGE only: 4*go*dA*L, 4*ge*L*nA, (row 0 or M) ? 4*go*K*L : 0
+};
+
+__device__ __forceinline__ void tag_stage_rows(int blk, int lane, const PairCtx &J, int *recs)
+{
+    const int rr = blk * WAVE + lane + 1;
+    int4 *d = (int4 *)(recs + (((blk & 1) * WAVE) + lane) * TREC);
+    if (rr > J.M) {
+        d[0] = make_int4(MZ_BIG, 0, 0, 0);            // never active: column counter never reaches BIG
+        d[1] = d[2] = d[3] = d[4] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    const int K = J.K, L = J.L;
+    const uint8_t *col = J.A + (long long)(rr - 1) * K;
+    unsigned cnt = 0;
+    int dA = 0, a00 = 0, a11 = 0, other = 0;
+    for (int i = 0; i < K; ++i) {
+        const unsigned ch = col[i];
+        const bool dash = ch == '-';
+        const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
+        const int cl = byte_class(ch);
+        cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+        other += cl == 5;
+        dA += dash;
+        a00 += (!dash) & (!pdash);
+        a11 += dash & pdash;
+    }
+    const int nA = K - dA;
+    const int go = c_sc.go, ge = c_sc.ge, g1 = 2 * c_sc.g1;
+    int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
+    int w[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
+        w[l] = 2 * (acc - go * dA);                   // -go*dA per unit count: sums to -go*dA*L over a column
+    }
+    const bool last = rr >= J.M;
+    const int lo = J.LB[rr], hi = J.RB[rr];
+    d[0] = make_int4(4 * lo, 4 * (hi - lo),
+                     last ? 0 : pack2(-K * g1, -dA * g1), last ? 0 : pack2(-K * g1, 0));
+    d[1] = make_int4(last ? 0 : pack2(-K * g1, -K * g1),
+                     pack2((nA - dA) * g1, -a11 * g1), pack2(-a00 * g1, 0), pack2((nA - a00 - dA) * g1, 0));
+    d[2] = make_int4(pack2((nA - dA) * g1, -dA * g1), pack2(-a00 * g1, 0),
+                     4 * (go + ge) * nA * L, 4 * (go * L * (nA - a00) + ge * L * nA));
+    d[3] = make_int4(pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]), 4 * go * dA * L);
+    d[4] = make_int4(4 * ge * L * nA, last ? 4 * go * K * L : 0, 0, 0);
+}
+
+__device__ __forceinline__ void tag_load_rec(TagRow &R, const int *src)
+{
+    const int4 *s = (const int4 *)src;
+    const int4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4];
+    R.lo4 = a.x; R.wid4 = a.y; R.rIx = a.z; R.rIy = a.w;
+    R.rIz = b.x; R.rCxA = b.y; R.rCxB = b.z; R.rCy = b.w;
+    R.rCz = c.x; R.rDx = c.y; R.cDe = c.z; R.penDye = c.w;
+    R.w01 = d.x; R.w23 = d.y; R.w45 = d.z; R.kC = d.w;
+    R.extD = e.x; R.kIfix = e.y;
+}
+
+// ring[f*FRING + (col & 127)]: uA=-2g2*(dB,PB00)  uB=-2g2*(PB11,0)  2*cnt01 2*cnt23 2*cnt45
+//                              xI = 4*ge*K*nB + 4*go*K*L - 1
+__device__ __forceinline__ void tag_stage_bcols(int first, int lane, const PairCtx &J, int *ring)
+{
+    const int cc = first + lane;
+    int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * c_sc.go * J.K * J.L - 1;
+    if (cc >= 1 && cc <= J.N) {
+        const int L = J.L, g2 = 2 * c_sc.g2;
+        const uint8_t *col = J.B + (long long)(cc - 1) * L;
+        unsigned cnt = 0;
+        int dB = 0, b00 = 0, b11 = 0, other = 0;
+        for (int j = 0; j < L; ++j) {
+            const unsigned ch = col[j];
+            const bool dash = ch == '-';
+            const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
+            const int cl = byte_class(ch);
+            cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+            other += cl == 5;
+            dB += dash;
+            b00 += (!dash) & (!pdash);
+            b11 += dash & pdash;
+        }
+        e0 = pack2(-g2 * dB, -g2 * b00);
+        e1 = pack2(-g2 * b11, 0);
+        e2 = pack2(2 * (cnt & 0xff), 2 * ((cnt >> 8) & 0xff));
+        e3 = pack2(2 * ((cnt >> 16) & 0xff), 2 * (cnt >> 24));
+        e4 = pack2(2 * dB, 2 * other);
+        e5 += 4 * c_sc.ge * J.K * (L - dB);
+    }
+    const int i = cc & (FRING - 1);
+    ring[i] = e0; ring[FRING + i] = e1; ring[2 * FRING + i] = e2;
+    ring[3 * FRING + i] = e3; ring[4 * FRING + i] = e4; ring[5 * FRING + i] = e5;
+}
+
+struct TagState {
+    TagRow R;
+    Tri st;                       // this lane's latest cell (tagged), sentinel while idle
+    Tri u0, u1;                   // row above: alternately "one step ago" / "two steps ago"
+    int r4;                       // 4 * current row
+    unsigned wC, wD, wI;          // 2-bit flag streams
+    int rlo, lfin, tfin, cst;
+};
+
+// one step; Un receives the row-above triple of this step, Uo holds the one of the step before
+template <bool EDGE>
+__device__ __forceinline__ void tag_step(TagState &S, Tri &Un, const Tri &Uo, int t, int lane, const PairCtx &J,
+                                         int *s_rec, const int *s_ring, int *s_ring_w, uint32_t *tbw)
+{
+    Un.C = ror1(S.st.C); Un.D = ror1(S.st.D); Un.I = ror1(S.st.I);
+
+    if (t > S.tfin) {                                  // oldest row finished at step t-1
+        const int rn = S.rlo + WAVE;
+        if (lane == S.lfin) {
+            S.r4 = 4 * rn;
+            tag_load_rec(S.R, s_rec + ((((rn - 1) >> 6) & 1) * WAVE + lane) * TREC);
+            S.st.C = NEGT + 2; S.st.D = NEGT; S.st.I = NEGT + 1;
+        }
+        if (S.lfin == 0) {
+            tag_stage_rows(((rn - 1) >> 6) + 1, lane, J, s_rec);
+            __syncthreads();
+        }
+        S.rlo += 1;
+        S.lfin = (S.lfin + 1) & (WAVE - 1);
+        const int l4 = __builtin_amdgcn_readlane(S.R.lo4, S.lfin), w4 = __builtin_amdgcn_readlane(S.R.wid4, S.lfin);
+        S.tfin = S.rlo > J.M ? MZ_BIG : S.rlo + ((l4 + w4) >> 2);
+    }
+    if (t - S.rlo > S.cst) {
+        tag_stage_bcols(S.cst + 1, lane, J, s_ring_w);
+        S.cst += WAVE;
+        __syncthreads();
+    }
+
+    const TagRow &R = S.R;
+    const int c4 = 4 * t - S.r4;                       // 4 * column; also the ring byte offset
+    const int *e = (const int *)((const char *)s_ring + (c4 & (4 * FRING - 4)));
+    const int uA = e[0], uB = e[FRING], c01 = e[2 * FRING], c23 = e[3 * FRING], c45 = e[4 * FRING], xI = e[5 * FRING];
+    const Tri left = S.st, &up = Un, &dg = Uo;
+    int x, y, z, mI, mC, mD, nI, nC, nD;
+
+    // I: candidates inherit tags 2 / 0 / 1 from C / D / I of (r, c-1)
+    x = dot2(R.rIx, uA, left.C);
+    y = dot2(R.rIy, uA, left.D);
+    z = dot2(R.rIz, uA, left.I);
+    mI = max(max(x, y), z);
+    nI = (mI & ~3) - xI;
+    if (EDGE) nI += R.kIfix;                           // rows 0 and M pay no gap-open (mz_yama.c:123)
+
+    // C
+    x = dot2(R.rCxB, uB, dot2(R.rCxA, uA, dg.C));
+    y = dot2(R.rCy, uA, dg.D);
+    z = dot2(R.rCz, uA, dg.I);
+    if (EDGE) {                                        // no gap-open entering column 1 (mz_yama.c:173)
+        const bool g = c4 > 4;
+        x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
+        mC = max(max(x, y), z);
+        nC = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, (mC & ~3) | 2))) + (g ? 0 : R.kC);
+    } else {
+        mC = max(max(x, y), z);
+        nC = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, (mC & ~3) | 2)));
+    }
+
+    // D
+    if (EDGE) {                                        // none in column 0 or N (mz_yama.c:211)
+        const bool g = (c4 > 0) & (c4 < 4 * J.N);
+        x = dot2(R.rDx, uA, up.C - (R.cDe - R.extD));
+        y = up.D - (R.penDye - R.extD);
+        z = up.I - (R.cDe - R.extD);
+        x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
+        mD = max(max(x, y), z);
+        nD = (mD & ~3) - R.extD;
+    } else {
+        x = dot2(R.rDx, uA, up.C - R.cDe);
+        y = up.D - R.penDye;
+        z = up.I - R.cDe;
+        mD = max(max(x, y), z);
+        nD = mD & ~3;
+    }
+
+    // idle lanes keep publishing the sentinel (the reference's "unwritten dp[col] is still MININT")
+    const bool active = (unsigned)(c4 - R.lo4) <= (unsigned)R.wid4;
+    S.st.C = active ? nC : NEGT + 2;
+    S.st.D = active ? nD : NEGT;
+    S.st.I = active ? nI : NEGT + 1;
+    if (EDGE && S.rlo == 0 && lane == WAVE - 1) { S.st.C = NEGT + 2; S.st.D = NEGT; }   // row 0: C = D = NEG
+
+    S.wC = __builtin_amdgcn_alignbit(mC, S.wC, 2);
+    S.wD = __builtin_amdgcn_alignbit(mD, S.wD, 2);
+    S.wI = __builtin_amdgcn_alignbit(mI, S.wI, 2);
+    if ((t & 15) == 15) {
+        uint32_t *g = tbw + (t >> 4) * (3 * WAVE) + lane;
+        g[0] = S.wC; g[WAVE] = S.wD; g[2 * WAVE] = S.wI;
+    }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void tag_steps(TagState &S, int t0, int t1, int lane, const PairCtx &J,
+                                          int *s_rec, int *s_ring, uint32_t *tbw)
+{
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    t1 = __builtin_amdgcn_readfirstlane(t1);
+    S.rlo = __builtin_amdgcn_readfirstlane(S.rlo);
+    S.lfin = __builtin_amdgcn_readfirstlane(S.lfin);
+    S.tfin = __builtin_amdgcn_readfirstlane(S.tfin);
+    S.cst = __builtin_amdgcn_readfirstlane(S.cst);
+    int t = t0;
+    if ((t & 1) && t <= t1) {                          // odd steps write u1, even steps write u0
+        tag_step<EDGE>(S, S.u1, S.u0, t, lane, J, s_rec, s_ring, s_ring, tbw);
+        ++t;
+    }
+    for (; t + 1 <= t1; t += 2) {
+        tag_step<EDGE>(S, S.u0, S.u1, t, lane, J, s_rec, s_ring, s_ring, tbw);
+        tag_step<EDGE>(S, S.u1, S.u0, t + 1, lane, J, s_rec, s_ring, s_ring, tbw);
+    }
+    if (t <= t1)
+        tag_step<EDGE>(S, S.u0, S.u1, t, lane, J, s_rec, s_ring, s_ring, tbw);
+}
+
+__device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int lane, int *s_rec, int *s_ring)
+{
+    PairCtx J;
+    J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
+    J.A = b.poolA + b.offA[p]; J.B = b.poolB + b.offB[p];
+    J.LB = b.poolLB + b.offBand[p]; J.RB = b.poolRB + b.offBand[p];
+    const int M = J.M, N = J.N;
+    uint32_t *tbw = b.tbw + b.offTb[p];
+
+    tag_stage_rows(0, lane, J, s_rec);
+    tag_stage_rows(1, lane, J, s_rec);
+    tag_stage_bcols(0, lane, J, s_ring);
+    tag_stage_bcols(WAVE, lane, J, s_ring);
+    __syncthreads();
+
+    TagState S;
+    S.cst = 2 * WAVE - 1;
+    S.st.C = NEGT + 2; S.st.D = NEGT; S.st.I = NEGT + 1;
+    if (lane == WAVE - 1) {                           // row 0 (mz_yama.c:83-94): every vector zero, no opens
+        S.r4 = 0;
+        S.R.lo4 = 0; S.R.wid4 = 4 * J.RB[0];
+        S.R.rIx = S.R.rIy = S.R.rIz = S.R.rCxA = S.R.rCxB = S.R.rCy = S.R.rCz = S.R.rDx = 0;
+        S.R.cDe = S.R.penDye = 0; S.R.w01 = S.R.w23 = S.R.w45 = 0;
+        S.R.kC = S.R.extD = 0; S.R.kIfix = 4 * c_sc.go * J.K * J.L;
+        S.st.C = 2; S.st.D = 0; S.st.I = 1;           // grid point (0,0): value 0 in all three states
+    } else {
+        S.r4 = 4 * (lane + 1);
+        tag_load_rec(S.R, s_rec + lane * TREC);
+    }
+    S.rlo = 0; S.lfin = WAVE - 1;
+    S.tfin = J.RB[0];
+    S.u0.C = NEGT + 2; S.u0.D = NEGT; S.u0.I = NEGT + 1;
+    S.u1 = S.u0;
+    S.wC = S.wD = S.wI = 0;
+
+    const int Tend = M + N;
+    int eLo = max(b.edgeLo[p], J.RB[0] + 1);          // row 0 is live until step RB[0]
+    int eHi = b.edgeHi[p];                            // first step that can touch column N or row M
+    eLo = min(eLo, Tend);
+    eHi = max(eHi, eLo + 1);
+    tag_steps<true>(S, 1, eLo, lane, J, s_rec, s_ring, tbw);
+    tag_steps<false>(S, eLo + 1, min(eHi - 1, Tend), lane, J, s_rec, s_ring, tbw);
+    tag_steps<true>(S, max(eHi, eLo + 1), Tend, lane, J, s_rec, s_ring, tbw);
+
+    if ((Tend & 15) != 15) {                          // flush the partial group
+        const int sh = 2 * (15 - (Tend & 15));
+        uint32_t *g = tbw + (Tend >> 4) * (3 * WAVE) + lane;
+        g[0] = S.wC >> sh; g[WAVE] = S.wD >> sh; g[2 * WAVE] = S.wI >> sh;
+    }
+    if (lane == ((M - 1) & (WAVE - 1))) {             // (C,D,I) at (M,N), unscaled
+        b.final3[3 * p + 0] = S.st.C >> 2;
+        b.final3[3 * p + 1] = S.st.D >> 2;
+        b.final3[3 * p + 2] = S.st.I >> 2;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
+{
+    __shared__ __attribute__((aligned(16))) int s_rec[2 * WAVE * TREC];
+    __shared__ __attribute__((aligned(16))) int s_ring[6 * FRING];
+#ifdef MZ_LDS_PAD
+    __shared__ int s_pad[MZ_LDS_PAD];
+    if (b.n < 0) s_pad[threadIdx.x] = 1;
+#endif
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK) return;
+    const int mode = b.mode[p];
+    if (mode == MZ_MODE_FASTT)     dp_tag_body(b, p, lane, s_rec, s_ring);
+    else if (mode == MZ_MODE_FAST) dp_fast_body<false>(b, p, lane, s_rec, s_ring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -934,6 +1283,7 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
+    const bool tagged = mode == MZ_MODE_FASTT;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -943,11 +1293,19 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
     while (r > 0 || c > 0) {
         if (r < 0 || c < 0 || n >= limit) { status = MZ_E_TRACEBACK; break; }
         unsigned stb;
+        const int r_was = r;
         if (r == 0) {
             stb = MZ_FI << 4;                              // row 0 bytes, mz_yama.c:92
+        } else if (tagged) {
+            // 2-bit tag streams: word ((t>>4)*3 + s)*64 + lane, s = 0/1/2 for the C/D/I pick; read only
+            // the stream of the node we stand on and put its tag where the decode below expects it
+            const int t = r + c, l = (r - 1) & (WAVE - 1);
+            const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
+            const unsigned tg = (tbw[((t >> 4) * 3 + sidx) * WAVE + l] >> (2 * (t & 15))) & 3;
+            stb = tg | (tg << 2) | (tg << 4);
         } else if (mode != MZ_MODE_STRIP) {
-            const int t = r + c;
-            stb = (tbw[(t >> 2) * WAVE + ((r - 1) & (WAVE - 1))] >> (8 * (t & 3))) & 0xff;
+            const int t = r + c, g = t >> 2, l = (r - 1) & (WAVE - 1);
+            stb = (tbw[g * WAVE + l] >> (8 * (t & 3))) & 0xff;
         } else {
             const int s = (r - 1) >> 6, l = (r - 1) & (WAVE - 1);
             const int clo = (int)tbw[2 * s];
@@ -956,10 +1314,12 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
             stb = (tbw[base + (long long)(tau >> 2) * WAVE + l] >> (8 * (tau & 3))) & 0xff;
         }
         ops[n++] = (uint8_t)node;
-        if (node == MZ_FI)      { c -= 1;         node = (stb >> 4) & 3; }
-        else if (node == MZ_FD) { r -= 1;         node = (stb >> 2) & 3; }
-        else if (node == MZ_FC) { r -= 1; c -= 1; node = stb & 3; }
+        int nx;
+        if (node == MZ_FI)      { c -= 1;         nx = (stb >> 4) & 3; }
+        else if (node == MZ_FD) { r -= 1;         nx = (stb >> 2) & 3; }
+        else if (node == MZ_FC) { r -= 1; c -= 1; nx = stb & 3; }
         else { status = MZ_E_TRACEBACK; break; }
+        node = (tagged && r_was > 0) ? 2 - nx : nx;     // tagged kernels store tie-break tags: C=2, I=1, D=0
     }
     if (status == MZ_OK && (r != 0 || c != 0)) status = MZ_E_TRACEBACK;
     b.om[p] = n;
@@ -1022,6 +1382,9 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.ge = m->gap_extend;
     h.g1 = m->g1;
     h.g2 = m->g2;
+    h.maxS = 0;
+    for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
+    h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
     return 0;

@@ -177,8 +177,8 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     m->g1 = m->g2 = 0;
     if (!g_no_fast && (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0)) {
         if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
-        else for (x = 258; x >= 1; --x)
-            if (m->gap_open % x == 0 && m->gap_open / x <= 258) { m->g1 = x; m->g2 = m->gap_open / x; break; }
+        else for (x = 1; x * x <= m->gap_open; ++x)       /* the most balanced factorisation */
+            if (m->gap_open % x == 0 && m->gap_open / x <= 258) { m->g1 = m->gap_open / x; m->g2 = x; }
     }
     for (a = 0; a < 36; ++a)
         if (m->S6[a] < -258 || m->S6[a] > 258)      /* 127 rows * |score| must fit the int16 dot-product operand */
