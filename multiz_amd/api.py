@@ -38,9 +38,11 @@ class Out(C.Structure):
 class DevBatchC(C.Structure):
     _fields_ = [("n", C.c_int32), ("pad_", C.c_int32)] + \
         [(k, C.c_void_p) for k in ("K", "L", "M", "N", "offA", "offB", "offBand", "poolA", "poolB", "poolLB", "poolRB",
-                                   "status", "badrow", "mode", "cells", "edgeLo", "edgeHi", "szTb", "szScript", "szOut",
-                                   "offTb", "offScript", "offOut", "totals", "tbw", "script", "out")] + \
-        [("capTb", C.c_int64), ("capScript", C.c_int64), ("capOut", C.c_int64), ("om", C.c_void_p), ("final3", C.c_void_p)]
+                                   "status", "badrow", "mode", "cells", "edgeLo", "edgeHi", "szTb", "szScript", "szOut", "szPrep",
+                                   "offTb", "offScript", "offOut", "offPrep", "totals", "packList", "scanAux",
+                                   "tbw", "script", "out", "prep")] + \
+        [("capTb", C.c_int64), ("capScript", C.c_int64), ("capOut", C.c_int64), ("capPrep", C.c_int64),
+         ("om", C.c_void_p), ("final3", C.c_void_p)]
 
 
 _lib = None
@@ -161,8 +163,11 @@ class DevBatch:
         self.tbw = torch.empty(tb + 64, dtype=torch.int32, device=self.dev)
         self.script = torch.empty(sc + 64, dtype=torch.uint8, device=self.dev)
         self.out = torch.empty(ou + 64, dtype=torch.uint8, device=self.dev)
-        self.c.tbw, self.c.script, self.c.out = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr()
-        self.c.capTb, self.c.capScript, self.c.capOut = tb + 64, sc + 64, ou + 64
+        # packed kernel: 20 dwords per (padded) row + 7 dwords per (padded) column
+        pr = int(((((M + 47) // 48) * 48 + 96) * 20 + 7 * (((N + 1 + 63) // 64) * 64 + 64)).sum())
+        self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)
+        self.c.tbw, self.c.script, self.c.out, self.c.prep = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr(), self.prep.data_ptr()
+        self.c.capTb, self.c.capScript, self.c.capOut, self.c.capPrep = tb + 64, sc + 64, ou + 64, pr + 64
 
     def stream_ptr(self):
         return self.torch.cuda.current_stream(self.dev).cuda_stream
@@ -184,7 +189,7 @@ class DevBatch:
         return dict(status=self._view(self.c.status, n, np.int32), mode=self._view(self.c.mode, n, np.int32),
                     cells=self._view(self.c.cells, n, np.int64), om=self._view(self.c.om, n, np.int32),
                     final3=self._view(self.c.final3, 3 * n, np.int32).reshape(n, 3),
-                    offOut=self._view(self.c.offOut, n, np.int64), totals=self._view(self.c.totals, 4, np.int64))
+                    offOut=self._view(self.c.offOut, n, np.int64), totals=self._view(self.c.totals, 8, np.int64))
 
     def output_cols(self, i: int, res: dict, K: int, L: int):
         om, off = int(res["om"][i]), int(res["offOut"][i])

@@ -68,7 +68,7 @@ static struct {
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
-    gbuf h_in, d_in, d_plan, d_tb, d_script, d_out, h_res;
+    gbuf h_in, d_in, d_plan, d_tb, d_script, d_out, d_prep, h_res;
 } G;
 
 static int dev_reserve(gbuf *b, size_t need)
@@ -114,10 +114,10 @@ int mz_init(int device)
 void mz_finalize(void)
 {
     int i;
-    gbuf *d[] = { &G.d_in, &G.d_plan, &G.d_tb, &G.d_script, &G.d_out };
+    gbuf *d[] = { &G.d_in, &G.d_plan, &G.d_tb, &G.d_script, &G.d_out, &G.d_prep };
     if (!G.ready) return;
     hipStreamSynchronize(G.stream);
-    for (i = 0; i < 5; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+    for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
     if (G.h_in.p)  { hipHostFree(G.h_in.p);  G.h_in.p = NULL;  G.h_in.cap = 0; }
     if (G.h_res.p) { hipHostFree(G.h_res.p); G.h_res.p = NULL; G.h_res.cap = 0; }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
@@ -136,6 +136,7 @@ static int ensure_init(void)
 /* ------------------------------------------------------------------ scores */
 
 static int g_no_fast;                      /* mz_enable_fast(0): exact kernels only */
+static int g_pack;                         /* mz_enable_pack(1): experimental packed kernel */
 
 static int class_of(int ch)
 {
@@ -175,6 +176,7 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     /* gap_open = g1*g2, both small enough that 127*g fits an int16 dot-product operand; the fast
      * kernel needs it (MZ_NO_FAST=1 in the environment disables that kernel: exact kernel only) */
     m->g1 = m->g2 = 0;
+    m->pack = g_pack || (getenv("MZ_PACK") && atoi(getenv("MZ_PACK")) != 0);
     if (!g_no_fast && (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0)) {
         if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
         else for (x = 1; x * x <= m->gap_open; ++x)       /* the most balanced factorisation */
@@ -209,6 +211,13 @@ void mz_enable_fast(int on)
     mz_scores_explicit = 0;
 }
 
+void mz_enable_pack(int on)
+{
+    g_pack = on != 0;
+    G.scores_ok = 0;
+    mz_scores_explicit = 0;
+}
+
 /* hand the reference-style globals (ss, gop, gap_extend) to the device if they changed */
 static int sync_global_scores(void)
 {
@@ -231,8 +240,9 @@ size_t mz_dev_plan_bytes(int n)
 {
     size_t s = 0, N = (size_t)(n > 0 ? n : 1);
     s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
-    s += 7 * al256(8 * N);                 /* cells, 3 sizes, 3 offsets */
-    s += al256(8 * 4);                     /* totals */
+    s += 9 * al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
+    s += al256(8 * 8);                     /* totals */
+    s += al256(4 * N) + al256(8 * 6 * (N / 1024 + 2));   /* packList, scanAux */
     s += al256(4 * N) + al256(12 * N);     /* om, final3 */
     return s;
 }
@@ -245,9 +255,10 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     TAKE(status, int32_t *, 4 * N); TAKE(badrow, int32_t *, 4 * N); TAKE(mode, int32_t *, 4 * N);
     TAKE(edgeLo, int32_t *, 4 * N); TAKE(edgeHi, int32_t *, 4 * N);
     TAKE(cells, int64_t *, 8 * N);
-    TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N);
-    TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N);
-    TAKE(totals, int64_t *, 32);
+    TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N); TAKE(szPrep, int64_t *, 8 * N);
+    TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N); TAKE(offPrep, int64_t *, 8 * N);
+    TAKE(totals, int64_t *, 64);
+    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 6 * (N / 1024 + 2));
     TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
 #undef TAKE
 }
@@ -305,7 +316,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
     char *h, *d;
     int32_t *hK, *hL, *hM, *hN, *hLB, *hRB;
-    int64_t *hoA, *hoB, *hoBand, totals[4];
+    int64_t *hoA, *hoB, *hoBand, totals[8];
     uint8_t *hA, *hB;
     int p, failed = 0;
 
@@ -358,15 +369,16 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 
     if (dev_reserve(&G.d_plan, mz_dev_plan_bytes(n))) return -1;
     mz_dev_carve(&b, G.d_plan.p);
-    b.capTb = b.capScript = b.capOut = INT64_MAX;        /* sizes are not known yet */
+    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
     if (mzk_plan(&b, G.stream)) return set_err("%s", mzk_last_error());
     HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, G.stream));
     HIPCK(hipStreamSynchronize(G.stream));
 
     if (dev_reserve(&G.d_tb, 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script, (size_t)totals[1] + 256) ||
-        dev_reserve(&G.d_out, (size_t)totals[2] + 256))
+        dev_reserve(&G.d_out, (size_t)totals[2] + 256) || dev_reserve(&G.d_prep, 4 * (size_t)totals[4] + 256))
         return -1;
     b.tbw = (uint32_t *)G.d_tb.p; b.script = (uint8_t *)G.d_script.p; b.out = (uint8_t *)G.d_out.p;
+    b.prep = (uint32_t *)G.d_prep.p; b.capPrep = (int64_t)(G.d_prep.cap / 4);
     b.capTb = (int64_t)(G.d_tb.cap / 4); b.capScript = (int64_t)G.d_script.cap; b.capOut = (int64_t)G.d_out.cap;
 
     if (mzk_dp(&b, G.stream) || mzk_walk(&b, G.stream) || mzk_emit(&b, G.stream))

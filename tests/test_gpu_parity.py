@@ -17,24 +17,7 @@ def mz():
     m.api.init(0)
     yield m
     m.lib().mz_enable_fast(1)
-
-
-def _check(res, pairs, tags=None, exact_scores=True):
-    for i, ((A, B, LB, RB), r) in enumerate(zip(pairs, res)):
-        tag = tags[i] if tags else i
-        want = mo.yama(A, B, LB, RB, variant="profile")
-        assert want.rc == 0
-        assert r.status == 0, (tag, r.status)
-        assert r.OM == want.OM, tag
-        assert np.array_equal(r.cols, want.cols), tag
-        # (C,D,I) at (M,N): the fast kernel may hold a different value in an UNREACHABLE state
-        # (about -2^30 either way); reachable ones and the winner must agree
-        if exact_scores:
-            assert np.array_equal(r.score, want.final), tag
-        else:
-            assert r.score.max() == want.final.max(), tag
-            live = want.final > -(1 << 29)
-            assert np.array_equal(r.score[live], want.final[live]), tag
+    m.lib().mz_enable_pack(0)
 
 
 @pytest.mark.parametrize("fast", [1, 0])
@@ -202,3 +185,44 @@ def test_empty_and_tiny_batches(mz):
     A = np.frombuffer(b"A", dtype=np.uint8).reshape(1, 1)
     r = mz.yama_one(A, A, np.array([0, 0], dtype=np.int32), np.array([1, 1], dtype=np.int32))
     assert r.status == 0 and r.OM == 1 and bytes(r.cols.ravel()) == b"AA"
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_packed_kernel_matches_oracle(mz, golden, seed):
+    # the opt-in packed kernel (four pairs per wave, LDS-DMA fed): same outputs as every other kernel
+    mz.lib().mz_enable_fast(1)
+    mz.lib().mz_enable_pack(1)
+    try:
+        pairs = [(c["A"], c["B"], c["LB"], c["RB"]) for c in golden] + _random_pairs(seed, 300)
+        _check(mz.yama_batch(pairs), pairs, exact_scores=False)
+        from multiz_amd import synth
+        batch = synth.make_batch(37, 2, 2, 900, 1100, 30, first_pair=seed)          # 37: a partly filled last wave
+        db = mz.DevBatch(batch)
+        db.run()
+        res = db.results()
+        assert (res["status"] == 0).all() and (res["mode"] == 4).all()
+        om, hs, _, bad = mo.yama_batch(batch, variant=1, threads=4)
+        host_out = db.out.cpu().numpy()
+        for i in range(37):
+            m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+            assert m_ == om[i] and _hash(host_out[o0: o0 + m_ * 4], m_) == int(hs[i]), i
+    finally:
+        mz.lib().mz_enable_pack(0)
+
+
+def _check(res, pairs, tags=None, exact_scores=True):
+    for i, ((A, B, LB, RB), r) in enumerate(zip(pairs, res)):
+        tag = tags[i] if tags else i
+        want = mo.yama(A, B, LB, RB, variant="profile")
+        assert want.rc == 0
+        assert r.status == 0, (tag, r.status)
+        assert r.OM == want.OM, tag
+        assert np.array_equal(r.cols, want.cols), tag
+        # (C,D,I) at (M,N): the fast kernel may hold a different value in an UNREACHABLE state
+        # (about -2^30 either way); reachable ones and the winner must agree
+        if exact_scores:
+            assert np.array_equal(r.score, want.final), tag
+        else:
+            assert r.score.max() == want.final.max(), tag
+            live = want.final > -(1 << 29)
+            assert np.array_equal(r.score[live], want.final[live]), tag
