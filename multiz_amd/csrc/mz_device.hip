@@ -1292,6 +1292,7 @@ struct PackState {
     Tri u0, u1;                   // previous lane's last row: alternately one / two steps ago
     unsigned w[PK_R][3];          // 2-bit flag streams per row: C, D, I picks
     int r4;                       // 4 * first row of the lane's current block
+    int q;                        // the lane's current block (rows 3q+1..3q+3); -1 = the row-0 block
     int thr4;                     // 4 * (next column at which this group's ring needs service), BIG when done
     int nbR, nbO;                 // column blocks requested / confirmed so far for this group
     int N4;                       // 4 * N of this lane's pair
@@ -1383,15 +1384,25 @@ __device__ __forceinline__ void pack_load_row(PackRow &R, const int4 *rec)
     R.w01 = d.x; R.w23 = d.y; R.w45 = d.z; R.nd = d.w;
 }
 
-// asynchronously copy super-block sb (rows 48*sb+1 .. 48*sb+48: 3072 contiguous bytes) of a pair into LDS
-__device__ __forceinline__ void pack_request_rows(const int4 *grecs, int sb, int4 *dst, int lane)
+// Row records are consumed strictly in row order (blocks are armed in order), so each pair keeps a FIFO of
+// two 12-row chunks (4 blocks each) in LDS: chunk c = rows 12c+1..12c+12 lives in half (c & 1).
+#define PK_CH 12
+// asynchronously copy chunk c of a pair (768 contiguous bytes = 48 x 16 B) into its half of the FIFO
+__device__ __forceinline__ void pack_request_chunk(const int4 *grecs, int c, int4 *fifo, int lane)
 {
-    const int4 *src = grecs + (long long)sb * (PK_H * 4);
-    ((volatile int *)dst)[PK_H * 16 - 1] = 0;          // arrival word: nd of the last record (never 0 in HBM)
+    int4 *dst = fifo + (c & 1) * (PK_CH * 4);
+    ((volatile int *)dst)[PK_CH * 16 - 1] = 0;         // arrival word: nd of the chunk's last record (never 0 in HBM)
     __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + m * WAVE + lane), (lptr_t)(dst + m * WAVE), 16, 0, 0);
+    if (lane < PK_CH * 4)
+        __builtin_amdgcn_global_load_lds((gptr_t)(grecs + (long long)c * (PK_CH * 4) + lane), (lptr_t)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void pack_confirm_chunk(int c, int4 *fifo, int *errflag)
+{
+    const volatile int *flag = (const volatile int *)(fifo + (c & 1) * (PK_CH * 4)) + (PK_CH * 16 - 1);
+    for (int spin = 0; *flag == 0; ++spin) {
+        if (spin > (1 << 22)) { *errflag = MZ_E_TRACEBACK; break; }                // never hang the GPU
+        __builtin_amdgcn_s_sleep(4);
+    }
 }
 
 __device__ __forceinline__ const int4 *uniform_ptr(const int4 *p, int srclane)
@@ -1416,34 +1427,32 @@ __device__ __forceinline__ void pack_step(PackState &S, Tri (&X)[PK_R], Tri (&Y)
     for (int j = 0; j < PK_R; ++j) E[j] = pack_col(ring, c4 - 4 * j);
     Un.C = rror1(X[PK_R - 1].C); Un.D = rror1(X[PK_R - 1].D); Un.I = rror1(X[PK_R - 1].I);
 
-    // ---- a lane whose last row has computed its last cell takes its next block (rows + 48)
+    // ---- a lane whose last row has computed its last cell takes its next block (rows + 48).  Blocks are
+    //      armed in order, at most one per pair per step; block q is read from the FIFO, chunk q/4.
     const bool fin = c4 - 4 * (PK_R - 1) > S.R[PK_R - 1].lo4 + S.R[PK_R - 1].wid4;
-    if (__ballot(fin)) {
-        // lane 0 of a group entering super-block sb: sb must have landed (it was requested a super-block
-        // ago); the buffer of sb-1 is free by now (rows finish in order), so request sb+1 into it
-        unsigned long long m0 = __ballot(fin && (lane & 15) == 0);
-        while (m0) {
+    const unsigned long long mfin = __ballot(fin);
+    if (mfin) {
+        for (unsigned long long m0 = mfin; m0;) {      // entering a chunk: it must have landed (requested 4+ blocks ago)
             const int src = __ffsll((long long)m0) - 1, g = src >> 4;
-            m0 &= m0 - 1;
-            const int sb = (__builtin_amdgcn_readlane(S.r4, src) >> 2) / PK_H + 1;
-            int4 *bufs = rowsAll + g * (2 * PK_H * 4);
-            const volatile int *flag = (const volatile int *)(bufs + (sb & 1) * (PK_H * 4)) + (PK_H * 16 - 1);
-            for (int spin = 0; *flag == 0; ++spin) {
-                if (spin > (1 << 22)) { *errflag = MZ_E_TRACEBACK; break; }        // never hang the GPU
-                __builtin_amdgcn_s_sleep(4);
-            }
-            pack_request_rows(uniform_ptr(recs, src), sb + 1, bufs + ((sb + 1) & 1) * (PK_H * 4), lane);
+            m0 &= ~(0xFFFFULL << (16 * g));
+            const int q = __builtin_amdgcn_readlane(S.q, src) + 16;
+            if ((q & 3) == 0) pack_confirm_chunk(q >> 2, rowsAll + g * (2 * PK_CH * 4), errflag);
         }
         if (fin) {
-            const int first = (S.r4 >> 2) + PK_H;      // first row of the new block
-            const int sb = (first - 1) / PK_H;
-            const int4 *rec = rowsAll + (lane >> 4) * (2 * PK_H * 4) + (sb & 1) * (PK_H * 4) + ((first - 1) - sb * PK_H) * 4;
+            S.q += 16;
+            const int4 *rec = rowsAll + (lane >> 4) * (2 * PK_CH * 4) + ((3 * S.q) % (2 * PK_CH)) * 4;
 #pragma unroll
             for (int j = 0; j < PK_R; ++j) {
                 pack_load_row(S.R[j], rec + j * 4);
                 X[j].C = Y[j].C = NEGT + 2; X[j].D = Y[j].D = NEGT; X[j].I = Y[j].I = NEGT + 1;
             }
             S.r4 += 4 * PK_H;
+        }
+        for (unsigned long long m0 = mfin; m0;) {      // a chunk's last block has been read: refill its half
+            const int src = __ffsll((long long)m0) - 1, g = src >> 4;
+            m0 &= ~(0xFFFFULL << (16 * g));
+            const int q = __builtin_amdgcn_readlane(S.q, src);
+            if ((q & 3) == 3) pack_request_chunk(uniform_ptr(recs, src), (q >> 2) + 2, rowsAll + g * (2 * PK_CH * 4), lane);
         }
     }
     const int c4n = 4 * t - S.r4;
@@ -1545,7 +1554,7 @@ __device__ __forceinline__ void pack_steps(PackState &S, int t0, int t1, int te0
 
 __global__ __launch_bounds__(WAVE, 1) void k_dp_pack(mz_dev_batch b)
 {
-    __shared__ __attribute__((aligned(16))) int4 s_rows[4 * 2 * PK_H * 4];      // 24 KB: 4 pairs x 2 super-blocks x 48 records
+    __shared__ __attribute__((aligned(16))) int4 s_rows[4 * 2 * PK_CH * 4];     // 6 KB: 4 pairs x FIFO of 2 chunks x 12 records
     __shared__ __attribute__((aligned(16))) int  s_ring[4 * 6 * PK_RING];       // 24 KB
 
     const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
@@ -1569,7 +1578,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_dp_pack(mz_dev_batch b)
     S.N4 = 4 * N; S.Tend = Tend; S.M = M;
     S.goL4 = 4 * c_sc.go * b.L[p]; S.geL4 = 4 * c_sc.ge * b.L[p]; S.kI4 = 4 * c_sc.go * b.K[p] * b.L[p];
 
-    // ---- prologue: column blocks 0 and 1 and row super-blocks 0 and 1 of every pair, then wait once
+    // ---- prologue: column blocks 0 and 1 of every pair; the first 15 blocks of rows (rows 1..45) pass through
+    //      the FIFO in two rounds (chunks 0,1 then 2,3), after which chunk 4 is requested
     for (int g = 0; g < 4; ++g) {
         const int npad = __builtin_amdgcn_readlane(Npad, g * 16);
         const int *gcols = (const int *)uniform_ptr((const int4 *)cols, g * 16);
@@ -1579,29 +1589,39 @@ __global__ __launch_bounds__(WAVE, 1) void k_dp_pack(mz_dev_batch b)
             for (int f = 0; f < 6; ++f)
                 __builtin_amdgcn_global_load_lds((gptr_t)(gcols + (long long)f * npad + blk * WAVE + lane),
                                                  (lptr_t)(gring + f * PK_RING + blk * WAVE), 4, 0, 0);
-        const int4 *grecs = uniform_ptr(recs, g * 16);
-        pack_request_rows(grecs, 0, s_rows + g * (2 * PK_H * 4), lane);
-        pack_request_rows(grecs, 1, s_rows + g * (2 * PK_H * 4) + PK_H * 4, lane);
     }
     S.nbR = S.nbO = 2;
     S.thr4 = (2 * WAVE < Npad) ? 4 * (2 * WAVE - 10) : MZ_BIG;  // blocks 0 and 1 are in; block 2 is requested near column 118
-    __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0): everything requested so far has landed
-    __syncthreads();
 
     const int q0 = li == 15 ? -1 : li;                 // first block; row 0 is the last row of block -1
+    S.q = q0;
     S.r4 = 4 * (3 * q0 + 1);
 #pragma unroll
     for (int j = 0; j < PK_R; ++j) {
-        if (q0 >= 0) pack_load_row(S.R[j], s_rows + grp * (2 * PK_H * 4) + (3 * q0 + j) * 4);
-        else {
-            PackRow &R = S.R[j];
-            R.lo4 = MZ_BIG; R.wid4 = 0;
-            R.rIx = R.rIy = R.rIz = R.rCxA = R.rCxB = R.rCy = R.rCz = R.rDx = 0;
-            R.cDe = R.penDye = R.w01 = R.w23 = R.w45 = 0; R.nd = 0x7fff7fff;
-        }
+        PackRow &R = S.R[j];
+        R.lo4 = MZ_BIG; R.wid4 = 0;
+        R.rIx = R.rIy = R.rIz = R.rCxA = R.rCxB = R.rCy = R.rCz = R.rDx = 0;
+        R.cDe = R.penDye = R.w01 = R.w23 = R.w45 = 0; R.nd = 0x7fff7fff;
         S.X[j].C = S.Y[j].C = NEGT + 2; S.X[j].D = S.Y[j].D = NEGT; S.X[j].I = S.Y[j].I = NEGT + 1;
         S.w[j][0] = S.w[j][1] = S.w[j][2] = 0;
     }
+    for (int round = 0; round < 2; ++round) {
+        for (int g = 0; g < 4; ++g) {
+            const int4 *grecs = uniform_ptr(recs, g * 16);
+            pack_request_chunk(grecs, 2 * round, s_rows + g * (2 * PK_CH * 4), lane);
+            pack_request_chunk(grecs, 2 * round + 1, s_rows + g * (2 * PK_CH * 4), lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): everything requested so far has landed
+        __syncthreads();
+        if (q0 >= 8 * round && q0 < 8 * round + 8) {   // blocks 0..7 sit in chunks 0,1; blocks 8..15 in chunks 2,3
+#pragma unroll
+            for (int j = 0; j < PK_R; ++j)
+                pack_load_row(S.R[j], s_rows + grp * (2 * PK_CH * 4) + ((3 * q0) % (2 * PK_CH) + j) * 4);
+        }
+        __syncthreads();
+    }
+    for (int g = 0; g < 4; ++g)                        // blocks 8..11 (chunk 2) are consumed: its half takes chunk 4
+        pack_request_chunk(uniform_ptr(recs, g * 16), 4, s_rows + g * (2 * PK_CH * 4), lane);
     if (q0 < 0) {                                      // row 0: no penalties at all, extension only
         PackRow &R = S.R[PK_R - 1];
         R.lo4 = 0; R.wid4 = 4 * b.poolRB[b.offBand[p]]; R.nd = 0;
