@@ -71,6 +71,8 @@ def lib():
         for f in ("mz_dev_plan", "mz_dev_dp", "mz_dev_walk", "mz_dev_emit"):
             getattr(_lib, f).argtypes = [C.POINTER(DevBatchC), C.c_void_p]
         _lib.mz_dev_run.argtypes = [C.POINTER(DevBatchC), C.c_void_p, C.POINTER(C.c_float)]
+        _lib.mz_dev_run_async.argtypes = [C.POINTER(DevBatchC), C.c_void_p, C.c_void_p]
+        _lib.mz_dev_wait.argtypes = [C.c_void_p]
         _lib.free_cols = C.CDLL(None).free
         _lib.free_cols.argtypes = [C.c_void_p]
     return _lib
@@ -168,6 +170,29 @@ class DevBatch:
         self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)
         self.c.tbw, self.c.script, self.c.out, self.c.prep = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr(), self.prep.data_ptr()
         self.c.capTb, self.c.capScript, self.c.capOut, self.c.capPrep = tb + 64, sc + 64, ou + 64, pr + 64
+        torch.cuda.synchronize(self.dev)                     # inputs complete (run_async's plan runs on a library stream)
+
+    def alternate(self) -> "DevBatch":
+        """a second workspace (traceback, script, output, plan arrays) over the SAME resident inputs, for the
+        pipelined mz_dev_run_async(): consecutive batches must not share a workspace"""
+        import copy
+        torch = self.torch
+        o = copy.copy(self)
+        o.plan_mem = torch.empty_like(self.plan_mem)
+        o.c = DevBatchC()
+        C.memmove(C.byref(o.c), C.byref(self.c), C.sizeof(DevBatchC))
+        lib().mz_dev_carve(C.byref(o.c), o.plan_mem.data_ptr())
+        o.tbw, o.script, o.out, o.prep = (torch.empty_like(t) for t in (self.tbw, self.script, self.out, self.prep))
+        o.c.tbw, o.c.script, o.c.out, o.c.prep = o.tbw.data_ptr(), o.script.data_ptr(), o.out.data_ptr(), o.prep.data_ptr()
+        return o
+
+    def run_async(self, ready_event=None):
+        """inputs must be complete (e.g. torch.cuda.synchronize() after building the batch) or ready_event given"""
+        ev = None if ready_event is None else ready_event.cuda_event
+        _check(lib().mz_dev_run_async(C.byref(self.c), self.stream_ptr(), ev), "mz_dev_run_async")
+
+    def wait(self):
+        _check(lib().mz_dev_wait(self.stream_ptr()), "mz_dev_wait")
 
     def stream_ptr(self):
         return self.torch.cuda.current_stream(self.dev).cuda_stream

@@ -11,6 +11,10 @@ int mzk_plan(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
 int mzk_walk(const mz_dev_batch *b, void *stream);
 int mzk_emit(const mz_dev_batch *b, void *stream);
+/* the same three phases on the slice [first, first+count) of the batch */
+int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
+int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream);
+int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream);
 const char *mzk_last_error(void);
 #ifdef __cplusplus
 }

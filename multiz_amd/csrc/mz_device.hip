@@ -438,13 +438,8 @@ __device__ __forceinline__ Tri cell(const RowRegs &R, int c, int N, int4 q, Tri 
 }
 
 // wf64: 64 DP rows in flight, row r on lane (r-1)&63 (row 0 on lane 63), cell (r, t-r) at step t.
-__global__ __launch_bounds__(WAVE) void k_dp_wf64(mz_dev_batch b)
+__device__ __forceinline__ void dp_wf64_body(const mz_dev_batch &b, int p, int lane, int *s_rec, int4 *s_ring)
 {
-    __shared__ __attribute__((aligned(16))) int  s_rec[2 * WAVE * REC_DW];
-    __shared__ __attribute__((aligned(16))) int4 s_ring[BRING];
-
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_WF64) return;
 
     PairCtx J;
     J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
@@ -1153,21 +1148,6 @@ __device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int la
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_dp_fast(mz_dev_batch b)
-{
-    __shared__ __attribute__((aligned(16))) int s_rec[2 * WAVE * TREC];
-    __shared__ __attribute__((aligned(16))) int s_ring[6 * FRING];
-#ifdef MZ_LDS_PAD
-    __shared__ int s_pad[MZ_LDS_PAD];
-    if (b.n < 0) s_pad[threadIdx.x] = 1;
-#endif
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK) return;
-    const int mode = b.mode[p];
-    if (mode == MZ_MODE_FASTT)     dp_tag_body(b, p, lane, s_rec, s_ring);
-    else if (mode == MZ_MODE_FAST) dp_fast_body<false>(b, p, lane, s_rec, s_ring);
-}
-
 // ------------------------------------------------------------------------------------------
 // packed kernel (MZ_MODE_PACK): FOUR block pairs per wave, 16 lanes per pair, 3 DP rows per lane.
 //
@@ -1667,13 +1647,8 @@ __global__ __launch_bounds__(WAVE, 1) void k_dp_pack(mz_dev_batch b)
 // for the next strip.  Arithmetic is the exact cell() of k_dp_wf64.  Slower than the rolling
 // wavefront for narrow bands (fill/drain per strip), efficient for wide ones.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_dp_strip(mz_dev_batch b)
+__device__ __forceinline__ void dp_strip_body(const mz_dev_batch &b, int p, int lane, int *s_rec, int4 *s_ring)
 {
-    __shared__ __attribute__((aligned(16))) int  s_rec[2 * WAVE * REC_DW];
-    __shared__ __attribute__((aligned(16))) int4 s_ring[BRING];
-
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_STRIP) return;
 
     PairCtx J;
     J.K = b.K[p]; J.L = b.L[p]; J.M = b.M[p]; J.N = b.N[p];
@@ -1805,13 +1780,35 @@ __global__ __launch_bounds__(WAVE) void k_dp_strip(mz_dev_batch b)
 }
 
 // ------------------------------------------------------------------------------------------
+// the DP kernel: one wave per pair, dispatching on the mode the plan chose.  [first, first+count) is the
+// slice of the batch this launch covers (the host runs a batch in a few slices so that the traceback walk
+// of one slice overlaps the DP of the next).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int count)
+{
+    __shared__ __attribute__((aligned(16))) int4 smem[(2 * WAVE * TREC + 6 * FRING) / 4];     // 13 KB, carved per mode
+#ifdef MZ_LDS_PAD
+    __shared__ int s_pad[MZ_LDS_PAD];
+    if (b.n < 0) s_pad[threadIdx.x] = 1;
+#endif
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK) return;
+    const int mode = b.mode[p];
+    int *s_rec = (int *)smem;
+    if (mode == MZ_MODE_FASTT)      dp_tag_body(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
+    else if (mode == MZ_MODE_FAST)  dp_fast_body<false>(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
+    else if (mode == MZ_MODE_WF64)  dp_wf64_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
+    else if (mode == MZ_MODE_STRIP) dp_strip_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
+}
+
+// ------------------------------------------------------------------------------------------
 // traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
+__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= b.n || b.status[p] != MZ_OK) return;
+    const int p = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= first + count || b.status[p] != MZ_OK) return;
     const int M = b.M[p], N = b.N[p];
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
@@ -1870,9 +1867,9 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b)
 // iteration; column m takes A[i] or dashes on top of B[j] or dashes, where (i, j) are the
 // running counts of A- and B-advancing ops up to m.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b)
+__global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int count)
 {
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = first + blockIdx.x, lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p], n = b.om[p];
     const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
@@ -1904,6 +1901,7 @@ __global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b)
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
 static char g_err[256];
+static int s_pack_enabled;      // set by mzk_upload_scores(): whether the plan may choose MZ_MODE_PACK
 static int fail(hipError_t e, const char *what)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -1924,6 +1922,7 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.maxS = 0;
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
     h.pack_ok = m->pack;
+    s_pack_enabled = m->pack;
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
@@ -1946,30 +1945,31 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
     return 0;
 }
 
-extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)
+extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
-    if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_prep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_dp_pack, dim3((b->n + 3) / 4), dim3(WAVE), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_dp_fast, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_dp_wf64, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_dp_strip, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    if (count <= 0) return 0;
+    if (s_pack_enabled && first == 0) {          // experimental packed kernel: whole batch with the first slice
+        hipLaunchKernelGGL(k_prep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+        hipLaunchKernelGGL(k_dp_pack, dim3((b->n + 3) / 4), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    }
+    hipLaunchKernelGGL(k_dp, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }
-
-extern "C" int mzk_walk(const mz_dev_batch *b, void *stream)
+extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
-    if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_walk, dim3((b->n + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_walk, dim3((count + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "walk launch");
     return 0;
 }
-
-extern "C" int mzk_emit(const mz_dev_batch *b, void *stream)
+extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
-    if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "emit launch");
     return 0;
 }
+extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)   { return mzk_dp_range(b, 0, b->n, stream); }
+extern "C" int mzk_walk(const mz_dev_batch *b, void *stream) { return mzk_walk_range(b, 0, b->n, stream); }
+extern "C" int mzk_emit(const mz_dev_batch *b, void *stream) { return mzk_emit_range(b, 0, b->n, stream); }

@@ -60,11 +60,17 @@ __attribute__((noreturn)) void mz_fatalf(const char *fmt, ...)
 
 typedef struct gbuf { void *p; size_t cap; } gbuf;
 
+#define MZ_SLICES 4                        /* (number of helper events) */
+
 static struct {
     int ready;
     int device;
     hipStream_t stream;
+    hipStream_t stream2;                   /* pipelined form: traceback walk + emit of batch k beside the DP of batch k+1 */
+    hipStream_t stream3;                   /* pipelined form: plan of batch k+1 beside the DP of batch k */
     hipEvent_t ev[5];
+    hipEvent_t evs[MZ_SLICES + 1];
+    int async_k;                           /* batches issued through mz_dev_run_async() */
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
@@ -103,7 +109,10 @@ int mz_init(int device)
         return set_err("HIP device %d out of range (%d present)", device, count);
     HIPCK(hipSetDevice(device));
     HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&G.stream2, hipStreamNonBlocking));
+    HIPCK(hipStreamCreateWithFlags(&G.stream3, hipStreamNonBlocking));
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
+    for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
     G.device = device;
     G.ready = 1;
     G.scores_ok = 0;
@@ -121,6 +130,11 @@ void mz_finalize(void)
     if (G.h_in.p)  { hipHostFree(G.h_in.p);  G.h_in.p = NULL;  G.h_in.cap = 0; }
     if (G.h_res.p) { hipHostFree(G.h_res.p); G.h_res.p = NULL; G.h_res.cap = 0; }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
+    for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
+    hipStreamSynchronize(G.stream2);
+    hipStreamDestroy(G.stream2);
+    hipStreamSynchronize(G.stream3);
+    hipStreamDestroy(G.stream3);
     hipStreamDestroy(G.stream);
     G.ready = 0;
 }
@@ -292,19 +306,60 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
     int i;
     if (ensure_init() || sync_global_scores()) return -1;
     s = (hipStream_t)pick_stream(stream);
-    if (ms) HIPCK(hipEventRecord(G.ev[0], s));
-    if (mzk_plan(b, s)) return set_err("%s", mzk_last_error());
-    if (ms) HIPCK(hipEventRecord(G.ev[1], s));
-    if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
-    if (ms) HIPCK(hipEventRecord(G.ev[2], s));
-    if (mzk_walk(b, s)) return set_err("%s", mzk_last_error());
-    if (ms) HIPCK(hipEventRecord(G.ev[3], s));
-    if (mzk_emit(b, s)) return set_err("%s", mzk_last_error());
-    if (ms) {
+    if (ms) {                              /* serial, one HIP event pair per phase */
+        HIPCK(hipEventRecord(G.ev[0], s));
+        if (mzk_plan(b, s)) return set_err("%s", mzk_last_error());
+        HIPCK(hipEventRecord(G.ev[1], s));
+        if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
+        HIPCK(hipEventRecord(G.ev[2], s));
+        if (mzk_walk(b, s)) return set_err("%s", mzk_last_error());
+        HIPCK(hipEventRecord(G.ev[3], s));
+        if (mzk_emit(b, s)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[4], s));
         HIPCK(hipEventSynchronize(G.ev[4]));
         for (i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&ms[i], G.ev[i], G.ev[i + 1]));
+        return 0;
     }
+    if (mzk_plan(b, s) || mzk_dp(b, s) || mzk_walk(b, s) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+    return 0;
+}
+
+/* Pipelined form for a stream of batches.  The DP is VALU-bound; the traceback walk is a latency-bound
+ * pointer chase and the plan a short bandwidth burst, both of which leave the VALUs idle.  So the DPs of
+ * successive batches run back to back on `stream`, the plan of batch k+1 runs on a third stream beside the DP
+ * of batch k, and walk + emit of batch k on a second stream beside the DP of batch k+1.  Consecutive calls MUST
+ * therefore use different workspaces (tbw/script/out and the plan arrays); with two alternating workspaces
+ * the library orders "reuse of workspace w" after "walk/emit of the batch that used w last".  The plan does
+ * not run on `stream`, so the batch's inputs must be complete when the call is made, or `ready_event` (a
+ * hipEvent_t recorded after their producer) must be given.  mz_dev_wait() makes `stream` wait for everything
+ * issued so far. */
+int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
+{
+    hipStream_t s;
+    const int slot = G.async_k & 1;
+    if (ensure_init() || sync_global_scores()) return -1;
+    s = (hipStream_t)pick_stream(stream);
+    if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
+    if (G.async_k >= 2) HIPCK(hipStreamWaitEvent(G.stream3, G.evs[slot], 0));   /* workspace of batch k-2 is free */
+    if (mzk_plan(b, G.stream3)) return set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(G.evs[3], G.stream3));
+    HIPCK(hipStreamWaitEvent(s, G.evs[3], 0));
+    if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(G.evs[2], s));
+    HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
+    if (mzk_walk(b, G.stream2) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(G.evs[slot], G.stream2));
+    G.async_k++;
+    return 0;
+}
+
+int mz_dev_wait(void *stream)
+{
+    hipStream_t s;
+    if (ensure_init()) return -1;
+    s = (hipStream_t)pick_stream(stream);
+    if (G.async_k >= 1) HIPCK(hipStreamWaitEvent(s, G.evs[(G.async_k - 1) & 1], 0));
+    if (G.async_k >= 2) HIPCK(hipStreamWaitEvent(s, G.evs[G.async_k & 1], 0));
     return 0;
 }
 

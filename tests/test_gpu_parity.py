@@ -165,6 +165,32 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
         assert np.array_equal(bot[~(bot == 45).all(axis=1)], B)
 
 
+def test_pipelined_batches_two_workspaces(mz):
+    # mz_dev_run_async(): walk + emit of batch k overlap plan + DP of batch k+1 on a second stream; two
+    # alternating workspaces.  After mz_dev_wait() both must hold exactly what the serial form produces.
+    from multiz_amd import synth
+    c = synth.CONFIGS["c2"]
+    batch = synth.make_batch(2000, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=123)
+    ref = mz.DevBatch(batch)
+    ref.run()
+    r0 = ref.results()
+    want = ref.out.cpu().numpy().copy()
+    a = mz.DevBatch(batch)
+    b = a.alternate()
+    for k in range(7):
+        (a if k % 2 == 0 else b).run_async()
+    a.wait()
+    width = batch["K"].astype(np.int64) + batch["L"]
+    for w in (a, b):
+        r = w.results()
+        assert np.array_equal(r["status"], r0["status"]) and np.array_equal(r["om"], r0["om"])
+        assert np.array_equal(r["final3"], r0["final3"]) and np.array_equal(r["offOut"], r0["offOut"])
+        got = w.out.cpu().numpy()
+        for i in range(len(width)):                      # (the 16-byte padding between pairs is never written)
+            o0, nb = int(r0["offOut"][i]), int(r0["om"][i]) * int(width[i])
+            assert np.array_equal(got[o0: o0 + nb], want[o0: o0 + nb]), i
+
+
 def test_long_block_regime(mz):
     # configs[4] shape (R=30, ~100k x 100k columns): traceback spills to HBM (6 MB per pair)
     from multiz_amd import synth
