@@ -67,7 +67,8 @@ enum {
  *           below 2^29 -- where guards that can only touch unreachable (sentinel) states are
  *           dropped; outputs are identical ("fast path equivalence") */
 enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 /* FAST with tag-encoded picks */,
-       MZ_MODE_PACK = 4 /* FASTT arithmetic, four pairs per wave (16 lanes x 3 rows each) */ };
+       MZ_MODE_PACK = 4 /* FASTT arithmetic, four pairs per wave (16 lanes x 3 rows each) */,
+       MZ_MODE_ROW = 5 /* FASTT arithmetic, lane = column, one band row per iteration (bands <= 63 wide) */ };
 
 typedef struct mz_dev_batch {
     int32_t n;
@@ -105,6 +106,7 @@ typedef struct mz_score_model {
     int32_t gap_extend;
     int32_t g1, g2;        /* gap_open = g1*g2 with both <= 258 (int16 dot-product operands); 0 = none */
     int32_t pack;          /* 1: let the plan pick the experimental packed kernel (MZ_MODE_PACK)          */
+    int32_t row;           /* 1 (default): let the plan pick the row-parallel kernel (MZ_MODE_ROW)        */
 } mz_score_model;
 
 
@@ -131,6 +133,9 @@ void mz_enable_fast(int on);
  * default: on MI355X it is slower than the one-pair-per-wave kernels.  MZ_PACK=1 in the
  * environment has the same effect.  Outputs are identical either way. */
 void mz_enable_pack(int on);
+/* 0: keep the plan from choosing the row-parallel kernel (MZ_MODE_ROW; default on; MZ_NO_ROW=1 in the
+ * environment also disables it).  Outputs are identical either way. */
+void mz_enable_row(int on);
 
 /* ---------------------------------------------------------------- host-buffer batch API */
 

@@ -8,6 +8,7 @@ extern "C" {
 /* all asynchronous on `stream` (a hipStream_t) */
 int mzk_upload_scores(const mz_score_model *m, void *stream);
 int mzk_plan(const mz_dev_batch *b, void *stream);
+int mzk_prep(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
 int mzk_walk(const mz_dev_batch *b, void *stream);
 int mzk_emit(const mz_dev_batch *b, void *stream);

@@ -19,6 +19,7 @@
 // No MFMA anywhere: this is an integer max-plus recurrence, not a contraction.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,8 +28,15 @@
 #define WAVE   64
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
+// row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then
+// column records of columns 0 .. ROW_NCOLS(N)-1
+#define RREC 8              // dwords per row record in b.prep
+#define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI P Q
+#define ROW_NROWS(M) ((M) + 2)
+#define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
+#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + (long long)RCOL * ROW_NCOLS(N))
 
-struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; int row_on; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
         else {
             const int need = N < 10 ? N : 10;
             int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
-            int wf_ok = 1, conn = 1, pk_ok = 1;
+            int wf_ok = 1, conn = 1, pk_ok = 1, row_ok = 1;
             int rL = 0, rN = M;             // last row with LB[r] <= 1, first row with RB[r] == N
             for (int r = lane; r <= M; r += WAVE) {
                 const int lo = LB[r], hi = RB[r];
@@ -106,11 +114,13 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 if (r + WAVE <= M && hi - LB[r + WAVE] > 62) wf_ok = 0;
                 if (r > 0 && lo > RB[r-1]) conn = 0;          // row r would not touch row r-1's band
                 if (r + 46 <= M && hi - LB[r + 46] > 44) pk_ok = 0;   // packed kernel: 48 rows in flight per pair
+                if (hi - lo > 62) row_ok = 0;                  // row-parallel kernel: one row of the band per wave
                 if (lo <= 1) rL = max(rL, r);
                 if (hi == N) rN = min(rN, r);
             }
             conn = wave_min(conn);
             pk_ok = wave_min(pk_ok);
+            row_ok = wave_min(row_ok);
             rL = -wave_min(-rL);
             rN = wave_min(rN);
             key = wave_min(key);
@@ -133,6 +143,15 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 edgeLo = rL + 1;
                 edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
                 szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
+                if (mode == MZ_MODE_FASTT && row_ok && c_sc.row_on &&
+                    (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 26) &&
+                    (long long)K * L * (c_sc.go + c_sc.ge) < (1LL << 20)) {
+                    mode = MZ_MODE_ROW;
+                    edgeLo = rL;                                // rows <= rL can hold column 0 or 1
+                    edgeHi = rN;                                // rows >= rN hold column N
+                    szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
+                    szPrep = ROW_PREP_DWORDS(M, N);
+                }
                 if (mode == MZ_MODE_PACK) {
                     szTb = (long long)(((M + N) >> 4) + 1) * 144;
                     szPrep = (long long)(((M + 47) / 48) * 48 + 96) * 16 + 6LL * (((N + 1 + 63) / 64) * 64 + 64);
@@ -1149,6 +1168,442 @@ __device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int la
 }
 
 // ------------------------------------------------------------------------------------------
+// row-parallel kernel (MZ_MODE_ROW) -- for bands at most 63 columns wide.
+//
+// The anti-diagonal wavefront keeps only about half of the 64 lanes busy on a band of width 2R+1
+// (an anti-diagonal crosses it in R+1 cells).  Here a lane owns a COLUMN (lane = column & 63, a ring
+// over the columns; a lane moves on to column c+64 when c drops out of the band on the left) and the
+// wave computes one whole ROW of the band per iteration, so ~(2R+1)/64 of the lanes work.  C(r,c)
+// and D(r,c) depend on row r-1 only (one DPP rotate for the diagonal).  I(r,c) depends on
+// I(r,c-1) -- a max-plus recurrence along the row:
+//     nI_c = max(J0_c, nI_{c-1} + e_c),   J0_c = open from C/D of (r,c-1),
+//     e_c  = -4K(go*(nB_c - PB00_c) + ge*nB_c)   (tag_step's  z-candidate minus xI, tag kept at 1).
+// e_c is a function of the column alone (rows 1..M-1; row M and row 0 pay no gap-open: e_c =
+// -4K*ge*nB_c), so with the prefix sums P_c = e_1 + ... + e_c staged once per column,
+//     nI_c = P_c + max_{k<=c} (J0_k - P_k),
+// a plain prefix MAXIMUM over the lanes: six DPP steps (row_shr 1,2,4,8, row_bcast 15, 31).  The ring
+// makes the band start at lane s = LB[r] & 63: lanes >= s (the lower ring period) are lifted by 2^30
+// so that they ignore lanes < s, and lanes < s (the wrapped tail) take the lower period's total from
+// lane 63.  Values are exact integers, so nI and all three pick flags (computed afterwards from the
+// final neighbours, as tag_step does) equal the wavefront kernel's.  Needs, beyond FASTT's conditions:
+// RB[r]-LB[r] <= 62 for every row, K*L*(go+ge+258)*(M+N+2) < 2^26 and K*L*(go+ge) < 2^20 (so that
+// |P| < 2^28 and the 2^30 lift separates the ring periods without overflow).
+// Traceback: 2-bit tag streams per lane as in FASTT, but one entry per ROW:
+//     tbw[((r>>4)*3 + s)*64 + (c & 63)], bits 2*(r&15).
+// ------------------------------------------------------------------------------------------
+// Work split: k_rowprep (one wave per pair, ahead of the DP) writes one 16-dword record per row of A
+// and one 8-dword record per column of B (with the running sums P, Q) to the pair's slice of b.prep.
+// k_dp_row then does nothing but the DP: the row record is uniform across the wave, so it is read with
+// scalar loads into SGPRs (no LDS traffic, no vector registers) one row ahead; column records are copied
+// 64 at a time into a 128-entry LDS ring from which a lane re-arms.  4 KB of LDS and ~64 VGPRs per wave:
+// eight waves per SIMD, which matters because the loop is latency-bound, not issue-bound, below that.
+// ------------------------------------------------------------------------------------------
+#define ROW_LIFT (1 << 30)
+
+typedef int int8v __attribute__((ext_vector_type(8)));
+
+
+__global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
+{
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_ROW) return;
+    const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p];
+    const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
+    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    int4 *rows = (int4 *)(b.prep + b.offPrep[p]);
+    int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
+    const int go = c_sc.go, ge = c_sc.ge, g2 = 2 * c_sc.g2;
+
+    // records are built one per lane in LDS and copied out linearly, so that every store instruction writes
+    // 1 KB of consecutive bytes
+    __shared__ int4 s_out[WAVE * (RREC / 4)];
+    const int nrows = ROW_NROWS(M);
+    for (int base = 0; base < nrows; base += WAVE) {
+        const int rr = base + lane + 1;
+        int4 *d = s_out + lane * (RREC / 4);
+        if (rr > M) {
+            d[0] = make_int4(MZ_BIG, 0, 0, 0);
+            d[1] = make_int4(0, 0, 0, 0);
+        } else {
+            const uint8_t *col = A + (long long)(rr - 1) * K;
+            unsigned cnt = 0;
+            int dA = 0, a00 = 0, a11 = 0, other = 0;
+            for (int i = 0; i < K; ++i) {
+                const unsigned ch = col[i];
+                const bool dash = ch == '-';
+                const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
+                const int cl = byte_class(ch);
+                cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+                other += cl == 5;
+                dA += dash;
+                a00 += (!dash) & (!pdash);
+                a11 += dash & pdash;
+            }
+            const int nA = K - dA;
+            int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
+            int w[6];
+#pragma unroll
+            for (int l = 0; l < 6; ++l) {
+                int acc = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
+                w[l] = 2 * (acc - go * dA);            // -go*dA per unit count: sums to -go*dA*L over a column
+            }
+            const bool last = rr >= M;
+            const int lo = LB[rr], hi = RB[rr];
+            // {lo4, wid4 | last, dA nA a00 a11 (bytes), cDe | penDye, w01, w23, w45}: the DP kernel derives
+            // the int16 row vectors from the four counts with scalar instructions
+            d[0] = make_int4(4 * lo, 4 * (hi - lo) | (int)last, dA | (nA << 8) | (a00 << 16) | (a11 << 24),
+                             4 * (go + ge) * nA * L);
+            d[1] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA), pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+        }
+        __syncthreads();
+        const int n4 = min(WAVE, nrows - base) * (RREC / 4);
+        int4 *g = rows + (long long)base * (RREC / 4);
+#pragma unroll
+        for (int k = 0; k < RREC / 4; ++k) {
+            const int i = k * WAVE + lane;
+            if (i < n4) g[i] = s_out[i];
+        }
+        __syncthreads();
+    }
+
+    int carryP = 0, carryQ = 0;
+    for (int cc = lane; cc < ROW_NCOLS(N); cc += WAVE) {
+        int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * go * K * L - 1, eP = 0, eQ = 0;
+        if (cc >= 1 && cc <= N) {
+            const uint8_t *col = B + (long long)(cc - 1) * L;
+            unsigned cnt = 0;
+            int dB = 0, b00 = 0, b11 = 0, other = 0;
+            for (int j = 0; j < L; ++j) {
+                const unsigned ch = col[j];
+                const bool dash = ch == '-';
+                const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
+                const int cl = byte_class(ch);
+                cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+                other += cl == 5;
+                dB += dash;
+                b00 += (!dash) & (!pdash);
+                b11 += dash & pdash;
+            }
+            const int nB = L - dB;
+            e0 = pack2(-g2 * dB, -g2 * b00);
+            e1 = pack2(-g2 * b11, 0);
+            e2 = pack2(2 * (cnt & 0xff), 2 * ((cnt >> 8) & 0xff));
+            e3 = pack2(2 * ((cnt >> 16) & 0xff), 2 * (cnt >> 24));
+            e4 = pack2(2 * dB, 2 * other);
+            e5 += 4 * ge * K * nB;
+            eP = -4 * K * (go * (nB - b00) + ge * nB);
+            eQ = -4 * K * ge * nB;
+        }
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int y = __shfl_up(eP, o), z = __shfl_up(eQ, o);
+            if (lane >= o) { eP += y; eQ += z; }
+        }
+        eP += carryP; eQ += carryQ;
+        carryP = __builtin_amdgcn_readlane(eP, WAVE - 1);
+        carryQ = __builtin_amdgcn_readlane(eQ, WAVE - 1);
+        s_out[2 * lane] = make_int4(e0, e1, e2, e3);
+        s_out[2 * lane + 1] = make_int4(e4, e5, eP, eQ);
+        __syncthreads();
+        int4 *g = cols + 2 * (cc - lane);
+        g[lane] = s_out[lane];
+        g[WAVE + lane] = s_out[WAVE + lane];
+        __syncthreads();
+    }
+}
+
+// the row record in SGPRs: one scalar load of 8 dwords, then scalar arithmetic for the int16 row vectors
+struct RowRec {
+    int lo4, wid4;                // 4*LB[r], 4*(RB[r]-LB[r])
+    int rIx, rIy, rIz;            // I-state row vectors against uA (zero on row M)
+    int rCxA, rCxB, rCy, rCz;     // C-state row vectors (rCxB is also the D-state vector rDx)
+    int cDe, penDye;              // 4*(go+ge)*nA*L, 4*(go*L*(nA-PA00) + ge*L*nA)
+    int w01, w23, w45;            // 2*(w[k] - go*dA)
+    int dA, nA, last;             // EDGE rows: kC = 4*go*dA*L, extD = 4*ge*L*nA, kIfix on row M
+};
+#define R_lo4(R)    ((R).lo4)
+#define R_wid4(R)   ((R).wid4)
+#define R_rIx(R)    ((R).rIx)
+#define R_rIy(R)    ((R).rIy)
+#define R_rIz(R)    ((R).rIz)
+#define R_rCxA(R)   ((R).rCxA)
+#define R_rCxB(R)   ((R).rCxB)
+#define R_rCy(R)    ((R).rCy)
+#define R_rCz(R)    ((R).rCz)
+#define R_rDx(R)    ((R).rCxB)
+#define R_cDe(R)    ((R).cDe)
+#define R_penDye(R) ((R).penDye)
+#define R_w01(R)    ((R).w01)
+#define R_w23(R)    ((R).w23)
+#define R_w45(R)    ((R).w45)
+
+__device__ __forceinline__ void row_rec_issue(int8v &raw, const int4 *rows, int r)
+{
+    const int4 *src = rows + (long long)(r - 1) * (RREC / 4);
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(raw) : "s"(src) : "memory");
+}
+// wait for the load, then derive (scalar ALU; Kg = K * 2*g1, g1x = 2*g1)
+__device__ __forceinline__ void row_rec_wait(RowRec &R, int8v &raw, int Kg, int g1x)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw) : : "memory");
+    const int cn = raw[2];
+    const int dA = cn & 0xff, nA = (cn >> 8) & 0xff, a00 = (cn >> 16) & 0xff, a11 = (int)((unsigned)cn >> 24);
+    const int last = raw[1] & 1;
+    const int t1 = (nA - dA) * g1x, t2 = dA * g1x, t3 = a00 * g1x, t4 = a11 * g1x;
+    R.lo4 = raw[0]; R.wid4 = raw[1] & ~3;
+    R.rIx = last ? 0 : pack2(-Kg, -t2);
+    R.rIy = last ? 0 : pack2(-Kg, 0);
+    R.rIz = last ? 0 : pack2(-Kg, -Kg);
+    R.rCxA = pack2(t1, -t4);
+    R.rCxB = pack2(-t3, 0);
+    R.rCy = pack2(t1 - t3, 0);
+    R.rCz = pack2(t1, -t2);
+    R.cDe = raw[3]; R.penDye = raw[4];
+    R.w01 = raw[5]; R.w23 = raw[6]; R.w45 = raw[7];
+    R.dA = dA; R.nA = nA; R.last = last;
+}
+
+struct RowState {
+    int c4;                       // 4 * the column this lane holds
+    int uA, uB, c01, c23, c45;
+    int xI, P, Q;                 // EDGE rows only
+    int xIPl, Pl;                 // xI + P and P, both minus 2^30 while the lane is in the lower ring period
+    Tri p;                        // row r-1 at this column (tagged), sentinel outside the band
+    Tri l;                        // the same, one lane to the left (= ror1(p) before any re-arm)
+    unsigned wC, wD, wI;
+};
+
+// copy 64 column records into the LDS ring
+__device__ __forceinline__ void row_stage_cols(int first, int lane, const int4 *cols, int4 *ring)
+{
+    const int cc = first + lane;
+    const int4 x = cols[2 * cc], y = cols[2 * cc + 1];
+    ring[2 * (cc & (FRING - 1))] = x;
+    ring[2 * (cc & (FRING - 1)) + 1] = y;
+}
+
+// column data of column c4/4 from the ring; lo4 = 4*LB of the row about to be computed
+__device__ __forceinline__ void row_load_col(RowState &S, const int4 *ring, int lo4)
+{
+    const int4 *e = (const int4 *)((const char *)ring + ((S.c4 << 3) & (32 * FRING - 32)));
+    const int4 x = e[0], y = e[1];
+    S.uA = x.x; S.uB = x.y; S.c01 = x.z; S.c23 = x.w;
+    S.c45 = y.x; S.xI = y.y; S.P = y.z; S.Q = y.w;
+    const int lift = ((S.c4 ^ lo4) >> 8) == 0 ? ROW_LIFT : 0;   // same 64-column period as the band's left edge
+    S.Pl = S.P - lift;
+    S.xIPl = S.xI + S.Pl;
+}
+
+// inclusive prefix maximum over the 64 lanes (lane order)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_max_step(int g)
+{
+    // old = INT_MIN is the identity of max: lanes without a source keep g, and the DPP folds into v_max_i32
+    const int t = __builtin_amdgcn_update_dpp((int)0x80000000, g, CTRL, ROWMASK, 0xF, false);
+    return max(g, t);
+}
+__device__ __forceinline__ int prefix_max64(int g)
+{
+    g = dpp_max_step<0x111, 0xF>(g);                  // row_shr:1
+    g = dpp_max_step<0x112, 0xF>(g);                  // row_shr:2
+    g = dpp_max_step<0x114, 0xF>(g);                  // row_shr:4
+    g = dpp_max_step<0x118, 0xF>(g);                  // row_shr:8
+    g = dpp_max_step<0x142, 0xA>(g);                  // row_bcast:15 into rows 1 and 3
+    g = dpp_max_step<0x143, 0xC>(g);                  // row_bcast:31 into rows 2 and 3
+    return g;
+}
+
+struct RowCtx { int K, L, N4, KL4go, Kg, g1x; };
+
+// one row of the band; EDGE = the row can hold column 0, 1 or N, or is row M
+template <bool EDGE>
+__device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, const RowCtx &J, const int4 *s_ring, uint32_t *tbw, int lane)
+{
+    Tri dg = S.l;                                      // (r-1, c-1), rotated at the end of row r-1
+    if (S.c4 < R_lo4(R)) {                             // column left the band: take column c+64
+        S.c4 += 4 * WAVE;
+        row_load_col(S, s_ring, R_lo4(R));
+        // neither (r-1, c+64) nor (r-1, c+63) was in row r-1's band (its width is at most 63)
+        S.p.C = NEGT + 2; S.p.D = NEGT; S.p.I = NEGT + 1;
+        dg = S.p;
+    }
+    const int c4 = S.c4, uA = S.uA, uB = S.uB;
+    const Tri &up = S.p;
+    int x, y, z, mI, mC, mD, nI, nC, nD;
+
+    // C
+    x = dot2(R_rCxB(R), uB, dot2(R_rCxA(R), uA, dg.C));
+    y = dot2(R_rCy(R), uA, dg.D);
+    z = dot2(R_rCz(R), uA, dg.I);
+    if (EDGE) {                                        // no gap-open entering column 1 (mz_yama.c:173)
+        const bool g = c4 > 4;
+        const int kC = 4 * c_sc.go * R.dA * J.L;
+        x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
+        mC = max(max(x, y), z);
+        nC = dot2(R_w01(R), S.c01, dot2(R_w23(R), S.c23, dot2(R_w45(R), S.c45, (mC & ~3) | 2))) + (g ? 0 : kC);
+    } else {
+        mC = max(max(x, y), z);
+        nC = dot2(R_w01(R), S.c01, dot2(R_w23(R), S.c23, dot2(R_w45(R), S.c45, (mC & ~3) | 2)));
+    }
+    // D
+    if (EDGE) {                                        // none in column 0 or N (mz_yama.c:211)
+        const bool g = (c4 > 0) & (c4 < J.N4);
+        const int extD = 4 * c_sc.ge * J.L * R.nA;
+        x = dot2(R_rDx(R), uA, up.C - (R_cDe(R) - extD));
+        y = up.D - (R_penDye(R) - extD);
+        z = up.I - (R_cDe(R) - extD);
+        x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
+        mD = max(max(x, y), z);
+        nD = (mD & ~3) - extD;
+    } else {
+        x = dot2(R_rDx(R), uA, up.C - R_cDe(R));
+        y = up.D - R_penDye(R);
+        z = up.I - R_cDe(R);
+        mD = max(max(x, y), z);
+        nD = mD & ~3;
+    }
+    const bool active = (unsigned)(c4 - R_lo4(R)) <= (unsigned)R_wid4(R);
+    nC = active ? nC : NEGT + 2;
+    nD = active ? nD : NEGT;
+
+    // I: open candidates from the finished C / D of (r, c-1), then the prefix maximum along the row.
+    // Lanes right of the band need no masking here: they come last in ring order.
+    const int lC = ror1(nC), lD = ror1(nD);
+    x = dot2(R_rIx(R), uA, lC);
+    y = dot2(R_rIy(R), uA, lD);
+    const int base = max(x, y);
+    int g, Pl;
+    if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
+        const bool last = R.last != 0;
+        const int lift = S.P - S.Pl;
+        Pl = (last ? S.Q : S.P) - lift;
+        g = (base & ~3) - S.xI + (last ? J.KL4go : 0) - Pl;
+    } else {
+        Pl = S.Pl;
+        g = (base & ~3) - S.xIPl;
+    }
+    g = prefix_max64(g);
+    g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
+    nI = active ? g + Pl : NEGT + 1;
+    const int lI = ror1(nI);
+    z = dot2(R_rIz(R), uA, lI);
+    mI = max(base, z);
+
+    S.p.C = nC; S.p.D = nD; S.p.I = nI;
+    S.l.C = lC; S.l.D = lD; S.l.I = lI;
+    S.wC = __builtin_amdgcn_alignbit(mC, S.wC, 2);
+    S.wD = __builtin_amdgcn_alignbit(mD, S.wD, 2);
+    S.wI = __builtin_amdgcn_alignbit(mI, S.wI, 2);
+    if ((r & 15) == 15) {
+        uint32_t *o = tbw + (r >> 4) * (3 * WAVE) + lane;
+        o[0] = S.wC; o[WAVE] = S.wD; o[2 * WAVE] = S.wI;
+    }
+}
+
+struct RowLoop { int cst, per; };                      // highest staged column, LB >> 6
+
+// bookkeeping before row r (record R): stage 64 columns ahead; re-lift when the band's left edge enters
+// the next 64-column period (every lane is then in the lower period again)
+__device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, const int4 *cols, int4 *s_ring)
+{
+    const int lo = R_lo4(R) >> 2;
+    if (lo + WAVE - 1 > Q.cst) {
+        row_stage_cols(Q.cst + 1, lane, cols, s_ring);
+        Q.cst += WAVE;
+        __syncthreads();
+    }
+    if ((lo >> 6) != Q.per) {
+        asm volatile("; re-lift (once per 64 columns): keep this a branch");
+        Q.per = lo >> 6;
+        const int lift = ((S.c4 ^ (4 * lo)) >> 8) == 0 ? ROW_LIFT : 0;
+        S.Pl = S.P - lift;
+        S.xIPl = S.xI + S.Pl;
+    }
+}
+
+// rows r0..r1, two per iteration so that the record registers alternate instead of being copied
+template <bool EDGE>
+__device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
+                                         const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
+{
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    r1 = __builtin_amdgcn_readfirstlane(r1);
+    if (r0 > r1) return;
+    // a record is complete (issued AND waited for) whenever it crosses a loop edge, so the compiler never
+    // copies registers whose scalar load is still in flight
+    RowRec Ra, Rb;
+    int8v raw;
+    row_rec_issue(raw, rows, r0);
+    row_rec_wait(Ra, raw, J.Kg, J.g1x);
+    int r = r0;
+    for (; r + 1 <= r1; r += 2) {
+        row_rec_issue(raw, rows, r + 1);
+        row_pre(S, Q, Ra, lane, cols, s_ring);
+        row_step<EDGE>(S, Ra, r, J, s_ring, tbw, lane);
+        row_rec_wait(Rb, raw, J.Kg, J.g1x);
+        row_rec_issue(raw, rows, r + 2);
+        row_pre(S, Q, Rb, lane, cols, s_ring);
+        row_step<EDGE>(S, Rb, r + 1, J, s_ring, tbw, lane);
+        row_rec_wait(Ra, raw, J.Kg, J.g1x);
+    }
+    if (r <= r1) {
+        row_pre(S, Q, Ra, lane, cols, s_ring);
+        row_step<EDGE>(S, Ra, r, J, s_ring, tbw, lane);
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int count)
+{
+    __shared__ int4 s_ring[2 * FRING];                 // 4 KB
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_ROW) return;
+    const int M = b.M[p], N = b.N[p];
+    RowCtx J;
+    J.K = b.K[p]; J.L = b.L[p]; J.N4 = 4 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
+    J.g1x = 2 * c_sc.g1; J.Kg = J.K * J.g1x;
+    const int4 *rows = (const int4 *)(b.prep + b.offPrep[p]);
+    const int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
+    uint32_t *tbw = b.tbw + b.offTb[p];
+    const int rL = b.edgeLo[p], rN = b.edgeHi[p];     // rows <= rL hold column 0/1, rows >= rN column N
+
+    RowLoop Q;
+    Q.per = 0;
+    row_stage_cols(0, lane, cols, s_ring);
+    row_stage_cols(WAVE, lane, cols, s_ring);
+    __syncthreads();
+    Q.cst = 2 * WAVE - 1;
+
+    // row 0 in closed form (mz_yama.c:83-94): C = D = NEG beyond (0,0); I(0,c) = -ge*K*(nB_1+..+nB_c)
+    RowState S;
+    S.c4 = 4 * lane;
+    row_load_col(S, s_ring, 0);
+    const int rb0 = (b.poolRB + b.offBand[p])[0];
+    S.p.C = lane == 0 ? 2 : NEGT + 2;
+    S.p.D = lane == 0 ? 0 : NEGT;
+    S.p.I = lane <= rb0 ? 1 + S.Q : NEGT + 1;
+    S.l.C = ror1(S.p.C); S.l.D = ror1(S.p.D); S.l.I = ror1(S.p.I);
+    S.wC = S.wD = S.wI = 0;
+
+    const int e1 = min(rL, M), e2 = max(rN, e1 + 1);  // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge
+    row_rows<true>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
+    row_rows<false>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
+    row_rows<true>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
+
+    if ((M & 15) != 15) {                              // flush the partial group
+        const int sh = 2 * (15 - (M & 15));
+        uint32_t *o = tbw + (M >> 4) * (3 * WAVE) + lane;
+        o[0] = S.wC >> sh; o[WAVE] = S.wD >> sh; o[2 * WAVE] = S.wI >> sh;
+    }
+    if (lane == (N & (WAVE - 1))) {                    // (C,D,I) at (M,N), unscaled
+        b.final3[3 * p + 0] = S.p.C >> 2;
+        b.final3[3 * p + 1] = S.p.D >> 2;
+        b.final3[3 * p + 2] = S.p.I >> 2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // packed kernel (MZ_MODE_PACK): FOUR block pairs per wave, 16 lanes per pair, 3 DP rows per lane.
 //
 // Why: one wave already saturates its SIMD's VALU pipe and a radius-30 band has only ~31-34 rows
@@ -1813,7 +2268,7 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
-    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK;
+    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode == MZ_MODE_ROW;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -1831,6 +2286,11 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
             const int t = r + c, q = (r - 1) / 3, j = (r - 1) - 3 * q;
             const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
             const unsigned tg = (tbw[((long long)(t >> 4) * 9 + j * 3 + sidx) * 16 + (q & 15)] >> (2 * (t & 15))) & 3;
+            stb = tg | (tg << 2) | (tg << 4);
+        } else if (mode == MZ_MODE_ROW) {
+            // row-parallel kernel: word ((r>>4)*3 + s)*64 + (c & 63), bits 2*(r&15)
+            const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
+            const unsigned tg = (tbw[((r >> 4) * 3 + sidx) * WAVE + (c & (WAVE - 1))] >> (2 * (r & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
         } else if (tagged) {
             // 2-bit tag streams: word ((t>>4)*3 + s)*64 + lane, s = 0/1/2 for the C/D/I pick; read only
@@ -1922,6 +2382,7 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.maxS = 0;
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
     h.pack_ok = m->pack;
+    h.row_on = m->row;
     s_pack_enabled = m->pack;
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
@@ -1945,6 +2406,15 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
     return 0;
 }
 
+// row / column records of the MZ_MODE_ROW pairs (needs the plan's offsets and the caller's prep buffer)
+extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_rowprep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b, 0, b->n);
+    CK(hipGetLastError(), "prep launch");
+    return 0;
+}
+
 extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
@@ -1952,7 +2422,10 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         hipLaunchKernelGGL(k_prep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
         hipLaunchKernelGGL(k_dp_pack, dim3((b->n + 3) / 4), dim3(WAVE), 0, (hipStream_t)stream, *b);
     }
-    hipLaunchKernelGGL(k_dp, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
+    if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_dp, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }

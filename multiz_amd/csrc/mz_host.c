@@ -109,8 +109,12 @@ int mz_init(int device)
         return set_err("HIP device %d out of range (%d present)", device, count);
     HIPCK(hipSetDevice(device));
     HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
-    HIPCK(hipStreamCreateWithFlags(&G.stream2, hipStreamNonBlocking));
-    HIPCK(hipStreamCreateWithFlags(&G.stream3, hipStreamNonBlocking));
+    {   /* helper streams run at the lowest priority: the DP on the caller's stream gets the wave slots first */
+        int lowest = 0, highest = 0;
+        HIPCK(hipDeviceGetStreamPriorityRange(&lowest, &highest));
+        HIPCK(hipStreamCreateWithPriority(&G.stream2, hipStreamNonBlocking, lowest));
+        HIPCK(hipStreamCreateWithPriority(&G.stream3, hipStreamNonBlocking, lowest));
+    }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
     G.device = device;
@@ -151,6 +155,7 @@ static int ensure_init(void)
 
 static int g_no_fast;                      /* mz_enable_fast(0): exact kernels only */
 static int g_pack;                         /* mz_enable_pack(1): experimental packed kernel */
+static int g_no_row;                       /* mz_enable_row(0): no row-parallel kernel */
 
 static int class_of(int ch)
 {
@@ -191,6 +196,7 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
      * kernel needs it (MZ_NO_FAST=1 in the environment disables that kernel: exact kernel only) */
     m->g1 = m->g2 = 0;
     m->pack = g_pack || (getenv("MZ_PACK") && atoi(getenv("MZ_PACK")) != 0);
+    m->row = !g_no_row && !(getenv("MZ_NO_ROW") && atoi(getenv("MZ_NO_ROW")) != 0);
     if (!g_no_fast && (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0)) {
         if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
         else for (x = 1; x * x <= m->gap_open; ++x)       /* the most balanced factorisation */
@@ -228,6 +234,13 @@ void mz_enable_fast(int on)
 void mz_enable_pack(int on)
 {
     g_pack = on != 0;
+    G.scores_ok = 0;
+    mz_scores_explicit = 0;
+}
+
+void mz_enable_row(int on)
+{
+    g_no_row = !on;
     G.scores_ok = 0;
     mz_scores_explicit = 0;
 }
@@ -282,7 +295,7 @@ static void *pick_stream(void *s) { return s ? s : (void *)G.stream; }
 int mz_dev_plan(const mz_dev_batch *b, void *stream)
 {
     if (ensure_init() || sync_global_scores()) return -1;
-    return mzk_plan(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+    return (mzk_plan(b, pick_stream(stream)) || mzk_prep(b, pick_stream(stream))) ? set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_dp(const mz_dev_batch *b, void *stream)
 {
@@ -308,7 +321,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
     s = (hipStream_t)pick_stream(stream);
     if (ms) {                              /* serial, one HIP event pair per phase */
         HIPCK(hipEventRecord(G.ev[0], s));
-        if (mzk_plan(b, s)) return set_err("%s", mzk_last_error());
+        if (mzk_plan(b, s) || mzk_prep(b, s)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[1], s));
         if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[2], s));
@@ -320,7 +333,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
         for (i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&ms[i], G.ev[i], G.ev[i + 1]));
         return 0;
     }
-    if (mzk_plan(b, s) || mzk_dp(b, s) || mzk_walk(b, s) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(b, s) || mzk_prep(b, s) || mzk_dp(b, s) || mzk_walk(b, s) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
     return 0;
 }
 
@@ -341,7 +354,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     s = (hipStream_t)pick_stream(stream);
     if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
     if (G.async_k >= 2) HIPCK(hipStreamWaitEvent(G.stream3, G.evs[slot], 0));   /* workspace of batch k-2 is free */
-    if (mzk_plan(b, G.stream3)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.evs[3], G.stream3));
     HIPCK(hipStreamWaitEvent(s, G.evs[3], 0));
     if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
@@ -436,7 +449,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     b.prep = (uint32_t *)G.d_prep.p; b.capPrep = (int64_t)(G.d_prep.cap / 4);
     b.capTb = (int64_t)(G.d_tb.cap / 4); b.capScript = (int64_t)G.d_script.cap; b.capOut = (int64_t)G.d_out.cap;
 
-    if (mzk_dp(&b, G.stream) || mzk_walk(&b, G.stream) || mzk_emit(&b, G.stream))
+    if (mzk_prep(&b, G.stream) || mzk_dp(&b, G.stream) || mzk_walk(&b, G.stream) || mzk_emit(&b, G.stream))
         return set_err("%s", mzk_last_error());
 
     /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */

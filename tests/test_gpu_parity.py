@@ -18,11 +18,19 @@ def mz():
     yield m
     m.lib().mz_enable_fast(1)
     m.lib().mz_enable_pack(0)
+    m.lib().mz_enable_row(1)
 
 
-@pytest.mark.parametrize("fast", [1, 0])
+def _kernels(mz, which):
+    """2: everything the plan may pick (row-parallel kernel included); 1: wavefront kernels only (tagged /
+    fast / exact); 0: exact kernels only"""
+    mz.lib().mz_enable_fast(1 if which else 0)
+    mz.lib().mz_enable_row(1 if which == 2 else 0)
+
+
+@pytest.mark.parametrize("fast", [2, 1, 0])
 def test_golden_vectors(mz, golden, fast):
-    mz.lib().mz_enable_fast(fast)
+    _kernels(mz, fast)
     pairs = [(c["A"], c["B"], c["LB"], c["RB"]) for c in golden]
     res = mz.yama_batch(pairs)
     for c, r in zip(golden, res):
@@ -47,9 +55,9 @@ def _random_pairs(seed, n, kmax=8, mmax=420):
     return pairs
 
 
-@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("fast", [2, 1, 0])
 def test_random_pairs_one_batch(mz, fast):
-    mz.lib().mz_enable_fast(fast)
+    _kernels(mz, fast)
     pairs = _random_pairs(2026 + fast, 400)
     _check(mz.yama_batch(pairs), pairs, exact_scores=(fast == 0))
 
