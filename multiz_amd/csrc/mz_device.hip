@@ -34,7 +34,7 @@
 #define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI P Q
 #define ROW_NROWS(M) ((M) + 2)
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
-#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + (long long)RCOL * ROW_NCOLS(N))
+#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + (long long)RCOL * ROW_NCOLS(N) + 2LL * ((M) + 1))
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; int row_on; };
 __constant__ ScoreConst c_sc;
@@ -81,6 +81,20 @@ __device__ __forceinline__ long long wave_sum64(long long v)
     return v;
 }
 
+// transposed band (the band seen column by column): rows of column c are t_lo(c) .. t_hi(c)
+__device__ __forceinline__ int t_lo(const int *RB, int M, int c)        // first r with RB[r] >= c
+{
+    int lo = 0, hi = M;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (RB[mid] >= c) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__device__ __forceinline__ int t_hi(const int *LB, int M, int c)        // last r with LB[r] <= c
+{
+    int lo = 0, hi = M;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (LB[mid] <= c) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 // ------------------------------------------------------------------------------------------
 // plan: validity prologue of yama (reference mz_yama.c:58-71), work sizes, kernel mode
 // ------------------------------------------------------------------------------------------
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
         else {
             const int need = N < 10 ? N : 10;
             int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
-            int wf_ok = 1, conn = 1, pk_ok = 1, row_ok = 1;
+            int wf_ok = 1, conn = 1, pk_ok = 1, row_ok = 1, col_ok = 1;
             int rL = 0, rN = M;             // last row with LB[r] <= 1, first row with RB[r] == N
             for (int r = lane; r <= M; r += WAVE) {
                 const int lo = LB[r], hi = RB[r];
@@ -115,12 +129,14 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 if (r > 0 && lo > RB[r-1]) conn = 0;          // row r would not touch row r-1's band
                 if (r + 46 <= M && hi - LB[r + 46] > 44) pk_ok = 0;   // packed kernel: 48 rows in flight per pair
                 if (hi - lo > 62) row_ok = 0;                  // row-parallel kernel: one row of the band per wave
+                if (r + 63 <= M && LB[r + 63] <= hi) col_ok = 0;   // transposed: a column would span 64 rows
                 if (lo <= 1) rL = max(rL, r);
                 if (hi == N) rN = min(rN, r);
             }
             conn = wave_min(conn);
             pk_ok = wave_min(pk_ok);
             row_ok = wave_min(row_ok);
+            col_ok = wave_min(col_ok);
             rL = -wave_min(-rL);
             rN = wave_min(rN);
             key = wave_min(key);
@@ -143,14 +159,29 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 edgeLo = rL + 1;
                 edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
                 szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
-                if (mode == MZ_MODE_FASTT && row_ok && c_sc.row_on &&
+                if (mode == MZ_MODE_FASTT && c_sc.row_on &&
                     (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 26) &&
                     (long long)K * L * (c_sc.go + c_sc.ge) < (1LL << 20)) {
-                    mode = MZ_MODE_ROW;
-                    edgeLo = rL;                                // rows <= rL can hold column 0 or 1
-                    edgeHi = rN;                                // rows >= rN hold column N
-                    szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
-                    szPrep = ROW_PREP_DWORDS(M, N);
+                    if (row_ok) {
+                        mode = MZ_MODE_ROW;
+                        edgeLo = rL;                            // rows <= rL can hold column 0 or 1
+                        edgeHi = rN;                            // rows >= rN hold column N
+                        szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
+                        szPrep = ROW_PREP_DWORDS(M, N);
+                    } else if (2 * L * (c_sc.maxS + c_sc.go) <= 32767) {
+                        // the same kernel on the transposed problem (A and B, D and I exchanged): the band
+                        // column by column must be at most 63 rows high
+                        // (column c lies in rows r and r+63 iff LB[r+63] <= c <= RB[r]: checked in the row loop)
+                        const int cL = RB[1 < M ? 1 : M];       // last column whose first row is 0 or 1
+                        const int cN = LB[M];                   // first column that reaches row M
+                        if (col_ok) {
+                            mode = MZ_MODE_COL;
+                            edgeLo = cL;
+                            edgeHi = cN;
+                            szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
+                            szPrep = ROW_PREP_DWORDS(N, M);
+                        }
+                    }
                 }
                 if (mode == MZ_MODE_PACK) {
                     szTb = (long long)(((M + N) >> 4) + 1) * 144;
@@ -1203,20 +1234,35 @@ __device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int la
 typedef int int8v __attribute__((ext_vector_type(8)));
 
 
-__global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
+// COL: the transposed problem -- A and B exchange roles, the band is read column by column, and the I slot
+// of the kernel (which then holds the reference's D state) carries tag 0 instead of 1
+template <bool COL>
+__device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int lane, int4 *s_out)
 {
-    const int p = first + blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_ROW) return;
-    const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p];
-    const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
+    const int K = COL ? b.L[p] : b.K[p], L = COL ? b.K[p] : b.L[p];
+    const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];
+    const uint8_t *A = COL ? b.poolB + b.offB[p] : b.poolA + b.offA[p];
+    const uint8_t *B = COL ? b.poolA + b.offA[p] : b.poolB + b.offB[p];
     const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    const int TI = COL ? 0 : 1;
     int4 *rows = (int4 *)(b.prep + b.offPrep[p]);
     int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
     const int go = c_sc.go, ge = c_sc.ge, g2 = 2 * c_sc.g2;
+    // COL: the band column by column -- tlo[c] = first row with RB[r] >= c, thi[c] = last row with LB[r] <= c,
+    // scattered from the rows (both arrays are monotone, so the work is M + N) into the tail of the prep slice
+    int *tlo = (int *)(cols + (RCOL / 4) * ROW_NCOLS(N)), *thi = tlo + (M + 1);
+    if (COL) {
+        for (int r = lane; r <= N; r += WAVE) {        // N = the reference's M: rows of the band arrays
+            const int c1 = RB[r], c0 = r > 0 ? RB[r - 1] + 1 : 0;
+            for (int cc = c0; cc <= c1; ++cc) tlo[cc] = r;
+            const int d0 = LB[r], d1 = r < N ? LB[r + 1] - 1 : M;
+            for (int cc = d0; cc <= d1; ++cc) thi[cc] = r;
+        }
+        __syncthreads();                               // (stores are complete at the L2; the loads below bypass the L1)
+    }
 
     // records are built one per lane in LDS and copied out linearly, so that every store instruction writes
     // 1 KB of consecutive bytes
-    __shared__ int4 s_out[WAVE * (RREC / 4)];
     const int nrows = ROW_NROWS(M);
     for (int base = 0; base < nrows; base += WAVE) {
         const int rr = base + lane + 1;
@@ -1250,7 +1296,9 @@ __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int
                 w[l] = 2 * (acc - go * dA);            // -go*dA per unit count: sums to -go*dA*L over a column
             }
             const bool last = rr >= M;
-            const int lo = LB[rr], hi = RB[rr];
+            // (written by other lanes of this wave above: read past the L1)
+            const int lo = COL ? __hip_atomic_load(tlo + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB[rr];
+            const int hi = COL ? __hip_atomic_load(thi + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RB[rr];
             // {lo4, wid4 | last, dA nA a00 a11 (bytes), cDe | penDye, w01, w23, w45}: the DP kernel derives
             // the int16 row vectors from the four counts with scalar instructions
             d[0] = make_int4(4 * lo, 4 * (hi - lo) | (int)last, dA | (nA << 8) | (a00 << 16) | (a11 << 24),
@@ -1270,7 +1318,7 @@ __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int
 
     int carryP = 0, carryQ = 0;
     for (int cc = lane; cc < ROW_NCOLS(N); cc += WAVE) {
-        int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * go * K * L - 1, eP = 0, eQ = 0;
+        int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * go * K * L - TI, eP = 0, eQ = 0;
         if (cc >= 1 && cc <= N) {
             const uint8_t *col = B + (long long)(cc - 1) * L;
             unsigned cnt = 0;
@@ -1312,6 +1360,16 @@ __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int
         g[WAVE + lane] = s_out[WAVE + lane];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
+{
+    __shared__ int4 s_out[WAVE * 2];
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK) return;
+    const int mode = b.mode[p];
+    if (mode == MZ_MODE_ROW)      rowprep_body<false>(b, p, lane, s_out);
+    else if (mode == MZ_MODE_COL) rowprep_body<true>(b, p, lane, s_out);
 }
 
 // the row record in SGPRs: one scalar load of 8 dwords, then scalar arithmetic for the int16 row vectors
@@ -1417,16 +1475,19 @@ __device__ __forceinline__ int prefix_max64(int g)
 
 struct RowCtx { int K, L, N4, KL4go, Kg, g1x; };
 
-// one row of the band; EDGE = the row can hold column 0, 1 or N, or is row M
-template <bool EDGE>
+// one row of the band; EDGE = the row can hold column 0, 1 or N, or is row M (COL: or is row 1).
+// COL = transposed problem: the D slot holds the reference's I state (tag 1) and the I slot its D state
+// (tag 0), so that one max still resolves the reference's tie order C > I > D.
+template <bool EDGE, bool COL>
 __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, const RowCtx &J, const int4 *s_ring, uint32_t *tbw, int lane)
 {
+    constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
     Tri dg = S.l;                                      // (r-1, c-1), rotated at the end of row r-1
     if (S.c4 < R_lo4(R)) {                             // column left the band: take column c+64
         S.c4 += 4 * WAVE;
         row_load_col(S, s_ring, R_lo4(R));
         // neither (r-1, c+64) nor (r-1, c+63) was in row r-1's band (its width is at most 63)
-        S.p.C = NEGT + 2; S.p.D = NEGT; S.p.I = NEGT + 1;
+        S.p.C = NEGT + 2; S.p.D = NEGT + TD; S.p.I = NEGT + TI;
         dg = S.p;
     }
     const int c4 = S.c4, uA = S.uA, uB = S.uB;
@@ -1438,7 +1499,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     y = dot2(R_rCy(R), uA, dg.D);
     z = dot2(R_rCz(R), uA, dg.I);
     if (EDGE) {                                        // no gap-open entering column 1 (mz_yama.c:173)
-        const bool g = c4 > 4;
+        const bool g = COL ? (r > 1) : (c4 > 4);       // (transposed: the reference's column 1 is row 1)
         const int kC = 4 * c_sc.go * R.dA * J.L;
         x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
         mC = max(max(x, y), z);
@@ -1456,17 +1517,17 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
         z = up.I - (R_cDe(R) - extD);
         x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
         mD = max(max(x, y), z);
-        nD = (mD & ~3) - extD;
+        nD = ((mD & ~3) | TD) - extD;
     } else {
         x = dot2(R_rDx(R), uA, up.C - R_cDe(R));
         y = up.D - R_penDye(R);
         z = up.I - R_cDe(R);
         mD = max(max(x, y), z);
-        nD = mD & ~3;
+        nD = (mD & ~3) | TD;
     }
     const bool active = (unsigned)(c4 - R_lo4(R)) <= (unsigned)R_wid4(R);
     nC = active ? nC : NEGT + 2;
-    nD = active ? nD : NEGT;
+    nD = active ? nD : NEGT + TD;
 
     // I: open candidates from the finished C / D of (r, c-1), then the prefix maximum along the row.
     // Lanes right of the band need no masking here: they come last in ring order.
@@ -1486,7 +1547,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     }
     g = prefix_max64(g);
     g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
-    nI = active ? g + Pl : NEGT + 1;
+    nI = active ? g + Pl : NEGT + TI;
     const int lI = ror1(nI);
     z = dot2(R_rIz(R), uA, lI);
     mI = max(base, z);
@@ -1524,7 +1585,7 @@ __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R
 }
 
 // rows r0..r1, two per iteration so that the record registers alternate instead of being copied
-template <bool EDGE>
+template <bool EDGE, bool COL>
 __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
                                          const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
 {
@@ -1541,27 +1602,26 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
     for (; r + 1 <= r1; r += 2) {
         row_rec_issue(raw, rows, r + 1);
         row_pre(S, Q, Ra, lane, cols, s_ring);
-        row_step<EDGE>(S, Ra, r, J, s_ring, tbw, lane);
+        row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
         row_rec_wait(Rb, raw, J.Kg, J.g1x);
         row_rec_issue(raw, rows, r + 2);
         row_pre(S, Q, Rb, lane, cols, s_ring);
-        row_step<EDGE>(S, Rb, r + 1, J, s_ring, tbw, lane);
+        row_step<EDGE, COL>(S, Rb, r + 1, J, s_ring, tbw, lane);
         row_rec_wait(Ra, raw, J.Kg, J.g1x);
     }
     if (r <= r1) {
         row_pre(S, Q, Ra, lane, cols, s_ring);
-        row_step<EDGE>(S, Ra, r, J, s_ring, tbw, lane);
+        row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int count)
+template <bool COL>
+__device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int lane, int4 *s_ring)
 {
-    __shared__ int4 s_ring[2 * FRING];                 // 4 KB
-    const int p = first + blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_ROW) return;
-    const int M = b.M[p], N = b.N[p];
+    constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
+    const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];      // rows / columns of this run
     RowCtx J;
-    J.K = b.K[p]; J.L = b.L[p]; J.N4 = 4 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
+    J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N4 = 4 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
     J.g1x = 2 * c_sc.g1; J.Kg = J.K * J.g1x;
     const int4 *rows = (const int4 *)(b.prep + b.offPrep[p]);
     const int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
@@ -1579,28 +1639,40 @@ __global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int 
     RowState S;
     S.c4 = 4 * lane;
     row_load_col(S, s_ring, 0);
-    const int rb0 = (b.poolRB + b.offBand[p])[0];
+    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    const int rb0 = COL ? t_hi(LB, N, 0) : RB[0];
     S.p.C = lane == 0 ? 2 : NEGT + 2;
-    S.p.D = lane == 0 ? 0 : NEGT;
-    S.p.I = lane <= rb0 ? 1 + S.Q : NEGT + 1;
+    S.p.D = lane == 0 ? TD : NEGT + TD;
+    S.p.I = lane <= rb0 ? TI + S.Q : NEGT + TI;
     S.l.C = ror1(S.p.C); S.l.D = ror1(S.p.D); S.l.I = ror1(S.p.I);
     S.wC = S.wD = S.wI = 0;
 
-    const int e1 = min(rL, M), e2 = max(rN, e1 + 1);  // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge
-    row_rows<true>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
-    row_rows<false>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
-    row_rows<true>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
+    // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge (transposed: row 1 is always an edge row)
+    const int e1 = min(max(rL, COL ? 1 : 0), M), e2 = max(rN, e1 + 1);
+    row_rows<true, COL>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
+    row_rows<false, COL>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
+    row_rows<true, COL>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
 
     if ((M & 15) != 15) {                              // flush the partial group
         const int sh = 2 * (15 - (M & 15));
         uint32_t *o = tbw + (M >> 4) * (3 * WAVE) + lane;
         o[0] = S.wC >> sh; o[WAVE] = S.wD >> sh; o[2 * WAVE] = S.wI >> sh;
     }
-    if (lane == (N & (WAVE - 1))) {                    // (C,D,I) at (M,N), unscaled
+    if (lane == (N & (WAVE - 1))) {                    // the reference's (C,D,I) at (M,N), unscaled
         b.final3[3 * p + 0] = S.p.C >> 2;
-        b.final3[3 * p + 1] = S.p.D >> 2;
-        b.final3[3 * p + 2] = S.p.I >> 2;
+        b.final3[3 * p + 1] = (COL ? S.p.I : S.p.D) >> 2;
+        b.final3[3 * p + 2] = (COL ? S.p.D : S.p.I) >> 2;
     }
+}
+
+__global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int count)
+{
+    __shared__ int4 s_ring[2 * FRING];                 // 4 KB
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (b.status[p] != MZ_OK) return;
+    const int mode = b.mode[p];
+    if (mode == MZ_MODE_ROW)      dp_row_body<false>(b, p, lane, s_ring);
+    else if (mode == MZ_MODE_COL) dp_row_body<true>(b, p, lane, s_ring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2260,15 +2332,17 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
 // traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
+#define WALK_LANES 16            // pairs per wave: the chase is latency-bound, so waves in flight matter, not lanes
 __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
 {
-    const int p = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x >= WALK_LANES) return;
+    const int p = first + blockIdx.x * WALK_LANES + threadIdx.x;
     if (p >= first + count || b.status[p] != MZ_OK) return;
     const int M = b.M[p], N = b.N[p];
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
-    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode == MZ_MODE_ROW;
+    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode == MZ_MODE_ROW || mode == MZ_MODE_COL;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -2286,6 +2360,13 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
             const int t = r + c, q = (r - 1) / 3, j = (r - 1) - 3 * q;
             const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
             const unsigned tg = (tbw[((long long)(t >> 4) * 9 + j * 3 + sidx) * 16 + (q & 15)] >> (2 * (t & 15))) & 3;
+            stb = tg | (tg << 2) | (tg << 4);
+        } else if (mode == MZ_MODE_COL) {
+            // transposed row-parallel kernel: one entry per COLUMN, lane = row & 63; its D slot (stream 1)
+            // holds the picks of the reference's I state and its I slot (stream 2) those of D.  Column 0 is
+            // not stored: only D is reachable there (mz_yama.c:211), and it comes from D.
+            const int sidx = node == MZ_FC ? 0 : node == MZ_FI ? 1 : 2;
+            const unsigned tg = c == 0 ? 0u : (tbw[((c >> 4) * 3 + sidx) * WAVE + (r & (WAVE - 1))] >> (2 * (c & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
         } else if (mode == MZ_MODE_ROW) {
             // row-parallel kernel: word ((r>>4)*3 + s)*64 + (c & 63), bits 2*(r&15)
@@ -2432,7 +2513,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_walk, dim3((count + WAVE - 1) / WAVE), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "walk launch");
     return 0;
 }
