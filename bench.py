@@ -82,7 +82,7 @@ def main():
     batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"],
                              first_pair=rank * pairs)
     db = mz.DevBatch(batch, device=dev)                          # inputs now resident in HBM
-    db2 = db.alternate()                                         # second workspace for the pipelined form
+    ring = [db, db.alternate(), db.alternate()]                  # three rotating workspaces for the pipelined form
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -96,21 +96,22 @@ def main():
     for _ in range(args.steps):
         kern_ms += np.array(db.run(timed=True))
     sync_all()
-    # production form for a stream of batches (mz_dev_run_async): the latency-bound traceback walk + emit of
-    # step k run on a second stream beside plan + DP of step k+1, on two alternating workspaces.  Every step
-    # does all of its work; all K steps are complete before the closing synchronisation.  The parity gate
-    # below checks what these pipelined steps left in BOTH workspaces.
+    # production form for a stream of batches (mz_dev_run_async): the DPs run back to back; plan + prep of step
+    # k+1 and the latency-bound traceback walk + emit of step k-1 run on two helper streams beside the DP of
+    # step k, on three rotating workspaces.  Every step does all of its work; all K steps are complete before
+    # the closing synchronisation.  The parity gate below checks what these pipelined steps left in EVERY
+    # workspace they used.
     for i in range(args.warmup):
-        (db if i % 2 == 0 else db2).run_async()
+        ring[i % 3].run_async()
     db.wait()
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        (db if (args.warmup + i) % 2 == 0 else db2).run_async()
+        ring[(args.warmup + i) % 3].run_async()
     db.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    workspaces = [db] + ([db2] if args.warmup + args.steps >= 2 else [])
+    workspaces = ring[:min(3, args.warmup + args.steps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -174,13 +174,14 @@ int mz_dev_emit(const mz_dev_batch *b, void *stream);   /* merged columns       
 /* The whole path for one batch, phases one after the other on `stream`.  If ms != NULL it receives the
  * HIP-event time of {plan, dp, walk, emit} in milliseconds (synchronises the stream). */
 int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4]);
-/* Pipelined form for a stream of batches.  The DPs of successive batches run back to back on `stream`; the
- * plan of batch k+1 runs on a library stream beside the DP of batch k, and walk + emit of batch k on another
- * beside the DP of batch k+1 (the walk is latency-bound, the plan a short bandwidth burst, the DP VALU-bound).
- * Consecutive calls must use different workspaces (two alternating ones suffice; the library orders reuse).
- * The batch's inputs must be complete when the call is made, or ready_event (a hipEvent_t recorded after
- * their producer) must be given; NULL otherwise.  mz_dev_wait() makes `stream` wait for everything issued so
- * far; results of a batch are valid after it. */
+/* Pipelined form for a stream of batches.  The DPs of successive batches run back to back on `stream`; plan
+ * and prep of a batch run on one library stream and walk + emit on another, beside the DPs of the neighbouring
+ * batches.  Calls in flight at the same time must use different workspaces (tbw/script/out/prep and the plan
+ * arrays); the library keys a workspace by its tbw pointer and orders its reuse after the walk/emit of the
+ * batch that used it last (at most 8 workspaces in rotation).  Three rotating workspaces keep everything but
+ * the DP off the critical path; two work, with less overlap.  The batch's inputs must be complete when the
+ * call is made, or ready_event (a hipEvent_t recorded after their producer) must be given; NULL otherwise.
+ * mz_dev_wait() makes `stream` wait for everything issued so far; results of a batch are valid after it. */
 int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event);
 int mz_dev_wait(void *stream);
 

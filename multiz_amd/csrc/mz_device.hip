@@ -30,8 +30,8 @@
 #define REC_DW 16           // dwords per staged row record
 // row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then
 // column records of columns 0 .. ROW_NCOLS(N)-1
-#define RREC 8              // dwords per row record in b.prep
-#define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI P Q
+#define RREC 16             // dwords per row record in b.prep
+#define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI+P P Q
 #define ROW_NROWS(M) ((M) + 2)
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
 #define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + (long long)RCOL * ROW_NCOLS(N) + 2LL * ((M) + 1))
@@ -64,6 +64,14 @@ __device__ __forceinline__ int dot4(int a, int b, int acc) { return __builtin_am
 __device__ __forceinline__ int dot2(int a, int b, int acc)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
+}
+// acc + a.b with the result in a new register (VOP3P form): the compiler's choice, v_dot2c, accumulates
+// in place and costs a v_mov when acc must survive; a is a scalar register
+__device__ __forceinline__ int dot2_keep(int a, int b, int acc)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(acc));
+    return d;
 }
 // lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
 __device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
 // Exclusive prefix sums of the per-pair sizes, the failure count and the list of packed-kernel pairs.
 // Three small launches: per-block totals, scan of the block totals, per-block scan + write.
 #define SCAN_Q 6
-#define SCAN_B 1024
+#define SCAN_B 256          // small blocks: these kernels run beside the DP and must fit into whatever slots are free
 __device__ __forceinline__ void scan_load(const mz_dev_batch &b, int i, long long v[SCAN_Q])
 {
     if (i < b.n) {
@@ -1269,7 +1277,7 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
         int4 *d = s_out + lane * (RREC / 4);
         if (rr > M) {
             d[0] = make_int4(MZ_BIG, 0, 0, 0);
-            d[1] = make_int4(0, 0, 0, 0);
+            d[1] = d[2] = d[3] = make_int4(0, 0, 0, 0);
         } else {
             const uint8_t *col = A + (long long)(rr - 1) * K;
             unsigned cnt = 0;
@@ -1299,11 +1307,13 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
             // (written by other lanes of this wave above: read past the L1)
             const int lo = COL ? __hip_atomic_load(tlo + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB[rr];
             const int hi = COL ? __hip_atomic_load(thi + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RB[rr];
-            // {lo4, wid4 | last, dA nA a00 a11 (bytes), cDe | penDye, w01, w23, w45}: the DP kernel derives
-            // the int16 row vectors from the four counts with scalar instructions
-            d[0] = make_int4(4 * lo, 4 * (hi - lo) | (int)last, dA | (nA << 8) | (a00 << 16) | (a11 << 24),
-                             4 * (go + ge) * nA * L);
-            d[1] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA), pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+            // {lo32, wid32, rIx, rCxA | rCxB (= rDx), rCy, rCz, cDe | penDye - cDe, w01, w23, w45 | rIy, rIz, dA nA last, -}
+            const int g1 = 2 * c_sc.g1;
+            const int cDe = 4 * (go + ge) * nA * L;
+            d[0] = make_int4(32 * lo, 32 * (hi - lo), last ? 0 : pack2(-K * g1, -dA * g1), pack2((nA - dA) * g1, -a11 * g1));
+            d[1] = make_int4(pack2(-a00 * g1, 0), pack2((nA - a00 - dA) * g1, 0), pack2((nA - dA) * g1, -dA * g1), cDe);
+            d[2] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA) - cDe, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+            d[3] = make_int4(last ? 0 : pack2(-K * g1, 0), last ? 0 : pack2(-K * g1, -K * g1), dA | (nA << 8) | ((int)last << 16), 0);
         }
         __syncthreads();
         const int n4 = min(WAVE, nrows - base) * (RREC / 4);
@@ -1353,7 +1363,7 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
         carryP = __builtin_amdgcn_readlane(eP, WAVE - 1);
         carryQ = __builtin_amdgcn_readlane(eQ, WAVE - 1);
         s_out[2 * lane] = make_int4(e0, e1, e2, e3);
-        s_out[2 * lane + 1] = make_int4(e4, e5, eP, eQ);
+        s_out[2 * lane + 1] = make_int4(e4, e5 + eP, eP, eQ);      // xI + P, P, Q
         __syncthreads();
         int4 *g = cols + 2 * (cc - lane);
         g[lane] = s_out[lane];
@@ -1364,7 +1374,7 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
 
 __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
 {
-    __shared__ int4 s_out[WAVE * 2];
+    __shared__ int4 s_out[WAVE * (RREC / 4)];
     const int p = first + blockIdx.x, lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int mode = b.mode[p];
@@ -1372,61 +1382,65 @@ __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int
     else if (mode == MZ_MODE_COL) rowprep_body<true>(b, p, lane, s_out);
 }
 
-// the row record in SGPRs: one scalar load of 8 dwords, then scalar arithmetic for the int16 row vectors
-struct RowRec {
-    int lo4, wid4;                // 4*LB[r], 4*(RB[r]-LB[r])
-    int rIx, rIy, rIz;            // I-state row vectors against uA (zero on row M)
-    int rCxA, rCxB, rCy, rCz;     // C-state row vectors (rCxB is also the D-state vector rDx)
-    int cDe, penDye;              // 4*(go+ge)*nA*L, 4*(go*L*(nA-PA00) + ge*L*nA)
-    int w01, w23, w45;            // 2*(w[k] - go*dA)
-    int dA, nA, last;             // EDGE rows: kC = 4*go*dA*L, extD = 4*ge*L*nA, kIfix on row M
-};
-#define R_lo4(R)    ((R).lo4)
-#define R_wid4(R)   ((R).wid4)
-#define R_rIx(R)    ((R).rIx)
-#define R_rIy(R)    ((R).rIy)
-#define R_rIz(R)    ((R).rIz)
-#define R_rCxA(R)   ((R).rCxA)
-#define R_rCxB(R)   ((R).rCxB)
-#define R_rCy(R)    ((R).rCy)
-#define R_rCz(R)    ((R).rCz)
-#define R_rDx(R)    ((R).rCxB)
-#define R_cDe(R)    ((R).cDe)
-#define R_penDye(R) ((R).penDye)
-#define R_w01(R)    ((R).w01)
-#define R_w23(R)    ((R).w23)
-#define R_w45(R)    ((R).w45)
+// the row record in SGPRs.  (The scalar unit is shared by the four SIMDs of a CU: deriving the vectors from
+// a compact record with ~25 scalar instructions per row made the loop scalar-bound, so the prep pass stores
+// them ready-made.)  16 dwords in memory; interior rows load the first 12, EDGE rows all of them:
+//   a = {lo32, wid32, rIx, rCxA, rCxB (= rDx), rCy, rCz, cDe}   b = {penDye - cDe, w01, w23, w45}
+//   c = {rIy, rIz, dA | nA << 8 | last << 16, -}    (rIy, rIz are pair constants except on the last row)
+typedef int int8v __attribute__((ext_vector_type(8)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+struct RowRec { int8v a; int4v b; int4v c; };
+#define R_lo32(R)   ((R).a[0])      /* 32 * LB[r]: the column counter is kept times 32, the ring byte offset */
+#define R_wid32(R)  ((R).a[1])      /* 32 * (RB[r] - LB[r]) */
+#define R_rIx(R)    ((R).a[2])
+#define R_rCxA(R)   ((R).a[3])
+#define R_rCxB(R)   ((R).a[4])
+#define R_rDx(R)    ((R).a[4])
+#define R_rCy(R)    ((R).a[5])
+#define R_rCz(R)    ((R).a[6])
+#define R_cDe(R)    ((R).a[7])
+#define R_dDy(R)    ((R).b[0])      /* penDye - cDe */
+#define R_w01(R)    ((R).b[1])
+#define R_w23(R)    ((R).b[2])
+#define R_w45(R)    ((R).b[3])
+#define R_dA(R)     ((R).c[2] & 0xff)
+#define R_nA(R)     (((R).c[2] >> 8) & 0xff)
+#define R_last(R)   ((R).c[2] >> 16)
 
-__device__ __forceinline__ void row_rec_issue(int8v &raw, const int4 *rows, int r)
+// a uniform 64-bit value in scalar registers (the compiler keeps what it loaded with vector loads in VGPRs)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 {
-    const int4 *src = rows + (long long)(r - 1) * (RREC / 4);
-    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(raw) : "s"(src) : "memory");
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
-// wait for the load, then derive (scalar ALU; Kg = K * 2*g1, g1x = 2*g1)
-__device__ __forceinline__ void row_rec_wait(RowRec &R, int8v &raw, int Kg, int g1x)
+
+// scalar loads return out of order, so the only wait is "all of them": records are requested in batches and
+// a batch is waited for as a whole (row_rec_wait*)
+template <bool FULL, int OFF>
+__device__ __forceinline__ void row_rec_issue(RowRec &R, unsigned long long rp)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw) : : "memory");
-    const int cn = raw[2];
-    const int dA = cn & 0xff, nA = (cn >> 8) & 0xff, a00 = (cn >> 16) & 0xff, a11 = (int)((unsigned)cn >> 24);
-    const int last = raw[1] & 1;
-    const int t1 = (nA - dA) * g1x, t2 = dA * g1x, t3 = a00 * g1x, t4 = a11 * g1x;
-    R.lo4 = raw[0]; R.wid4 = raw[1] & ~3;
-    R.rIx = last ? 0 : pack2(-Kg, -t2);
-    R.rIy = last ? 0 : pack2(-Kg, 0);
-    R.rIz = last ? 0 : pack2(-Kg, -Kg);
-    R.rCxA = pack2(t1, -t4);
-    R.rCxB = pack2(-t3, 0);
-    R.rCy = pack2(t1 - t3, 0);
-    R.rCz = pack2(t1, -t2);
-    R.cDe = raw[3]; R.penDye = raw[4];
-    R.w01 = raw[5]; R.w23 = raw[6]; R.w45 = raw[7];
-    R.dA = dA; R.nA = nA; R.last = last;
+    if (FULL)
+        asm volatile("s_load_dwordx8 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx4 %2, %3, %6"
+                     : "=&s"(R.a), "=&s"(R.b), "=&s"(R.c) : "s"(rp), "n"(OFF), "n"(OFF + 32), "n"(OFF + 48) : "memory");
+    else
+        asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4"
+                     : "=&s"(R.a), "=&s"(R.b) : "s"(rp), "n"(OFF), "n"(OFF + 32) : "memory");
+}
+template <bool FULL>
+__device__ __forceinline__ void row_rec_wait(RowRec &R)
+{
+    if (FULL) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(R.c) : : "memory");
+    else      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b) : : "memory");
+}
+__device__ __forceinline__ void row_rec_wait2(RowRec &R, RowRec &T)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(T.a), "+s"(T.b) : : "memory");
 }
 
 struct RowState {
-    int c4;                       // 4 * the column this lane holds
+    int c32;                      // 32 * the column this lane holds
     int uA, uB, c01, c23, c45;
-    int xI, P, Q;                 // EDGE rows only
+    int xIP, P, Q;                // xI + P (EDGE rows recover xI), running sums
     int xIPl, Pl;                 // xI + P and P, both minus 2^30 while the lane is in the lower ring period
     Tri p;                        // row r-1 at this column (tagged), sentinel outside the band
     Tri l;                        // the same, one lane to the left (= ror1(p) before any re-arm)
@@ -1442,16 +1456,16 @@ __device__ __forceinline__ void row_stage_cols(int first, int lane, const int4 *
     ring[2 * (cc & (FRING - 1)) + 1] = y;
 }
 
-// column data of column c4/4 from the ring; lo4 = 4*LB of the row about to be computed
-__device__ __forceinline__ void row_load_col(RowState &S, const int4 *ring, int lo4)
+// column data of column c32/32 from the ring; lo32 = 32*LB of the row about to be computed
+__device__ __forceinline__ void row_load_col(RowState &S, const int4 *ring, int lo32)
 {
-    const int4 *e = (const int4 *)((const char *)ring + ((S.c4 << 3) & (32 * FRING - 32)));
+    const int4 *e = (const int4 *)((const char *)ring + (S.c32 & (32 * FRING - 32)));
     const int4 x = e[0], y = e[1];
     S.uA = x.x; S.uB = x.y; S.c01 = x.z; S.c23 = x.w;
-    S.c45 = y.x; S.xI = y.y; S.P = y.z; S.Q = y.w;
-    const int lift = ((S.c4 ^ lo4) >> 8) == 0 ? ROW_LIFT : 0;   // same 64-column period as the band's left edge
+    S.c45 = y.x; S.xIP = y.y; S.P = y.z; S.Q = y.w;
+    const int lift = ((S.c32 ^ lo32) >> 11) == 0 ? ROW_LIFT : 0;  // same 64-column period as the band's left edge
     S.Pl = S.P - lift;
-    S.xIPl = S.xI + S.Pl;
+    S.xIPl = S.xIP - lift;
 }
 
 // inclusive prefix maximum over the 64 lanes (lane order)
@@ -1473,7 +1487,7 @@ __device__ __forceinline__ int prefix_max64(int g)
     return g;
 }
 
-struct RowCtx { int K, L, N4, KL4go, Kg, g1x; };
+struct RowCtx { int K, L, N32, KL4go, rIy, rIz; };     // rIy, rIz: the I-state vectors of every row but the last
 
 // one row of the band; EDGE = the row can hold column 0, 1 or N, or is row M (COL: or is row 1).
 // COL = transposed problem: the D slot holds the reference's I state (tag 1) and the I slot its D state
@@ -1482,15 +1496,16 @@ template <bool EDGE, bool COL>
 __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, const RowCtx &J, const int4 *s_ring, uint32_t *tbw, int lane)
 {
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
-    Tri dg = S.l;                                      // (r-1, c-1), rotated at the end of row r-1
-    if (S.c4 < R_lo4(R)) {                             // column left the band: take column c+64
-        S.c4 += 4 * WAVE;
-        row_load_col(S, s_ring, R_lo4(R));
-        // neither (r-1, c+64) nor (r-1, c+63) was in row r-1's band (its width is at most 63)
-        S.p.C = NEGT + 2; S.p.D = NEGT + TD; S.p.I = NEGT + TI;
-        dg = S.p;
+    const Tri dg = S.l;                                // (r-1, c-1), rotated at the end of row r-1
+    // column left the band: take column c+64.  Neither (r-1, c+64) nor (r-1, c+63) was in row r-1's band
+    // (its width is at most 63), so a re-armed lane's C and D are sentinels in this row: instead of resetting
+    // its "up" and "diagonal" registers, the lane is masked out of C and D below.
+    const bool fresh = S.c32 < R_lo32(R);
+    if (fresh) {
+        S.c32 += 32 * WAVE;
+        row_load_col(S, s_ring, R_lo32(R));
     }
-    const int c4 = S.c4, uA = S.uA, uB = S.uB;
+    const int c32 = S.c32, uA = S.uA, uB = S.uB;
     const Tri &up = S.p;
     int x, y, z, mI, mC, mD, nI, nC, nD;
 
@@ -1499,8 +1514,8 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     y = dot2(R_rCy(R), uA, dg.D);
     z = dot2(R_rCz(R), uA, dg.I);
     if (EDGE) {                                        // no gap-open entering column 1 (mz_yama.c:173)
-        const bool g = COL ? (r > 1) : (c4 > 4);       // (transposed: the reference's column 1 is row 1)
-        const int kC = 4 * c_sc.go * R.dA * J.L;
+        const bool g = COL ? (r > 1) : (c32 > 32);     // (transposed: the reference's column 1 is row 1)
+        const int kC = 4 * c_sc.go * R_dA(R) * J.L;
         x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
         mC = max(max(x, y), z);
         nC = dot2(R_w01(R), S.c01, dot2(R_w23(R), S.c23, dot2(R_w45(R), S.c45, (mC & ~3) | 2))) + (g ? 0 : kC);
@@ -1508,39 +1523,39 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
         mC = max(max(x, y), z);
         nC = dot2(R_w01(R), S.c01, dot2(R_w23(R), S.c23, dot2(R_w45(R), S.c45, (mC & ~3) | 2)));
     }
-    // D
+    // D: the penalty cDe common to the three candidates is taken off after the pick
     if (EDGE) {                                        // none in column 0 or N (mz_yama.c:211)
-        const bool g = (c4 > 0) & (c4 < J.N4);
-        const int extD = 4 * c_sc.ge * J.L * R.nA;
-        x = dot2(R_rDx(R), uA, up.C - (R_cDe(R) - extD));
-        y = up.D - (R_penDye(R) - extD);
-        z = up.I - (R_cDe(R) - extD);
-        x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
+        const bool g = (c32 > 0) & (c32 < J.N32);
+        const int extD = 4 * c_sc.ge * J.L * R_nA(R);
+        x = dot2_keep(R_rDx(R), uA, up.C);
+        y = up.D - R_dDy(R);
+        x = g ? x : up.C + (R_cDe(R) - extD); y = g ? y : up.D + (R_cDe(R) - extD);
+        z = g ? up.I : up.I + (R_cDe(R) - extD);
         mD = max(max(x, y), z);
-        nD = ((mD & ~3) | TD) - extD;
+        nD = ((mD & ~3) | TD) - R_cDe(R);
     } else {
-        x = dot2(R_rDx(R), uA, up.C - R_cDe(R));
-        y = up.D - R_penDye(R);
-        z = up.I - R_cDe(R);
-        mD = max(max(x, y), z);
-        nD = (mD & ~3) | TD;
+        x = dot2_keep(R_rDx(R), uA, up.C);
+        y = up.D - R_dDy(R);
+        mD = max(max(x, y), up.I);
+        nD = ((mD & ~3) | TD) - R_cDe(R);
     }
-    const bool active = (unsigned)(c4 - R_lo4(R)) <= (unsigned)R_wid4(R);
-    nC = active ? nC : NEGT + 2;
-    nD = active ? nD : NEGT + TD;
+    const bool active = (unsigned)(c32 - R_lo32(R)) <= (unsigned)R_wid32(R);
+    const bool activeCD = active && !fresh;
+    nC = activeCD ? nC : NEGT + 2;
+    nD = activeCD ? nD : NEGT + TD;
 
     // I: open candidates from the finished C / D of (r, c-1), then the prefix maximum along the row.
     // Lanes right of the band need no masking here: they come last in ring order.
     const int lC = ror1(nC), lD = ror1(nD);
-    x = dot2(R_rIx(R), uA, lC);
-    y = dot2(R_rIy(R), uA, lD);
+    x = dot2_keep(R_rIx(R), uA, lC);                   // lC, lD, lI stay live: they are row r+1's diagonal
+    y = dot2_keep(EDGE ? R.c[0] : J.rIy, uA, lD);
     const int base = max(x, y);
     int g, Pl;
     if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
-        const bool last = R.last != 0;
+        const bool last = R_last(R) != 0;
         const int lift = S.P - S.Pl;
         Pl = (last ? S.Q : S.P) - lift;
-        g = (base & ~3) - S.xI + (last ? J.KL4go : 0) - Pl;
+        g = (base & ~3) - (S.xIP - S.P) + (last ? J.KL4go : 0) - Pl;
     } else {
         Pl = S.Pl;
         g = (base & ~3) - S.xIPl;
@@ -1549,7 +1564,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
     nI = active ? g + Pl : NEGT + TI;
     const int lI = ror1(nI);
-    z = dot2(R_rIz(R), uA, lI);
+    z = dot2_keep(EDGE ? R.c[1] : J.rIz, uA, lI);
     mI = max(base, z);
 
     S.p.C = nC; S.p.D = nD; S.p.I = nI;
@@ -1557,62 +1572,98 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     S.wC = __builtin_amdgcn_alignbit(mC, S.wC, 2);
     S.wD = __builtin_amdgcn_alignbit(mD, S.wD, 2);
     S.wI = __builtin_amdgcn_alignbit(mI, S.wI, 2);
-    if ((r & 15) == 15) {
-        uint32_t *o = tbw + (r >> 4) * (3 * WAVE) + lane;
-        o[0] = S.wC; o[WAVE] = S.wD; o[2 * WAVE] = S.wI;
-    }
 }
 
-struct RowLoop { int cst, per; };                      // highest staged column, LB >> 6
+struct RowLoop { int next32; };                        // 32 * first column of the next 64-column period
 
-// bookkeeping before row r (record R): stage 64 columns ahead; re-lift when the band's left edge enters
-// the next 64-column period (every lane is then in the lower period again)
+// bookkeeping before a row (record R), one scalar compare per row: when the band's left edge enters the next
+// 64-column period, stage the period after it (the ring then holds this period and the next: everything a
+// re-arming lane can ask for) and re-lift (every lane is in the lower period again)
 __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, const int4 *cols, int4 *s_ring)
 {
-    const int lo = R_lo4(R) >> 2;
-    if (lo + WAVE - 1 > Q.cst) {
-        row_stage_cols(Q.cst + 1, lane, cols, s_ring);
-        Q.cst += WAVE;
+    if (R_lo32(R) >= Q.next32) {
+        asm volatile("; next 64-column period (keep this a branch)");
+        row_stage_cols((Q.next32 >> 5) + WAVE, lane, cols, s_ring);
         __syncthreads();
-    }
-    if ((lo >> 6) != Q.per) {
-        asm volatile("; re-lift (once per 64 columns): keep this a branch");
-        Q.per = lo >> 6;
-        const int lift = ((S.c4 ^ (4 * lo)) >> 8) == 0 ? ROW_LIFT : 0;
+        const int lift = ((S.c32 ^ Q.next32) >> 11) == 0 ? ROW_LIFT : 0;
         S.Pl = S.P - lift;
-        S.xIPl = S.xI + S.Pl;
+        S.xIPl = S.xIP - lift;
+        Q.next32 += 32 * WAVE;
     }
 }
 
-// rows r0..r1, two per iteration so that the record registers alternate instead of being copied
+__device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int r, int lane)
+{
+    uint32_t *o = tbw + (r >> 4) * (3 * WAVE) + lane;
+    o[0] = S.wC; o[WAVE] = S.wD; o[2 * WAVE] = S.wI;
+}
+
+// one row at a time (EDGE rows, and the ends of the interior range): the next record is requested before the
+// row is computed and waited for after it
 template <bool EDGE, bool COL>
-__device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
-                                         const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
+__device__ __forceinline__ void row_rows_single(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
+                                                const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
 {
     r0 = __builtin_amdgcn_readfirstlane(r0);
     r1 = __builtin_amdgcn_readfirstlane(r1);
     if (r0 > r1) return;
-    // a record is complete (issued AND waited for) whenever it crosses a loop edge, so the compiler never
-    // copies registers whose scalar load is still in flight
     RowRec Ra, Rb;
-    int8v raw;
-    row_rec_issue(raw, rows, r0);
-    row_rec_wait(Ra, raw, J.Kg, J.g1x);
-    int r = r0;
-    for (; r + 1 <= r1; r += 2) {
-        row_rec_issue(raw, rows, r + 1);
+    unsigned long long rp = uniform64((unsigned long long)rows + (unsigned long long)(r0 - 1) * (4 * RREC));
+    row_rec_issue<EDGE, 0>(Ra, rp);
+    row_rec_wait<EDGE>(Ra);
+    for (int r = r0; r <= r1; ++r) {
+        row_rec_issue<EDGE, 4 * RREC>(Rb, rp);
         row_pre(S, Q, Ra, lane, cols, s_ring);
         row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
-        row_rec_wait(Rb, raw, J.Kg, J.g1x);
-        row_rec_issue(raw, rows, r + 2);
-        row_pre(S, Q, Rb, lane, cols, s_ring);
-        row_step<EDGE, COL>(S, Rb, r + 1, J, s_ring, tbw, lane);
-        row_rec_wait(Ra, raw, J.Kg, J.g1x);
+        if ((r & 15) == 15) row_store(S, tbw, r, lane);
+        row_rec_wait<EDGE>(Rb);
+        Ra = Rb;
+        rp += 4 * RREC;
     }
-    if (r <= r1) {
-        row_pre(S, Q, Ra, lane, cols, s_ring);
-        row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+}
+
+// interior rows r0..r1.  A record takes about as long to arrive from HBM as eight waves take to compute a
+// row, so records are requested TWO rows ahead, in batches of two (scalar loads return out of order: the only
+// wait is for all of them).  Four rows per iteration, starting on a multiple of four, so that the record
+// registers alternate instead of being copied and only the fourth row can close a 16-row traceback group.
+// A record is complete (requested AND waited for) whenever it crosses a loop edge, so the compiler never
+// copies registers whose load is still in flight.
+template <bool COL>
+__device__ __forceinline__ void row_rows_interior(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
+                                                  const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
+{
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    r1 = __builtin_amdgcn_readfirstlane(r1);
+    if (r0 > r1) return;
+    const int ra = min((r0 + 3) & ~3, r1 + 1);         // first multiple of four
+    row_rows_single<false, COL>(S, Q, r0, ra - 1, lane, J, rows, cols, s_ring, tbw);
+    int r = ra;
+    if (r + 3 <= r1) {
+        RowRec A0, A1, B0, B1;
+        unsigned long long rp = uniform64((unsigned long long)rows + (unsigned long long)(r - 1) * (4 * RREC));
+        row_rec_issue<false, 0>(A0, rp);
+        row_rec_issue<false, 4 * RREC>(A1, rp);
+        row_rec_wait2(A0, A1);
+        for (; r + 3 <= r1; r += 4) {
+            row_rec_issue<false, 8 * RREC>(B0, rp);
+            row_rec_issue<false, 12 * RREC>(B1, rp);
+            row_pre(S, Q, A0, lane, cols, s_ring);
+            row_step<false, COL>(S, A0, r, J, s_ring, tbw, lane);
+            row_pre(S, Q, A1, lane, cols, s_ring);
+            row_step<false, COL>(S, A1, r + 1, J, s_ring, tbw, lane);
+            row_rec_wait2(B0, B1);
+            row_rec_issue<false, 16 * RREC>(A0, rp);
+            row_rec_issue<false, 20 * RREC>(A1, rp);
+            row_pre(S, Q, B0, lane, cols, s_ring);
+            row_step<false, COL>(S, B0, r + 2, J, s_ring, tbw, lane);
+            row_pre(S, Q, B1, lane, cols, s_ring);
+            row_step<false, COL>(S, B1, r + 3, J, s_ring, tbw, lane);
+            if (((r + 3) & 15) == 15) row_store(S, tbw, r + 3, lane);
+            row_rec_wait2(A0, A1);
+            rp += 16 * RREC;
+        }
     }
+    row_rows_single<false, COL>(S, Q, r, r1, lane, J, rows, cols, s_ring, tbw);
 }
 
 template <bool COL>
@@ -1621,23 +1672,22 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
     const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];      // rows / columns of this run
     RowCtx J;
-    J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N4 = 4 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
-    J.g1x = 2 * c_sc.g1; J.Kg = J.K * J.g1x;
+    J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N32 = 32 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
+    J.rIy = pack2(-J.K * 2 * c_sc.g1, 0); J.rIz = pack2(-J.K * 2 * c_sc.g1, -J.K * 2 * c_sc.g1);
     const int4 *rows = (const int4 *)(b.prep + b.offPrep[p]);
     const int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
     uint32_t *tbw = b.tbw + b.offTb[p];
     const int rL = b.edgeLo[p], rN = b.edgeHi[p];     // rows <= rL hold column 0/1, rows >= rN column N
 
     RowLoop Q;
-    Q.per = 0;
+    Q.next32 = 32 * WAVE;
     row_stage_cols(0, lane, cols, s_ring);
     row_stage_cols(WAVE, lane, cols, s_ring);
     __syncthreads();
-    Q.cst = 2 * WAVE - 1;
 
     // row 0 in closed form (mz_yama.c:83-94): C = D = NEG beyond (0,0); I(0,c) = -ge*K*(nB_1+..+nB_c)
     RowState S;
-    S.c4 = 4 * lane;
+    S.c32 = 32 * lane;
     row_load_col(S, s_ring, 0);
     const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
     const int rb0 = COL ? t_hi(LB, N, 0) : RB[0];
@@ -1649,9 +1699,9 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 
     // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge (transposed: row 1 is always an edge row)
     const int e1 = min(max(rL, COL ? 1 : 0), M), e2 = max(rN, e1 + 1);
-    row_rows<true, COL>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
-    row_rows<false, COL>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
-    row_rows<true, COL>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
+    row_rows_single<true, COL>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
+    row_rows_interior<COL>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
+    row_rows_single<true, COL>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
 
     if ((M & 15) != 15) {                              // flush the partial group
         const int sh = 2 * (15 - (M & 15));
@@ -2318,21 +2368,27 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
     __shared__ int s_pad[MZ_LDS_PAD];
     if (b.n < 0) s_pad[threadIdx.x] = 1;
 #endif
-    const int p = first + blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK) return;
-    const int mode = b.mode[p];
+    // a fixed grid of waves strides over the batch: when the row-parallel kernels took every pair (the usual
+    // case) this launch costs a few microseconds instead of one dispatched-and-exited wave per pair
+    const int lane = threadIdx.x;
     int *s_rec = (int *)smem;
-    if (mode == MZ_MODE_FASTT)      dp_tag_body(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
-    else if (mode == MZ_MODE_FAST)  dp_fast_body<false>(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
-    else if (mode == MZ_MODE_WF64)  dp_wf64_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
-    else if (mode == MZ_MODE_STRIP) dp_strip_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
+    for (int p = first + blockIdx.x; p < first + count; p += gridDim.x) {
+        if (b.status[p] != MZ_OK) continue;
+        const int mode = b.mode[p];
+        if (mode == MZ_MODE_FASTT)      dp_tag_body(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
+        else if (mode == MZ_MODE_FAST)  dp_fast_body<false>(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
+        else if (mode == MZ_MODE_WF64)  dp_wf64_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
+        else if (mode == MZ_MODE_STRIP) dp_strip_body(b, p, lane, s_rec, (int4 *)(s_rec + 2 * WAVE * REC_DW));
+        else continue;
+        __syncthreads();                               // the next pair restages the same LDS
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // traceback walk (mz_yama.c:257-291): one lane per pair, serial pointer chase over the
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
-#define WALK_LANES 16            // pairs per wave: the chase is latency-bound, so waves in flight matter, not lanes
+#define WALK_LANES 64            // pairs per wave (measured: 16 per wave is no faster -- the chase is bound by its own dependent loads -- and costs four times the instruction issue beside the DP)
 __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
 {
     if (threadIdx.x >= WALK_LANES) return;
@@ -2506,7 +2562,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_dp, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }

@@ -70,7 +70,6 @@ static struct {
     hipStream_t stream3;                   /* pipelined form: plan of batch k+1 beside the DP of batch k */
     hipEvent_t ev[5];
     hipEvent_t evs[MZ_SLICES + 1];
-    int async_k;                           /* batches issued through mz_dev_run_async() */
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
@@ -109,11 +108,11 @@ int mz_init(int device)
         return set_err("HIP device %d out of range (%d present)", device, count);
     HIPCK(hipSetDevice(device));
     HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
-    {   /* helper streams run at the lowest priority: the DP on the caller's stream gets the wave slots first */
-        int lowest = 0, highest = 0;
-        HIPCK(hipDeviceGetStreamPriorityRange(&lowest, &highest));
-        HIPCK(hipStreamCreateWithPriority(&G.stream2, hipStreamNonBlocking, lowest));
-        HIPCK(hipStreamCreateWithPriority(&G.stream3, hipStreamNonBlocking, lowest));
+    {   /* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs
+         * 4 % of the pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
+        int prio = getenv("MZ_HELPER_PRIO") ? atoi(getenv("MZ_HELPER_PRIO")) : 0;
+        HIPCK(hipStreamCreateWithPriority(&G.stream2, hipStreamNonBlocking, prio));
+        HIPCK(hipStreamCreateWithPriority(&G.stream3, hipStreamNonBlocking, prio));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
@@ -123,6 +122,10 @@ int mz_init(int device)
     G.ss_seen = NULL;
     return 0;
 }
+
+#define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
+static struct { const void *key; hipEvent_t done; int used; } g_ws[MZ_WS_MAX];
+static int g_ws_victim;
 
 void mz_finalize(void)
 {
@@ -135,6 +138,7 @@ void mz_finalize(void)
     if (G.h_res.p) { hipHostFree(G.h_res.p); G.h_res.p = NULL; G.h_res.cap = 0; }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
+    for (i = 0; i < MZ_WS_MAX; ++i) if (g_ws[i].used) { hipEventDestroy(g_ws[i].done); g_ws[i].used = 0; }
     hipStreamSynchronize(G.stream2);
     hipStreamDestroy(G.stream2);
     hipStreamSynchronize(G.stream3);
@@ -269,7 +273,7 @@ size_t mz_dev_plan_bytes(int n)
     s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
     s += 9 * al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
     s += al256(8 * 8);                     /* totals */
-    s += al256(4 * N) + al256(8 * 6 * (N / 1024 + 2));   /* packList, scanAux */
+    s += al256(4 * N) + al256(8 * 6 * (N / 256 + 2));   /* packList, scanAux */
     s += al256(4 * N) + al256(12 * N);     /* om, final3 */
     return s;
 }
@@ -285,7 +289,7 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N); TAKE(szPrep, int64_t *, 8 * N);
     TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N); TAKE(offPrep, int64_t *, 8 * N);
     TAKE(totals, int64_t *, 64);
-    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 6 * (N / 1024 + 2));
+    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 6 * (N / 256 + 2));
     TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
 #undef TAKE
 }
@@ -337,23 +341,38 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
     return 0;
 }
 
-/* Pipelined form for a stream of batches.  The DP is VALU-bound; the traceback walk is a latency-bound
- * pointer chase and the plan a short bandwidth burst, both of which leave the VALUs idle.  So the DPs of
- * successive batches run back to back on `stream`, the plan of batch k+1 runs on a third stream beside the DP
- * of batch k, and walk + emit of batch k on a second stream beside the DP of batch k+1.  Consecutive calls MUST
- * therefore use different workspaces (tbw/script/out and the plan arrays); with two alternating workspaces
- * the library orders "reuse of workspace w" after "walk/emit of the batch that used w last".  The plan does
- * not run on `stream`, so the batch's inputs must be complete when the call is made, or `ready_event` (a
- * hipEvent_t recorded after their producer) must be given.  mz_dev_wait() makes `stream` wait for everything
- * issued so far. */
+/* Pipelined form for a stream of batches.  The DPs of successive batches run back to back on `stream`; plan
+ * and prep of a batch run on a third stream and walk + emit on a second, beside the DPs of the neighbouring
+ * batches (the walk is a latency-bound pointer chase, plan and prep are short bandwidth bursts; the DP is
+ * issue-bound).  Calls in flight at the same time MUST use different workspaces (tbw/script/out/prep and the
+ * plan arrays).  The library keys a workspace by its tbw pointer and orders "reuse of workspace w" after
+ * "walk/emit of the batch that used w last"; with three rotating workspaces the plan of batch k+1 does not
+ * wait for the walk of batch k-1 and everything but the DP is off the critical path.  The plan does not run
+ * on `stream`, so the batch's inputs must be complete when the call is made, or `ready_event` (a hipEvent_t
+ * recorded after their producer) must be given.  mz_dev_wait() makes `stream` wait for everything issued. */
+
 int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
 {
     hipStream_t s;
-    const int slot = G.async_k & 1;
+    int w, slot = -1;
     if (ensure_init() || sync_global_scores()) return -1;
     s = (hipStream_t)pick_stream(stream);
+    for (w = 0; w < MZ_WS_MAX; ++w) if (g_ws[w].used && g_ws[w].key == (const void *)b->tbw) slot = w;
+    if (slot < 0) {
+        for (w = 0; w < MZ_WS_MAX; ++w) if (!g_ws[w].used) { slot = w; break; }
+        if (slot < 0) {                                   /* table full: forget the oldest entry once it is idle */
+            slot = g_ws_victim;
+            g_ws_victim = (g_ws_victim + 1) % MZ_WS_MAX;
+            HIPCK(hipEventSynchronize(g_ws[slot].done));
+        } else {
+            HIPCK(hipEventCreateWithFlags(&g_ws[slot].done, hipEventDisableTiming));
+        }
+        g_ws[slot].key = (const void *)b->tbw;
+        g_ws[slot].used = 1;
+    } else {
+        HIPCK(hipStreamWaitEvent(G.stream3, g_ws[slot].done, 0));      /* its previous batch has been walked and emitted */
+    }
     if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
-    if (G.async_k >= 2) HIPCK(hipStreamWaitEvent(G.stream3, G.evs[slot], 0));   /* workspace of batch k-2 is free */
     if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.evs[3], G.stream3));
     HIPCK(hipStreamWaitEvent(s, G.evs[3], 0));
@@ -361,18 +380,18 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     HIPCK(hipEventRecord(G.evs[2], s));
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
     if (mzk_walk(b, G.stream2) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
-    HIPCK(hipEventRecord(G.evs[slot], G.stream2));
-    G.async_k++;
+    HIPCK(hipEventRecord(g_ws[slot].done, G.stream2));
     return 0;
 }
 
 int mz_dev_wait(void *stream)
 {
     hipStream_t s;
+    int w;
     if (ensure_init()) return -1;
     s = (hipStream_t)pick_stream(stream);
-    if (G.async_k >= 1) HIPCK(hipStreamWaitEvent(s, G.evs[(G.async_k - 1) & 1], 0));
-    if (G.async_k >= 2) HIPCK(hipStreamWaitEvent(s, G.evs[G.async_k & 1], 0));
+    for (w = 0; w < MZ_WS_MAX; ++w)
+        if (g_ws[w].used) HIPCK(hipStreamWaitEvent(s, g_ws[w].done, 0));
     return 0;
 }
 

@@ -173,7 +173,7 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
         assert np.array_equal(bot[~(bot == 45).all(axis=1)], B)
 
 
-def test_pipelined_batches_two_workspaces(mz):
+def test_pipelined_batches_rotating_workspaces(mz):
     # mz_dev_run_async(): walk + emit of batch k overlap plan + DP of batch k+1 on a second stream; two
     # alternating workspaces.  After mz_dev_wait() both must hold exactly what the serial form produces.
     from multiz_amd import synth
@@ -185,11 +185,14 @@ def test_pipelined_batches_two_workspaces(mz):
     want = ref.out.cpu().numpy().copy()
     a = mz.DevBatch(batch)
     b = a.alternate()
-    for k in range(7):
+    c3 = a.alternate()
+    for k in range(7):                                   # two alternating workspaces ...
         (a if k % 2 == 0 else b).run_async()
+    for k in range(7):                                   # ... then three rotating ones
+        (a, b, c3)[k % 3].run_async()
     a.wait()
     width = batch["K"].astype(np.int64) + batch["L"]
-    for w in (a, b):
+    for w in (a, b, c3):
         r = w.results()
         assert np.array_equal(r["status"], r0["status"]) and np.array_equal(r["om"], r0["om"])
         assert np.array_equal(r["final3"], r0["final3"]) and np.array_equal(r["offOut"], r0["offOut"])
