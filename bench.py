@@ -30,7 +30,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # HBM bytes of one k_dp_fast launch on the default c2 batch from the PMC passes in profiles/
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 note in
 # MI355X_MICROARCH.md section HBM).  Measured, never estimated; valid for the default c2 batch only.
-TRAFFIC_BYTES_PER_LAUNCH = (2 * 344210 + 4709740) * 1024   # profiles/r1b_pmc_summary.txt (tagged kernel, c2 batch)
+# k_dp_row on the c2 batch, profiles/r1d_pmc_summary.txt: FETCH_SIZE 4 079 862 KB (scalar-load lines exact, the
+# 1.80 GB of coalesced column-record loads counted at one half: +0.90 GB) + WRITE_SIZE 2 438 456 KB
+TRAFFIC_BYTES_PER_LAUNCH = 4079862 * 1024 + 900_000_000 + 2438456 * 1024
 
 
 def algorithmic_bytes(batch, om):
@@ -143,10 +145,10 @@ def main():
                    "pairs_total": all_pairs, "band_cells_total": all_cells, "parallelism": f"pairs sharded x{world}"},
         "kernel_ms": {"plan": round(kern_ms[0] / args.steps, 3), "dp": round(dp_ms, 3),
                       "walk": round(kern_ms[2] / args.steps, 3), "emit": round(kern_ms[3] / args.steps, 3)},
-        # dominant kernel: k_dp (the DP; one launch per step).  achieved = algorithmic bytes of the
+        # dominant kernel: k_dp_row (the DP; one launch per step).  achieved = algorithmic bytes of the
         # batch / its HIP-event time.  The kernel is VALU-issue bound, not HBM bound:
         # measured traffic (profiles/, separate --pmc passes) stays under 1 TB/s.
-        "roofline": {"bound": "hbm", "kernel": "k_dp", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_dp_row", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(roof_achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and pairs == 50000) else None,
                      "bytes_per_cell": round(total_bytes / cells, 4), "algorithmic_bytes": total_bytes,
                      "dp_kernel_gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1)},
