@@ -28,13 +28,13 @@
 #define WAVE   64
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
-// row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then
-// column records of columns 0 .. ROW_NCOLS(N)-1
+// row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then (COL
+// mode) the transposed band bounds
 #define RREC 16             // dwords per row record in b.prep
 #define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI+P P Q
 #define ROW_NROWS(M) ((M) + 2)
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
-#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + (long long)RCOL * ROW_NCOLS(N) + 2LL * ((M) + 1))
+#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + 2LL * ((M) + 1))
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; int row_on; };
 __constant__ ScoreConst c_sc;
@@ -1250,15 +1250,12 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
     const int K = COL ? b.L[p] : b.K[p], L = COL ? b.K[p] : b.L[p];
     const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];
     const uint8_t *A = COL ? b.poolB + b.offB[p] : b.poolA + b.offA[p];
-    const uint8_t *B = COL ? b.poolA + b.offA[p] : b.poolB + b.offB[p];
     const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
-    const int TI = COL ? 0 : 1;
     int4 *rows = (int4 *)(b.prep + b.offPrep[p]);
-    int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
-    const int go = c_sc.go, ge = c_sc.ge, g2 = 2 * c_sc.g2;
+    const int go = c_sc.go, ge = c_sc.ge;
     // COL: the band column by column -- tlo[c] = first row with RB[r] >= c, thi[c] = last row with LB[r] <= c,
     // scattered from the rows (both arrays are monotone, so the work is M + N) into the tail of the prep slice
-    int *tlo = (int *)(cols + (RCOL / 4) * ROW_NCOLS(N)), *thi = tlo + (M + 1);
+    int *tlo = (int *)(rows + (RREC / 4) * ROW_NROWS(M)), *thi = tlo + (M + 1);
     if (COL) {
         for (int r = lane; r <= N; r += WAVE) {        // N = the reference's M: rows of the band arrays
             const int c1 = RB[r], c0 = r > 0 ? RB[r - 1] + 1 : 0;
@@ -1326,50 +1323,6 @@ __device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int l
         __syncthreads();
     }
 
-    int carryP = 0, carryQ = 0;
-    for (int cc = lane; cc < ROW_NCOLS(N); cc += WAVE) {
-        int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * go * K * L - TI, eP = 0, eQ = 0;
-        if (cc >= 1 && cc <= N) {
-            const uint8_t *col = B + (long long)(cc - 1) * L;
-            unsigned cnt = 0;
-            int dB = 0, b00 = 0, b11 = 0, other = 0;
-            for (int j = 0; j < L; ++j) {
-                const unsigned ch = col[j];
-                const bool dash = ch == '-';
-                const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
-                const int cl = byte_class(ch);
-                cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
-                other += cl == 5;
-                dB += dash;
-                b00 += (!dash) & (!pdash);
-                b11 += dash & pdash;
-            }
-            const int nB = L - dB;
-            e0 = pack2(-g2 * dB, -g2 * b00);
-            e1 = pack2(-g2 * b11, 0);
-            e2 = pack2(2 * (cnt & 0xff), 2 * ((cnt >> 8) & 0xff));
-            e3 = pack2(2 * ((cnt >> 16) & 0xff), 2 * (cnt >> 24));
-            e4 = pack2(2 * dB, 2 * other);
-            e5 += 4 * ge * K * nB;
-            eP = -4 * K * (go * (nB - b00) + ge * nB);
-            eQ = -4 * K * ge * nB;
-        }
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const int y = __shfl_up(eP, o), z = __shfl_up(eQ, o);
-            if (lane >= o) { eP += y; eQ += z; }
-        }
-        eP += carryP; eQ += carryQ;
-        carryP = __builtin_amdgcn_readlane(eP, WAVE - 1);
-        carryQ = __builtin_amdgcn_readlane(eQ, WAVE - 1);
-        s_out[2 * lane] = make_int4(e0, e1, e2, e3);
-        s_out[2 * lane + 1] = make_int4(e4, e5 + eP, eP, eQ);      // xI + P, P, Q
-        __syncthreads();
-        int4 *g = cols + 2 * (cc - lane);
-        g[lane] = s_out[lane];
-        g[WAVE + lane] = s_out[WAVE + lane];
-        __syncthreads();
-    }
 }
 
 __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
@@ -1447,13 +1400,50 @@ struct RowState {
     unsigned wC, wD, wI;
 };
 
-// copy 64 column records into the LDS ring
-__device__ __forceinline__ void row_stage_cols(int first, int lane, const int4 *cols, int4 *ring)
+// Column records of columns first .. first+63 into the LDS ring, built from the raw bytes of B (column vectors,
+// class counts, and the running sums P, Q of the max-plus recurrence, carried from chunk to chunk): ~100
+// instructions per 64 columns, cheaper than a round trip of 32 bytes per column through HBM.
+struct ColSrc { const uint8_t *B; int L, N, K4go, K4ge, g2, xI0, carryP, carryQ; };   // K4go = 4*K*go, xI0 = 4*go*K*L - TI
+__device__ __forceinline__ void row_stage_cols(int first, int lane, ColSrc &Z, int4 *ring)
 {
     const int cc = first + lane;
-    const int4 x = cols[2 * cc], y = cols[2 * cc + 1];
-    ring[2 * (cc & (FRING - 1))] = x;
-    ring[2 * (cc & (FRING - 1)) + 1] = y;
+    int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = Z.xI0, eP = 0, eQ = 0;
+    if (cc >= 1 && cc <= Z.N) {
+        const int L = Z.L;
+        const uint8_t *col = Z.B + (long long)(cc - 1) * L;
+        unsigned cnt = 0;
+        int dB = 0, b00 = 0, b11 = 0, other = 0;
+        for (int j = 0; j < L; ++j) {
+            const unsigned ch = col[j];
+            const bool dash = ch == '-';
+            const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
+            const int cl = byte_class(ch);
+            cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+            other += cl == 5;
+            dB += dash;
+            b00 += (!dash) & (!pdash);
+            b11 += dash & pdash;
+        }
+        const int nB = L - dB;
+        e0 = pack2(-Z.g2 * dB, -Z.g2 * b00);
+        e1 = pack2(-Z.g2 * b11, 0);
+        e2 = pack2(2 * (cnt & 0xff), 2 * ((cnt >> 8) & 0xff));
+        e3 = pack2(2 * ((cnt >> 16) & 0xff), 2 * (cnt >> 24));
+        e4 = pack2(2 * dB, 2 * other);
+        e5 += Z.K4ge * nB;
+        eP = -(Z.K4go * (nB - b00) + Z.K4ge * nB);
+        eQ = -Z.K4ge * nB;
+    }
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int y = __shfl_up(eP, o), z = __shfl_up(eQ, o);
+        if (lane >= o) { eP += y; eQ += z; }
+    }
+    eP += Z.carryP; eQ += Z.carryQ;
+    Z.carryP = __builtin_amdgcn_readlane(eP, WAVE - 1);
+    Z.carryQ = __builtin_amdgcn_readlane(eQ, WAVE - 1);
+    ring[2 * (cc & (FRING - 1))] = make_int4(e0, e1, e2, e3);
+    ring[2 * (cc & (FRING - 1)) + 1] = make_int4(e4, e5 + eP, eP, eQ);      // xI + P, P, Q
 }
 
 // column data of column c32/32 from the ring; lo32 = 32*LB of the row about to be computed
@@ -1579,7 +1569,7 @@ struct RowLoop { int next32; };                        // 32 * first column of t
 // bookkeeping before a row (record R), one scalar compare per row: when the band's left edge enters the next
 // 64-column period, stage the period after it (the ring then holds this period and the next: everything a
 // re-arming lane can ask for) and re-lift (every lane is in the lower period again)
-__device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, const int4 *cols, int4 *s_ring)
+__device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, ColSrc &cols, int4 *s_ring)
 {
     if (R_lo32(R) >= Q.next32) {
         asm volatile("; next 64-column period (keep this a branch)");
@@ -1602,7 +1592,7 @@ __device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int 
 // row is computed and waited for after it
 template <bool EDGE, bool COL>
 __device__ __forceinline__ void row_rows_single(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
-                                                const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
+                                                const int4 *rows, ColSrc &cols, int4 *s_ring, uint32_t *tbw)
 {
     r0 = __builtin_amdgcn_readfirstlane(r0);
     r1 = __builtin_amdgcn_readfirstlane(r1);
@@ -1630,7 +1620,7 @@ __device__ __forceinline__ void row_rows_single(RowState &S, RowLoop &Q, int r0,
 // copies registers whose load is still in flight.
 template <bool COL>
 __device__ __forceinline__ void row_rows_interior(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
-                                                  const int4 *rows, const int4 *cols, int4 *s_ring, uint32_t *tbw)
+                                                  const int4 *rows, ColSrc &cols, int4 *s_ring, uint32_t *tbw)
 {
     r0 = __builtin_amdgcn_readfirstlane(r0);
     r1 = __builtin_amdgcn_readfirstlane(r1);
@@ -1675,7 +1665,10 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
     J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N32 = 32 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
     J.rIy = pack2(-J.K * 2 * c_sc.g1, 0); J.rIz = pack2(-J.K * 2 * c_sc.g1, -J.K * 2 * c_sc.g1);
     const int4 *rows = (const int4 *)(b.prep + b.offPrep[p]);
-    const int4 *cols = rows + (RREC / 4) * ROW_NROWS(M);
+    ColSrc cols;
+    cols.B = COL ? b.poolA + b.offA[p] : b.poolB + b.offB[p];
+    cols.L = J.L; cols.N = N; cols.K4go = 4 * J.K * c_sc.go; cols.K4ge = 4 * J.K * c_sc.ge; cols.g2 = 2 * c_sc.g2;
+    cols.xI0 = J.KL4go - TI; cols.carryP = cols.carryQ = 0;
     uint32_t *tbw = b.tbw + b.offTb[p];
     const int rL = b.edgeLo[p], rN = b.edgeHi[p];     // rows <= rL hold column 0/1, rows >= rN column N
 
