@@ -34,7 +34,7 @@
 #define RCOL 8              // dwords per column record: uA uB c01 c23 | c45 xI+P P Q
 #define ROW_NROWS(M) ((M) + 2)
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
-#define ROW_PREP_DWORDS(M, N) ((long long)RREC * ROW_NROWS(M) + 2LL * ((M) + 1))
+#define COL_PREP_DWORDS(N) (2LL * ((N) + 1))           // transposed band bounds of a COL pair
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; int row_on; };
 __constant__ ScoreConst c_sc;
@@ -66,11 +66,11 @@ __device__ __forceinline__ int dot2(int a, int b, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b), acc, false);
 }
 // acc + a.b with the result in a new register (VOP3P form): the compiler's choice, v_dot2c, accumulates
-// in place and costs a v_mov when acc must survive; a is a scalar register
+// in place and costs a v_mov when acc must survive
 __device__ __forceinline__ int dot2_keep(int a, int b, int acc)
 {
     int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(acc));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
     return d;
 }
 // lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                         edgeLo = rL;                            // rows <= rL can hold column 0 or 1
                         edgeHi = rN;                            // rows >= rN hold column N
                         szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
-                        szPrep = ROW_PREP_DWORDS(M, N);
                     } else if (2 * L * (c_sc.maxS + c_sc.go) <= 32767) {
                         // the same kernel on the transposed problem (A and B, D and I exchanged): the band
                         // column by column must be at most 63 rows high
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                             edgeLo = cL;
                             edgeHi = cN;
                             szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
-                            szPrep = ROW_PREP_DWORDS(N, M);
+                            szPrep = COL_PREP_DWORDS(N);
                         }
                     }
                 }
@@ -1242,152 +1241,102 @@ __device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int la
 typedef int int8v __attribute__((ext_vector_type(8)));
 
 
-// COL: the transposed problem -- A and B exchange roles, the band is read column by column, and the I slot
-// of the kernel (which then holds the reference's D state) carries tag 0 instead of 1
-template <bool COL>
-__device__ __forceinline__ void rowprep_body(const mz_dev_batch &b, int p, int lane, int4 *s_out)
-{
-    const int K = COL ? b.L[p] : b.K[p], L = COL ? b.K[p] : b.L[p];
-    const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];
-    const uint8_t *A = COL ? b.poolB + b.offB[p] : b.poolA + b.offA[p];
-    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
-    int4 *rows = (int4 *)(b.prep + b.offPrep[p]);
-    const int go = c_sc.go, ge = c_sc.ge;
-    // COL: the band column by column -- tlo[c] = first row with RB[r] >= c, thi[c] = last row with LB[r] <= c,
-    // scattered from the rows (both arrays are monotone, so the work is M + N) into the tail of the prep slice
-    int *tlo = (int *)(rows + (RREC / 4) * ROW_NROWS(M)), *thi = tlo + (M + 1);
-    if (COL) {
-        for (int r = lane; r <= N; r += WAVE) {        // N = the reference's M: rows of the band arrays
-            const int c1 = RB[r], c0 = r > 0 ? RB[r - 1] + 1 : 0;
-            for (int cc = c0; cc <= c1; ++cc) tlo[cc] = r;
-            const int d0 = LB[r], d1 = r < N ? LB[r + 1] - 1 : M;
-            for (int cc = d0; cc <= d1; ++cc) thi[cc] = r;
-        }
-        __syncthreads();                               // (stores are complete at the L2; the loads below bypass the L1)
-    }
-
-    // records are built one per lane in LDS and copied out linearly, so that every store instruction writes
-    // 1 KB of consecutive bytes
-    const int nrows = ROW_NROWS(M);
-    for (int base = 0; base < nrows; base += WAVE) {
-        const int rr = base + lane + 1;
-        int4 *d = s_out + lane * (RREC / 4);
-        if (rr > M) {
-            d[0] = make_int4(MZ_BIG, 0, 0, 0);
-            d[1] = d[2] = d[3] = make_int4(0, 0, 0, 0);
-        } else {
-            const uint8_t *col = A + (long long)(rr - 1) * K;
-            unsigned cnt = 0;
-            int dA = 0, a00 = 0, a11 = 0, other = 0;
-            for (int i = 0; i < K; ++i) {
-                const unsigned ch = col[i];
-                const bool dash = ch == '-';
-                const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
-                const int cl = byte_class(ch);
-                cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
-                other += cl == 5;
-                dA += dash;
-                a00 += (!dash) & (!pdash);
-                a11 += dash & pdash;
-            }
-            const int nA = K - dA;
-            int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
-            int w[6];
-#pragma unroll
-            for (int l = 0; l < 6; ++l) {
-                int acc = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
-                w[l] = 2 * (acc - go * dA);            // -go*dA per unit count: sums to -go*dA*L over a column
-            }
-            const bool last = rr >= M;
-            // (written by other lanes of this wave above: read past the L1)
-            const int lo = COL ? __hip_atomic_load(tlo + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB[rr];
-            const int hi = COL ? __hip_atomic_load(thi + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RB[rr];
-            // {lo32, wid32, rIx, rCxA | rCxB (= rDx), rCy, rCz, cDe | penDye - cDe, w01, w23, w45 | rIy, rIz, dA nA last, -}
-            const int g1 = 2 * c_sc.g1;
-            const int cDe = 4 * (go + ge) * nA * L;
-            d[0] = make_int4(32 * lo, 32 * (hi - lo), last ? 0 : pack2(-K * g1, -dA * g1), pack2((nA - dA) * g1, -a11 * g1));
-            d[1] = make_int4(pack2(-a00 * g1, 0), pack2((nA - a00 - dA) * g1, 0), pack2((nA - dA) * g1, -dA * g1), cDe);
-            d[2] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA) - cDe, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
-            d[3] = make_int4(last ? 0 : pack2(-K * g1, 0), last ? 0 : pack2(-K * g1, -K * g1), dA | (nA << 8) | ((int)last << 16), 0);
-        }
-        __syncthreads();
-        const int n4 = min(WAVE, nrows - base) * (RREC / 4);
-        int4 *g = rows + (long long)base * (RREC / 4);
-#pragma unroll
-        for (int k = 0; k < RREC / 4; ++k) {
-            const int i = k * WAVE + lane;
-            if (i < n4) g[i] = s_out[i];
-        }
-        __syncthreads();
-    }
-
-}
-
+// COL (the transposed problem): the band column by column -- tlo[c] = first row with RB[r] >= c, thi[c] =
+// last row with LB[r] <= c for c = 0..N, scattered from the rows (both arrays are monotone, so the work is
+// M + N) into the pair's prep slice.  ROW pairs need no prep.
 __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
 {
-    __shared__ int4 s_out[WAVE * (RREC / 4)];
     const int p = first + blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK) return;
-    const int mode = b.mode[p];
-    if (mode == MZ_MODE_ROW)      rowprep_body<false>(b, p, lane, s_out);
-    else if (mode == MZ_MODE_COL) rowprep_body<true>(b, p, lane, s_out);
+    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_COL) return;
+    const int M = b.M[p], N = b.N[p];
+    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    int *tlo = (int *)(b.prep + b.offPrep[p]), *thi = tlo + (N + 1);
+    for (int r = lane; r <= M; r += WAVE) {
+        const int c1 = RB[r], c0 = r > 0 ? RB[r - 1] + 1 : 0;
+        for (int cc = c0; cc <= c1; ++cc) tlo[cc] = r;
+        const int d0 = LB[r], d1 = r < M ? LB[r + 1] - 1 : N;
+        for (int cc = d0; cc <= d1; ++cc) thi[cc] = r;
+    }
 }
 
-// the row record in SGPRs.  (The scalar unit is shared by the four SIMDs of a CU: deriving the vectors from
-// a compact record with ~25 scalar instructions per row made the loop scalar-bound, so the prep pass stores
-// them ready-made.)  16 dwords in memory; interior rows load the first 12, EDGE rows all of them:
-//   a = {lo32, wid32, rIx, rCxA, rCxB (= rDx), rCy, rCz, cDe}   b = {penDye - cDe, w01, w23, w45}
-//   c = {rIy, rIz, dA | nA << 8 | last << 16, -}    (rIy, rIz are pair constants except on the last row)
-typedef int int8v __attribute__((ext_vector_type(8)));
-typedef int int4v __attribute__((ext_vector_type(4)));
-struct RowRec { int8v a; int4v b; int4v c; };
-#define R_lo32(R)   ((R).a[0])      /* 32 * LB[r]: the column counter is kept times 32, the ring byte offset */
-#define R_wid32(R)  ((R).a[1])      /* 32 * (RB[r] - LB[r]) */
-#define R_rIx(R)    ((R).a[2])
-#define R_rCxA(R)   ((R).a[3])
-#define R_rCxB(R)   ((R).a[4])
-#define R_rDx(R)    ((R).a[4])
-#define R_rCy(R)    ((R).a[5])
-#define R_rCz(R)    ((R).a[6])
-#define R_cDe(R)    ((R).a[7])
-#define R_dDy(R)    ((R).b[0])      /* penDye - cDe */
-#define R_w01(R)    ((R).b[1])
-#define R_w23(R)    ((R).b[2])
-#define R_w45(R)    ((R).b[3])
-#define R_dA(R)     ((R).c[2] & 0xff)
-#define R_nA(R)     (((R).c[2] >> 8) & 0xff)
-#define R_last(R)   ((R).c[2] >> 16)
+// The row record: 16 dwords, built for 64 rows at a time by the 64 lanes (row_stage_rows) in LDS and read back
+// by every lane of the wave (broadcast reads) one row ahead of its use; interior rows read 12 dwords.
+//   a = {lo32, wid32, rIx, rCxA}  b = {rCxB (= rDx), rCy, rCz, cDe}  c = {penDye - cDe, w01, w23, w45}
+//   d = {rIy, rIz, dA | nA << 8 | last << 16, -}    (rIy, rIz are pair constants except on the last row)
+// History: the records were first read with scalar loads from a prep pass in HBM (SGPR operands, no LDS).  That
+// made the loop wait ~0.8 us per scalar-cache miss, cost a 3 GB prep kernel per batch competing with the DP, and
+// -- with compact records derived by scalar code -- saturated the CU's shared scalar unit.
+struct RowRec { int4 a, b, c, d; };
+#define R_lo32(R)   ((R).a.x)       /* 32 * LB[r]: the column counter is kept times 32, the ring byte offset */
+#define R_wid32(R)  ((R).a.y)       /* 32 * (RB[r] - LB[r]) */
+#define R_rIx(R)    ((R).a.z)
+#define R_rCxA(R)   ((R).a.w)
+#define R_rCxB(R)   ((R).b.x)
+#define R_rDx(R)    ((R).b.x)
+#define R_rCy(R)    ((R).b.y)
+#define R_rCz(R)    ((R).b.z)
+#define R_cDe(R)    ((R).b.w)
+#define R_dDy(R)    ((R).c.x)       /* penDye - cDe */
+#define R_w01(R)    ((R).c.y)
+#define R_w23(R)    ((R).c.z)
+#define R_w45(R)    ((R).c.w)
+#define R_dA(R)     ((R).d.z & 0xff)
+#define R_nA(R)     (((R).d.z >> 8) & 0xff)
+#define R_last(R)   ((R).d.z >> 16)
 
-// a uniform 64-bit value in scalar registers (the compiler keeps what it loaded with vector loads in VGPRs)
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+struct RowSrc { const uint8_t *A; const int *lo, *hi; int K, L, M, go, ge, g1; };   // lo/hi: band of row r (ROW: LB/RB; COL: tlo/thi)
+
+// records of rows blk*64+1 .. blk*64+64 (dead beyond M) into s_rec[lane]
+__device__ __forceinline__ void row_stage_rows(int blk, int lane, const RowSrc &Z, int4 *s_rec)
 {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
+    const int rr = blk * WAVE + lane + 1;
+    int4 *d = s_rec + lane * (RREC / 4);
+    if (rr > Z.M) {
+        d[0] = make_int4(MZ_BIG, 0, 0, 0);
+        d[1] = d[2] = d[3] = make_int4(0, 0, 0, 0);
+        return;
+    }
+    const int K = Z.K, L = Z.L, go = Z.go, ge = Z.ge, g1 = Z.g1;
+    const uint8_t *col = Z.A + (long long)(rr - 1) * K;
+    unsigned cnt = 0;
+    int dA = 0, a00 = 0, a11 = 0, other = 0;
+    for (int i = 0; i < K; ++i) {
+        const unsigned ch = col[i];
+        const bool dash = ch == '-';
+        const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
+        const int cl = byte_class(ch);
+        cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+        other += cl == 5;
+        dA += dash;
+        a00 += (!dash) & (!pdash);
+        a11 += dash & pdash;
+    }
+    const int nA = K - dA;
+    int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
+    int w[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
+        w[l] = 2 * (acc - go * dA);                    // -go*dA per unit count: sums to -go*dA*L over a column
+    }
+    const bool last = rr >= Z.M;
+    const int lo = Z.lo[rr], hi = Z.hi[rr];
+    const int cDe = 4 * (go + ge) * nA * L;
+    d[0] = make_int4(32 * lo, 32 * (hi - lo), last ? 0 : pack2(-K * g1, -dA * g1), pack2((nA - dA) * g1, -a11 * g1));
+    d[1] = make_int4(pack2(-a00 * g1, 0), pack2((nA - a00 - dA) * g1, 0), pack2((nA - dA) * g1, -dA * g1), cDe);
+    d[2] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA) - cDe, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
+    d[3] = make_int4(last ? 0 : pack2(-K * g1, 0), last ? 0 : pack2(-K * g1, -K * g1), dA | (nA << 8) | ((int)last << 16), 0);
 }
 
-// scalar loads return out of order, so the only wait is "all of them": records are requested in batches and
-// a batch is waited for as a whole (row_rec_wait*)
-template <bool FULL, int OFF>
-__device__ __forceinline__ void row_rec_issue(RowRec &R, unsigned long long rp)
-{
-    if (FULL)
-        asm volatile("s_load_dwordx8 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx4 %2, %3, %6"
-                     : "=&s"(R.a), "=&s"(R.b), "=&s"(R.c) : "s"(rp), "n"(OFF), "n"(OFF + 32), "n"(OFF + 48) : "memory");
-    else
-        asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx4 %1, %2, %4"
-                     : "=&s"(R.a), "=&s"(R.b) : "s"(rp), "n"(OFF), "n"(OFF + 32) : "memory");
-}
+// the record of row r from the staged block (every lane reads the same address: LDS broadcast)
 template <bool FULL>
-__device__ __forceinline__ void row_rec_wait(RowRec &R)
+__device__ __forceinline__ void row_rec_read(RowRec &R, const int4 *s_rec, int r)
 {
-    if (FULL) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(R.c) : : "memory");
-    else      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b) : : "memory");
-}
-__device__ __forceinline__ void row_rec_wait2(RowRec &R, RowRec &T)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(T.a), "+s"(T.b) : : "memory");
+    const int4 *s = s_rec + ((r - 1) & (WAVE - 1)) * (RREC / 4);
+    R.a = s[0]; R.b = s[1]; R.c = s[2];
+    if (FULL) R.d = s[3];
 }
 
 struct RowState {
@@ -1538,7 +1487,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     // Lanes right of the band need no masking here: they come last in ring order.
     const int lC = ror1(nC), lD = ror1(nD);
     x = dot2_keep(R_rIx(R), uA, lC);                   // lC, lD, lI stay live: they are row r+1's diagonal
-    y = dot2_keep(EDGE ? R.c[0] : J.rIy, uA, lD);
+    y = dot2_keep(EDGE ? R.d.x : J.rIy, uA, lD);
     const int base = max(x, y);
     int g, Pl;
     if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
@@ -1554,7 +1503,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
     nI = active ? g + Pl : NEGT + TI;
     const int lI = ror1(nI);
-    z = dot2_keep(EDGE ? R.c[1] : J.rIz, uA, lI);
+    z = dot2_keep(EDGE ? R.d.y : J.rIz, uA, lI);
     mI = max(base, z);
 
     S.p.C = nC; S.p.D = nD; S.p.I = nI;
@@ -1571,7 +1520,7 @@ struct RowLoop { int next32; };                        // 32 * first column of t
 // re-arming lane can ask for) and re-lift (every lane is in the lower period again)
 __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, ColSrc &cols, int4 *s_ring)
 {
-    if (R_lo32(R) >= Q.next32) {
+    if (__builtin_amdgcn_readfirstlane(R_lo32(R)) >= Q.next32) {
         asm volatile("; next 64-column period (keep this a branch)");
         row_stage_cols((Q.next32 >> 5) + WAVE, lane, cols, s_ring);
         __syncthreads();
@@ -1588,83 +1537,64 @@ __device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int 
     o[0] = S.wC; o[WAVE] = S.wD; o[2 * WAVE] = S.wI;
 }
 
-// one row at a time (EDGE rows, and the ends of the interior range): the next record is requested before the
-// row is computed and waited for after it
+// rows r0..r1 of one phase, block of 64 staged rows by block; within a block two rows per iteration so that
+// the record registers alternate (the next row's record is read from LDS while the current row is computed).
+// Pairs start on even rows, so only the second row of a pair can close a 16-row traceback group.
 template <bool EDGE, bool COL>
-__device__ __forceinline__ void row_rows_single(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
-                                                const int4 *rows, ColSrc &cols, int4 *s_ring, uint32_t *tbw)
+__device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
+                                         const RowSrc &src, ColSrc &cols, int4 *s_rec, int4 *s_ring, uint32_t *tbw)
 {
     r0 = __builtin_amdgcn_readfirstlane(r0);
     r1 = __builtin_amdgcn_readfirstlane(r1);
-    if (r0 > r1) return;
-    RowRec Ra, Rb;
-    unsigned long long rp = uniform64((unsigned long long)rows + (unsigned long long)(r0 - 1) * (4 * RREC));
-    row_rec_issue<EDGE, 0>(Ra, rp);
-    row_rec_wait<EDGE>(Ra);
-    for (int r = r0; r <= r1; ++r) {
-        row_rec_issue<EDGE, 4 * RREC>(Rb, rp);
-        row_pre(S, Q, Ra, lane, cols, s_ring);
-        row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
-        if ((r & 15) == 15) row_store(S, tbw, r, lane);
-        row_rec_wait<EDGE>(Rb);
-        Ra = Rb;
-        rp += 4 * RREC;
-    }
-}
-
-// interior rows r0..r1.  A record takes about as long to arrive from HBM as eight waves take to compute a
-// row, so records are requested TWO rows ahead, in batches of two (scalar loads return out of order: the only
-// wait is for all of them).  Four rows per iteration, starting on a multiple of four, so that the record
-// registers alternate instead of being copied and only the fourth row can close a 16-row traceback group.
-// A record is complete (requested AND waited for) whenever it crosses a loop edge, so the compiler never
-// copies registers whose load is still in flight.
-template <bool COL>
-__device__ __forceinline__ void row_rows_interior(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
-                                                  const int4 *rows, ColSrc &cols, int4 *s_ring, uint32_t *tbw)
-{
-    r0 = __builtin_amdgcn_readfirstlane(r0);
-    r1 = __builtin_amdgcn_readfirstlane(r1);
-    if (r0 > r1) return;
-    const int ra = min((r0 + 3) & ~3, r1 + 1);         // first multiple of four
-    row_rows_single<false, COL>(S, Q, r0, ra - 1, lane, J, rows, cols, s_ring, tbw);
-    int r = ra;
-    if (r + 3 <= r1) {
-        RowRec A0, A1, B0, B1;
-        unsigned long long rp = uniform64((unsigned long long)rows + (unsigned long long)(r - 1) * (4 * RREC));
-        row_rec_issue<false, 0>(A0, rp);
-        row_rec_issue<false, 4 * RREC>(A1, rp);
-        row_rec_wait2(A0, A1);
-        for (; r + 3 <= r1; r += 4) {
-            row_rec_issue<false, 8 * RREC>(B0, rp);
-            row_rec_issue<false, 12 * RREC>(B1, rp);
-            row_pre(S, Q, A0, lane, cols, s_ring);
-            row_step<false, COL>(S, A0, r, J, s_ring, tbw, lane);
-            row_pre(S, Q, A1, lane, cols, s_ring);
-            row_step<false, COL>(S, A1, r + 1, J, s_ring, tbw, lane);
-            row_rec_wait2(B0, B1);
-            row_rec_issue<false, 16 * RREC>(A0, rp);
-            row_rec_issue<false, 20 * RREC>(A1, rp);
-            row_pre(S, Q, B0, lane, cols, s_ring);
-            row_step<false, COL>(S, B0, r + 2, J, s_ring, tbw, lane);
-            row_pre(S, Q, B1, lane, cols, s_ring);
-            row_step<false, COL>(S, B1, r + 3, J, s_ring, tbw, lane);
-            if (((r + 3) & 15) == 15) row_store(S, tbw, r + 3, lane);
-            row_rec_wait2(A0, A1);
-            rp += 16 * RREC;
+    for (int r = r0; r <= r1; ) {
+        if (((r - 1) & (WAVE - 1)) == 0 && r > 1) {    // first row of a block: every record of the block before is consumed
+            __syncthreads();
+            row_stage_rows((r - 1) >> 6, lane, src, s_rec);
+            __syncthreads();
+        }
+        const int last = min(r1, ((r - 1) | (WAVE - 1)) + 1);       // last row of this block within [r0, r1]
+        RowRec Ra, Rb;
+        row_rec_read<EDGE>(Ra, s_rec, r);
+        if (r & 1) {                                   // odd first row on its own
+            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            if ((r & 15) == 15) row_store(S, tbw, r, lane);
+            ++r;
+            if (r > last) continue;
+            row_rec_read<EDGE>(Ra, s_rec, r);
+        }
+        for (; r + 1 <= last; r += 2) {
+            row_rec_read<EDGE>(Rb, s_rec, r + 1);
+            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            if (r + 2 <= last) row_rec_read<EDGE>(Ra, s_rec, r + 2);
+            row_pre(S, Q, Rb, lane, cols, s_ring);
+            row_step<EDGE, COL>(S, Rb, r + 1, J, s_ring, tbw, lane);
+            if (((r + 1) & 15) == 15) row_store(S, tbw, r + 1, lane);
+        }
+        if (r <= last) {
+            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            if ((r & 15) == 15) row_store(S, tbw, r, lane);
+            ++r;
         }
     }
-    row_rows_single<false, COL>(S, Q, r, r1, lane, J, rows, cols, s_ring, tbw);
 }
 
 template <bool COL>
-__device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int lane, int4 *s_ring)
+__device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int lane, int4 *s_rec, int4 *s_ring)
 {
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
     const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];      // rows / columns of this run
     RowCtx J;
     J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N32 = 32 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
     J.rIy = pack2(-J.K * 2 * c_sc.g1, 0); J.rIz = pack2(-J.K * 2 * c_sc.g1, -J.K * 2 * c_sc.g1);
-    const int4 *rows = (const int4 *)(b.prep + b.offPrep[p]);
+    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    RowSrc src;
+    src.A = COL ? b.poolB + b.offB[p] : b.poolA + b.offA[p];
+    src.lo = COL ? (const int *)(b.prep + b.offPrep[p]) : LB;
+    src.hi = COL ? src.lo + (M + 1) : RB;              // (COL: M is the reference's N)
+    src.K = J.K; src.L = J.L; src.M = M; src.go = c_sc.go; src.ge = c_sc.ge; src.g1 = 2 * c_sc.g1;
     ColSrc cols;
     cols.B = COL ? b.poolA + b.offA[p] : b.poolB + b.offB[p];
     cols.L = J.L; cols.N = N; cols.K4go = 4 * J.K * c_sc.go; cols.K4ge = 4 * J.K * c_sc.ge; cols.g2 = 2 * c_sc.g2;
@@ -1676,13 +1606,13 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
     Q.next32 = 32 * WAVE;
     row_stage_cols(0, lane, cols, s_ring);
     row_stage_cols(WAVE, lane, cols, s_ring);
+    row_stage_rows(0, lane, src, s_rec);
     __syncthreads();
 
     // row 0 in closed form (mz_yama.c:83-94): C = D = NEG beyond (0,0); I(0,c) = -ge*K*(nB_1+..+nB_c)
     RowState S;
     S.c32 = 32 * lane;
     row_load_col(S, s_ring, 0);
-    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
     const int rb0 = COL ? t_hi(LB, N, 0) : RB[0];
     S.p.C = lane == 0 ? 2 : NEGT + 2;
     S.p.D = lane == 0 ? TD : NEGT + TD;
@@ -1692,9 +1622,9 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 
     // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge (transposed: row 1 is always an edge row)
     const int e1 = min(max(rL, COL ? 1 : 0), M), e2 = max(rN, e1 + 1);
-    row_rows_single<true, COL>(S, Q, 1, e1, lane, J, rows, cols, s_ring, tbw);
-    row_rows_interior<COL>(S, Q, e1 + 1, e2 - 1, lane, J, rows, cols, s_ring, tbw);
-    row_rows_single<true, COL>(S, Q, e2, M, lane, J, rows, cols, s_ring, tbw);
+    row_rows<true, COL>(S, Q, 1, e1, lane, J, src, cols, s_rec, s_ring, tbw);
+    row_rows<false, COL>(S, Q, e1 + 1, e2 - 1, lane, J, src, cols, s_rec, s_ring, tbw);
+    row_rows<true, COL>(S, Q, e2, M, lane, J, src, cols, s_rec, s_ring, tbw);
 
     if ((M & 15) != 15) {                              // flush the partial group
         const int sh = 2 * (15 - (M & 15));
@@ -1710,12 +1640,13 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 
 __global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int count)
 {
-    __shared__ int4 s_ring[2 * FRING];                 // 4 KB
+    __shared__ int4 s_ring[2 * FRING];                 // 4 KB: column records, 128-entry ring
+    __shared__ int4 s_rec[WAVE * (RREC / 4)];          // 4 KB: row records of the current block of 64 rows
     const int p = first + blockIdx.x, lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int mode = b.mode[p];
-    if (mode == MZ_MODE_ROW)      dp_row_body<false>(b, p, lane, s_ring);
-    else if (mode == MZ_MODE_COL) dp_row_body<true>(b, p, lane, s_ring);
+    if (mode == MZ_MODE_ROW)      dp_row_body<false>(b, p, lane, s_rec, s_ring);
+    else if (mode == MZ_MODE_COL) dp_row_body<true>(b, p, lane, s_rec, s_ring);
 }
 
 // ------------------------------------------------------------------------------------------
