@@ -1342,18 +1342,19 @@ __device__ __forceinline__ void row_rec_read(RowRec &R, const int4 *s_rec, int r
 struct RowState {
     int c32;                      // 32 * the column this lane holds
     int uA, uB, c01, c23, c45;
-    int xIP, P, Q;                // xI + P (EDGE rows recover xI), running sums
-    int xIPl, Pl;                 // xI + P and P, both minus 2^30 while the lane is in the lower ring period
+    int xIPl, Pl;                 // xI + P and P (running sum), both minus 2^30 while the lane is in the lower ring period
+    int Q;                        // running sum for rows 0 and M
     Tri p;                        // row r-1 at this column (tagged), sentinel outside the band
     Tri l;                        // the same, one lane to the left (= ror1(p) before any re-arm)
     unsigned wC, wD, wI;
 };
 
-// Column records of columns first .. first+63 into the LDS ring, built from the raw bytes of B (column vectors,
+// Column records of columns first .. first+63 into the LDS ring (lift = 2^30 if they belong to the ring period the
+// band's left edge is in, see row_pre), built from the raw bytes of B (column vectors,
 // class counts, and the running sums P, Q of the max-plus recurrence, carried from chunk to chunk): ~100
 // instructions per 64 columns, cheaper than a round trip of 32 bytes per column through HBM.
 struct ColSrc { const uint8_t *B; int L, N, K4go, K4ge, g2, xI0, carryP, carryQ; };   // K4go = 4*K*go, xI0 = 4*go*K*L - TI
-__device__ __forceinline__ void row_stage_cols(int first, int lane, ColSrc &Z, int4 *ring)
+__device__ __forceinline__ void row_stage_cols(int first, int lift, int lane, ColSrc &Z, int4 *ring)
 {
     const int cc = first + lane;
     int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = Z.xI0, eP = 0, eQ = 0;
@@ -1392,19 +1393,16 @@ __device__ __forceinline__ void row_stage_cols(int first, int lane, ColSrc &Z, i
     Z.carryP = __builtin_amdgcn_readlane(eP, WAVE - 1);
     Z.carryQ = __builtin_amdgcn_readlane(eQ, WAVE - 1);
     ring[2 * (cc & (FRING - 1))] = make_int4(e0, e1, e2, e3);
-    ring[2 * (cc & (FRING - 1)) + 1] = make_int4(e4, e5 + eP, eP, eQ);      // xI + P, P, Q
+    ring[2 * (cc & (FRING - 1)) + 1] = make_int4(e5 + eP - lift, eP - lift, e4, eQ);   // xI + P, P (both lifted or not), c45, Q
 }
 
-// column data of column c32/32 from the ring; lo32 = 32*LB of the row about to be computed
-__device__ __forceinline__ void row_load_col(RowState &S, const int4 *ring, int lo32)
+// column data of column c32/32 from the ring (its xI+P and P come lifted or not, as the ring holds them now)
+__device__ __forceinline__ void row_load_col(RowState &S, const int4 *ring)
 {
     const int4 *e = (const int4 *)((const char *)ring + (S.c32 & (32 * FRING - 32)));
     const int4 x = e[0], y = e[1];
     S.uA = x.x; S.uB = x.y; S.c01 = x.z; S.c23 = x.w;
-    S.c45 = y.x; S.xIP = y.y; S.P = y.z; S.Q = y.w;
-    const int lift = ((S.c32 ^ lo32) >> 11) == 0 ? ROW_LIFT : 0;  // same 64-column period as the band's left edge
-    S.Pl = S.P - lift;
-    S.xIPl = S.xIP - lift;
+    S.xIPl = y.x; S.Pl = y.y; S.c45 = y.z; S.Q = y.w;
 }
 
 // inclusive prefix maximum over the 64 lanes (lane order)
@@ -1442,7 +1440,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     const bool fresh = S.c32 < R_lo32(R);
     if (fresh) {
         S.c32 += 32 * WAVE;
-        row_load_col(S, s_ring, R_lo32(R));
+        row_load_col(S, s_ring);
     }
     const int c32 = S.c32, uA = S.uA, uB = S.uB;
     const Tri &up = S.p;
@@ -1492,9 +1490,9 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     int g, Pl;
     if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
         const bool last = R_last(R) != 0;
-        const int lift = S.P - S.Pl;
-        Pl = (last ? S.Q : S.P) - lift;
-        g = (base & ~3) - (S.xIP - S.P) + (last ? J.KL4go : 0) - Pl;
+        const int lift = ((c32 ^ R_lo32(R)) >> 11) == 0 ? ROW_LIFT : 0;       // lower ring period
+        Pl = last ? S.Q - lift : S.Pl;
+        g = (base & ~3) - (S.xIPl - S.Pl) + (last ? J.KL4go : 0) - Pl;
     } else {
         Pl = S.Pl;
         g = (base & ~3) - S.xIPl;
@@ -1515,18 +1513,23 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
 
 struct RowLoop { int next32; };                        // 32 * first column of the next 64-column period
 
-// bookkeeping before a row (record R), one scalar compare per row: when the band's left edge enters the next
-// 64-column period, stage the period after it (the ring then holds this period and the next: everything a
-// re-arming lane can ask for) and re-lift (every lane is in the lower period again)
+// bookkeeping before a row (record R), one scalar compare per row.  When the band's left edge enters the next
+// 64-column period k: the ring's copy of period k (still "upper", unlifted) is lifted in place, period k+1 is
+// staged unlifted (the ring then holds k and k+1: everything a re-arming lane can ask for, with the right
+// lift already applied), and the lanes that already hold a column of period k are lifted too.
 __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, ColSrc &cols, int4 *s_ring)
 {
     if (__builtin_amdgcn_readfirstlane(R_lo32(R)) >= Q.next32) {
         asm volatile("; next 64-column period (keep this a branch)");
-        row_stage_cols((Q.next32 >> 5) + WAVE, lane, cols, s_ring);
+        int2 *e = (int2 *)((char *)s_ring + (((Q.next32 >> 5) + lane) & (FRING - 1)) * 32 + 16);
+        int2 v = *e;
+        v.x -= ROW_LIFT; v.y -= ROW_LIFT;
+        *e = v;
+        row_stage_cols((Q.next32 >> 5) + WAVE, 0, lane, cols, s_ring);
         __syncthreads();
         const int lift = ((S.c32 ^ Q.next32) >> 11) == 0 ? ROW_LIFT : 0;
-        S.Pl = S.P - lift;
-        S.xIPl = S.xIP - lift;
+        S.Pl -= lift;
+        S.xIPl -= lift;
         Q.next32 += 32 * WAVE;
     }
 }
@@ -1581,38 +1584,55 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
     }
 }
 
+// a uniform 64-bit value in scalar registers
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 template <bool COL>
 __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int lane, int4 *s_rec, int4 *s_ring)
 {
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
-    const int M = COL ? b.N[p] : b.M[p], N = COL ? b.M[p] : b.N[p];      // rows / columns of this run
+    // everything per-pair is uniform: keep it in scalar registers (values the compiler fetched with vector
+    // loads would otherwise sit in VGPRs and cost occupancy)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+    const int M = UNI(COL ? b.N[p] : b.M[p]), N = UNI(COL ? b.M[p] : b.N[p]);      // rows / columns of this run
+    const int go = c_sc.go, ge = c_sc.ge, g1 = c_sc.g1, g2 = c_sc.g2;
     RowCtx J;
-    J.K = COL ? b.L[p] : b.K[p]; J.L = COL ? b.K[p] : b.L[p]; J.N32 = 32 * N; J.KL4go = 4 * c_sc.go * J.K * J.L;
-    J.rIy = pack2(-J.K * 2 * c_sc.g1, 0); J.rIz = pack2(-J.K * 2 * c_sc.g1, -J.K * 2 * c_sc.g1);
-    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
+    J.K = UNI(COL ? b.L[p] : b.K[p]); J.L = UNI(COL ? b.K[p] : b.L[p]); J.N32 = 32 * N; J.KL4go = 4 * go * J.K * J.L;
+    J.rIy = pack2(-J.K * 2 * g1, 0); J.rIz = pack2(-J.K * 2 * g1, -J.K * 2 * g1);
+    // (offsets made uniform, not pointers: a pointer rebuilt from integers loses its address space and every
+    // access through it becomes a flat_ instruction)
+    const long long oBand = (long long)uniform64((unsigned long long)b.offBand[p]);
+    const int *LB = b.poolLB + oBand, *RB = b.poolRB + oBand;
+    const uint8_t *pA = b.poolA + (long long)uniform64((unsigned long long)b.offA[p]);
+    const uint8_t *pB = b.poolB + (long long)uniform64((unsigned long long)b.offB[p]);
     RowSrc src;
-    src.A = COL ? b.poolB + b.offB[p] : b.poolA + b.offA[p];
-    src.lo = COL ? (const int *)(b.prep + b.offPrep[p]) : LB;
+    src.A = COL ? pB : pA;
+    src.lo = COL ? (const int *)(b.prep + (long long)uniform64((unsigned long long)b.offPrep[p])) : LB;
     src.hi = COL ? src.lo + (M + 1) : RB;              // (COL: M is the reference's N)
-    src.K = J.K; src.L = J.L; src.M = M; src.go = c_sc.go; src.ge = c_sc.ge; src.g1 = 2 * c_sc.g1;
+    src.K = J.K; src.L = J.L; src.M = M; src.go = go; src.ge = ge; src.g1 = 2 * g1;
     ColSrc cols;
-    cols.B = COL ? b.poolA + b.offA[p] : b.poolB + b.offB[p];
-    cols.L = J.L; cols.N = N; cols.K4go = 4 * J.K * c_sc.go; cols.K4ge = 4 * J.K * c_sc.ge; cols.g2 = 2 * c_sc.g2;
+    cols.B = COL ? pA : pB;
+    cols.L = J.L; cols.N = N; cols.K4go = 4 * J.K * go; cols.K4ge = 4 * J.K * ge; cols.g2 = 2 * g2;
     cols.xI0 = J.KL4go - TI; cols.carryP = cols.carryQ = 0;
-    uint32_t *tbw = b.tbw + b.offTb[p];
-    const int rL = b.edgeLo[p], rN = b.edgeHi[p];     // rows <= rL hold column 0/1, rows >= rN column N
+    uint32_t *tbw = b.tbw + (long long)uniform64((unsigned long long)b.offTb[p]);
+    const int rL = UNI(b.edgeLo[p]), rN = UNI(b.edgeHi[p]);   // rows <= rL hold column 0/1, rows >= rN column N
+#undef UNI
 
     RowLoop Q;
     Q.next32 = 32 * WAVE;
-    row_stage_cols(0, lane, cols, s_ring);
-    row_stage_cols(WAVE, lane, cols, s_ring);
+    row_stage_cols(0, ROW_LIFT, lane, cols, s_ring);
+    row_stage_cols(WAVE, 0, lane, cols, s_ring);
     row_stage_rows(0, lane, src, s_rec);
     __syncthreads();
 
     // row 0 in closed form (mz_yama.c:83-94): C = D = NEG beyond (0,0); I(0,c) = -ge*K*(nB_1+..+nB_c)
     RowState S;
     S.c32 = 32 * lane;
-    row_load_col(S, s_ring, 0);
+    row_load_col(S, s_ring);
     const int rb0 = COL ? t_hi(LB, N, 0) : RB[0];
     S.p.C = lane == 0 ? 2 : NEGT + 2;
     S.p.D = lane == 0 ? TD : NEGT + TD;
