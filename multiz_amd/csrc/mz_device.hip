@@ -1511,16 +1511,23 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     S.wI = __builtin_amdgcn_alignbit(mI, S.wI, 2);
 }
 
-struct RowLoop { int next32; };                        // 32 * first column of the next 64-column period
+struct RowLoop { int next32, rcross; };                // 32 * first column of the next 64-column period; first staged row at or beyond it
 
 // bookkeeping before a row (record R), one scalar compare per row.  When the band's left edge enters the next
 // 64-column period k: the ring's copy of period k (still "upper", unlifted) is lifted in place, period k+1 is
 // staged unlifted (the ring then holds k and k+1: everything a re-arming lane can ask for, with the right
 // lift already applied), and the lanes that already hold a column of period k are lifted too.
-__device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R, int lane, ColSrc &cols, int4 *s_ring)
+// first row of the staged block (rows blk*64+1 ..) whose band starts at or beyond column next32/32
+__device__ __forceinline__ int row_find_cross(const int4 *s_rec, int blk, int lane, int next32)
 {
-    if (__builtin_amdgcn_readfirstlane(R_lo32(R)) >= Q.next32) {
-        asm volatile("; next 64-column period (keep this a branch)");
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(s_rec[lane * (RREC / 4)].x >= next32 &&
+                                                             s_rec[lane * (RREC / 4)].x != MZ_BIG);
+    return m ? blk * WAVE + 1 + (int)__builtin_ctzll(m) : MZ_BIG;
+}
+
+__device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, int r, int lane, ColSrc &cols, const int4 *s_rec, int4 *s_ring)
+{
+    if (r == Q.rcross) {                               // scalar compare: the row was located when the block was staged
         int2 *e = (int2 *)((char *)s_ring + (((Q.next32 >> 5) + lane) & (FRING - 1)) * 32 + 16);
         int2 v = *e;
         v.x -= ROW_LIFT; v.y -= ROW_LIFT;
@@ -1531,6 +1538,7 @@ __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, const RowRec &R
         S.Pl -= lift;
         S.xIPl -= lift;
         Q.next32 += 32 * WAVE;
+        Q.rcross = row_find_cross(s_rec, (r - 1) >> 6, lane, Q.next32);
     }
 }
 
@@ -1554,12 +1562,13 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
             __syncthreads();
             row_stage_rows((r - 1) >> 6, lane, src, s_rec);
             __syncthreads();
+            Q.rcross = row_find_cross(s_rec, (r - 1) >> 6, lane, Q.next32);
         }
         const int last = min(r1, ((r - 1) | (WAVE - 1)) + 1);       // last row of this block within [r0, r1]
         RowRec Ra, Rb;
         row_rec_read<EDGE>(Ra, s_rec, r);
         if (r & 1) {                                   // odd first row on its own
-            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
             row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
             if ((r & 15) == 15) row_store(S, tbw, r, lane);
             ++r;
@@ -1568,15 +1577,15 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
         }
         for (; r + 1 <= last; r += 2) {
             row_rec_read<EDGE>(Rb, s_rec, r + 1);
-            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
             row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
             if (r + 2 <= last) row_rec_read<EDGE>(Ra, s_rec, r + 2);
-            row_pre(S, Q, Rb, lane, cols, s_ring);
+            row_pre(S, Q, r + 1, lane, cols, s_rec, s_ring);
             row_step<EDGE, COL>(S, Rb, r + 1, J, s_ring, tbw, lane);
             if (((r + 1) & 15) == 15) row_store(S, tbw, r + 1, lane);
         }
         if (r <= last) {
-            row_pre(S, Q, Ra, lane, cols, s_ring);
+            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
             row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
             if ((r & 15) == 15) row_store(S, tbw, r, lane);
             ++r;
@@ -1628,6 +1637,7 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
     row_stage_cols(WAVE, 0, lane, cols, s_ring);
     row_stage_rows(0, lane, src, s_rec);
     __syncthreads();
+    Q.rcross = row_find_cross(s_rec, 0, lane, Q.next32);
 
     // row 0 in closed form (mz_yama.c:83-94): C = D = NEG beyond (0,0); I(0,c) = -ge*K*(nB_1+..+nB_c)
     RowState S;

@@ -66,3 +66,21 @@ def subset(batch: dict, idx) -> dict:
 
 def band_cells(batch: dict) -> int:
     return int((batch["poolRB"].astype(np.int64) - batch["poolLB"].astype(np.int64) + 1)[: int(batch["offBand"][-1]) + int(batch["M"][-1]) + 1].sum())
+
+
+def pack_pairs(pairs) -> dict:
+    """a batch in the packed-pool layout from a list of (A, B, LB, RB) numpy tuples (A: (M,K) uint8, B: (N,L))"""
+    n = len(pairs)
+    out = {k: np.zeros(n, dtype=np.int32) for k in ("K", "L", "M", "N")}
+    oa, ob, od, pa, pb, plb, prb = [], [], [], [], [], [], []
+    a = b = d = 0
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        out["M"][i], out["K"][i] = A.shape
+        out["N"][i], out["L"][i] = B.shape
+        oa.append(a); ob.append(b); od.append(d)
+        pa.append(np.ascontiguousarray(A, dtype=np.uint8).ravel()); pb.append(np.ascontiguousarray(B, dtype=np.uint8).ravel())
+        plb.append(np.asarray(LB, dtype=np.int32)); prb.append(np.asarray(RB, dtype=np.int32))
+        a += A.size; b += B.size; d += len(LB)
+    out.update(offA=np.array(oa, dtype=np.int64), offB=np.array(ob, dtype=np.int64), offBand=np.array(od, dtype=np.int64),
+               poolA=np.concatenate(pa), poolB=np.concatenate(pb), poolLB=np.concatenate(plb), poolRB=np.concatenate(prb))
+    return out

@@ -173,6 +173,40 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
         assert np.array_equal(bot[~(bot == 45).all(axis=1)], B)
 
 
+def test_every_kernel_family_is_exercised(mz):
+    # mixed shapes through the device-resident API: the plan must send narrow bands to the row-parallel kernel
+    # (mode 5), wide-but-low ones to its transposed form (mode 6), the rest to the wavefront kernels, and every
+    # pair must match the oracle whatever kernel took it.  Band widths sit on the eligibility edges (62 / 63).
+    from multiz_amd import synth
+    rng = np.random.default_rng(77)
+    pairs = []
+    for K, L, M, N, R, band in ((2, 2, 300, 300, 30, "diag"), (3, 1, 200, 260, 30, "diag"), (1, 4, 260, 200, 30, "diag"),
+                                (2, 3, 70, 64, 31, "diag"), (2, 2, 64, 70, 31, "diag"), (4, 4, 150, 150, 12, "wander"),
+                                (2, 2, 150, 230, 25, "wander"), (2, 2, 230, 150, 25, "wander"), (5, 2, 90, 400, 30, "diag"),
+                                (2, 5, 400, 90, 30, "diag"), (2, 2, 500, 500, 60, "diag"), (1, 1, 63, 63, 31, "diag"),
+                                (2, 2, 40, 45, 10, "diag"), (6, 6, 129, 128, 30, "diag")):
+        for _ in range(6):
+            A, B, LB, RB = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth,
+                                            dash=float(rng.choice([0.0, 0.08, 0.3])), odd=float(rng.choice([0.0, 0.05])))
+            if mo.check(M, N, LB, RB)[0] == 0:
+                pairs.append((A, B, LB, RB))
+    batch = synth.pack_pairs(pairs)
+    _kernels(mz, 2)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    hist = np.bincount(res["mode"], minlength=7)
+    assert hist[5] > 0 and hist[6] > 0 and hist[:5].sum() > 0, hist
+    host_out = db.out.cpu().numpy()
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        want = mo.yama(A, B, LB, RB)
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == want.OM, (i, int(res["mode"][i]))
+        got = host_out[o0: o0 + m_ * (A.shape[1] + B.shape[1])].reshape(m_, -1)
+        assert np.array_equal(got, want.cols), (i, int(res["mode"][i]))
+
+
 def test_pipelined_batches_rotating_workspaces(mz):
     # mz_dev_run_async(): walk + emit of batch k overlap plan + DP of batch k+1 on a second stream; two
     # alternating workspaces.  After mz_dev_wait() both must hold exactly what the serial form produces.
