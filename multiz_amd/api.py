@@ -166,6 +166,8 @@ class DevBatch:
         self.script = torch.empty(sc + 64, dtype=torch.uint8, device=self.dev)
         self.out = torch.empty(ou + 64, dtype=torch.uint8, device=self.dev)
         # row records + column records of the row-parallel / packed kernels (k_plan's szPrep, rounded up)
+        # prep: transposed band bounds of the COL pairs (2 ints per column); the opt-in packed kernel wants its
+        # row/column records (20 dwords per padded row + 7 per padded column)
         mx = np.maximum(M, N)
         pr = int(((((mx + 47) // 48) * 48 + 96) * 20 + 8 * (((mx + 127) // 64) * 64 + 128) + 64).sum())
         self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)
