@@ -530,6 +530,17 @@ __attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o)
     }
 }
 
+/* one job, contiguous columns in and out (the staged pre_yama of mz_preyama.c) */
+void mz_py_run_one(mz_job *job, uchar **flat, int *om)
+{
+    mz_out o;
+    int rc = mz_yama_batch(1, job, &o);
+    if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+    if (o.status != MZ_OK) mz_fatal_status(job, &o);
+    *flat = o.cols;
+    *om = o.OM;
+}
+
 void yama(uchar **A, int K, int M, uchar **B, int L, int N, int *LB, int *RB, uchar ***OAL, int *OM)
 {
     mz_job j;

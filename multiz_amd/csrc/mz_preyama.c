@@ -170,99 +170,151 @@ static void bound_note(int *LB, int *RB, int row, int col, int hi_unset)
     if (RB[row] == hi_unset || RB[row] < col) RB[row] = col;
 }
 
-struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int v, FILE *fpw2)
+/* ------------------------------------------------------------------------------------------------
+ * pre_yama() in stages, so that a driver can run the yama() calls of many block pairs as one GPU
+ * batch (mz_multiz.c).  A stage never looks at anything but its own inputs and the
+ * merged columns handed to it, exactly as the reference's straight-line code does
+ * (mz_preyama.c:152-359); pre_yama() below is the three stages with a batch of one in between.
+ * ------------------------------------------------------------------------------------------------ */
+#include "mz_py.h"
+
+static void py_zero(mz_py *p) { memset(p, 0, sizeof *p); }
+
+void mz_py_free(mz_py *p)
+{
+    if (p->A) cols_free(p->A);
+    if (p->B) cols_free(p->B);
+    if (p->merged) cols_free(p->merged);
+    if (p->ref1) cols_free(p->ref1);
+    if (p->ref2) cols_free(p->ref2);
+    if (p->merged2) cols_free(p->merged2);
+    free(p->map1); free(p->map2); free(p->LB); free(p->RB);
+    py_zero(p);
+}
+
+/* wrap the contiguous merged columns of a yama result (malloc'ed, om columns of `rows` bytes) in the
+ * reference's 1-based pointer array */
+static uchar **cols_wrap(uchar *flat, int om, int rows)
+{
+    uchar **X = (uchar **)xmalloc((size_t)(om > 0 ? om : 1) * sizeof(uchar *)) - 1;
+    int i;
+    X[1] = flat;
+    for (i = 2; i <= om; ++i) X[i] = X[i - 1] + rows;
+    return X;
+}
+
+/* stage 1: slice, pack, derive the band.  MZ_PY_NULL: pre_yama() returns NULL (after writing a2's
+ * slice to fpw2 when a1 has nothing left to align, mz_preyama.c:193-196); MZ_PY_JOB: run p->job. */
+int mz_py_begin(mz_py *p, struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int v, FILE *fpw2)
 {
     struct mafComp *c;
-    struct mafAli *result;
-    uchar **A, **B, **merged;
-    int K = 0, L = 0, M, N, M_all, N_all, M_new, i, j, r;
-    int cbeg1, cend1, cbeg2, cend2;
-    int *map1, *map2, *LB, *RB;
+    int K = 0, L = 0, M, N, i, j, r;
+    int cend1;
 
+    py_zero(p);
+    p->a1 = a1; p->a2 = a2; p->radius = radius; p->v = v;
     for (c = a1->components; c; c = c->next) ++K;
     for (c = a2->components->next; c; c = c->next) ++L;     /* a2's top row only guides */
 
-    cbeg1 = mafPos2Col(a1->components, beg, a1->textSize);
+    p->cbeg1 = mafPos2Col(a1->components, beg, a1->textSize);
     cend1 = mafPos2Col(a1->components, end, a1->textSize);
-    cbeg2 = mafPos2Col(a2->components, beg, a2->textSize);
-    cend2 = mafPos2Col(a2->components, end, a2->textSize);
-    M = M_all = cend1 - cbeg1 + 1;
-    N = N_all = cend2 - cbeg2 + 1;
+    p->cbeg2 = mafPos2Col(a2->components, beg, a2->textSize);
+    p->cend2 = mafPos2Col(a2->components, end, a2->textSize);
+    M = p->M_all = cend1 - p->cbeg1 + 1;
+    N = p->N_all = p->cend2 - p->cbeg2 + 1;
 
     /* second block without its reference row, column-major, all-dash columns removed */
-    B = cols_new(N, L);
+    p->B = cols_new(N, L);
     for (i = 1; i <= N; ++i)
         for (r = 0, c = a2->components->next; r < L; ++r, c = c->next)
-            B[i][r] = (uchar)c->text[cbeg2 + i - 1];
-    map2 = rmColDash(B, &N, L);
-    if (N < 1) { cols_free(B); free(map2); return NULL; }
+            p->B[i][r] = (uchar)c->text[p->cbeg2 + i - 1];
+    p->map2 = rmColDash(p->B, &N, L);
+    if (N < 1) { mz_py_free(p); return MZ_PY_NULL; }
 
     if (v == 0) --K;                                          /* a1's reference row is aligned later */
     if (K == 0) {
-        if (fpw2) print_part_ali_col(a2, cbeg2, cend2, fpw2);
-        cols_free(B); free(map2);
-        return NULL;
+        if (fpw2) print_part_ali_col(a2, p->cbeg2, p->cend2, fpw2);
+        mz_py_free(p);
+        return MZ_PY_NULL;
     }
-    A = cols_new(M, K);
+    p->A = cols_new(M, K);
     for (i = 1; i <= M; ++i)
         for (r = 0, c = v == 0 ? a1->components->next : a1->components; r < K; ++r, c = c->next)
-            A[i][r] = (uchar)c->text[cbeg1 + i - 1];
+            p->A[i][r] = (uchar)c->text[p->cbeg1 + i - 1];
     if (v == 0) {
-        map1 = rmColDash(A, &M, K);
-        if (M < 1) { cols_free(A); cols_free(B); free(map1); free(map2); return NULL; }
+        p->map1 = rmColDash(p->A, &M, K);
+        if (M < 1) { mz_py_free(p); return MZ_PY_NULL; }
     } else {
-        map1 = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
-        for (i = 1; i <= M; ++i) map1[i] = i;
+        p->map1 = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+        for (i = 1; i <= M; ++i) p->map1[i] = i;
     }
 
     /* band from the shared reference row: walk both copies of it base by base */
-    LB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
-    RB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
-    for (i = 0; i <= M; ++i) { LB[i] = 0; RB[i] = N; }
-    for (i = cbeg1, j = cbeg2; i <= cend1; ++i, ++j) {
+    p->LB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    p->RB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    for (i = 0; i <= M; ++i) { p->LB[i] = 0; p->RB[i] = N; }
+    for (i = p->cbeg1, j = p->cbeg2; i <= cend1; ++i, ++j) {
         int ra, cb;
         while (a1->components->text[i] == '-') ++i;
         while (a2->components->text[j] == '-') ++j;
-        ra = map1[i - cbeg1 + 1];
-        cb = map2[j - cbeg2 + 1];
-        if (ra != -1 && cb != -1) bound_note(LB, RB, ra, cb, N);
+        ra = p->map1[i - p->cbeg1 + 1];
+        cb = p->map2[j - p->cbeg2 + 1];
+        if (ra != -1 && cb != -1) bound_note(p->LB, p->RB, ra, cb, N);
     }
-    smooth(LB, RB, M, N, radius);
-    yama(A, K, M, B, L, N, LB, RB, &merged, &M_new);
-    free(LB); free(RB);
+    smooth(p->LB, p->RB, M, N, radius);
+    p->K = K; p->L = L; p->M = M; p->N = N;
+    p->stage = 1;
+    p->job.K = K; p->job.L = L; p->job.M = M; p->job.N = N;
+    p->job.A = p->A[1]; p->job.B = p->B[1]; p->job.LB = p->LB; p->job.RB = p->RB;
+    return MZ_PY_JOB;
+}
 
-    if (v == 1) {
-        result = mafBuild(merged, K + L, M_new, a1, cbeg1, a2, cbeg2, 0);
-    } else {
+/* stage 2 / 3: `flat` = the merged columns of p->job (om columns; ownership passes to p).
+ * MZ_PY_DONE: *result is pre_yama()'s return value; MZ_PY_JOB: (v == 0) run p->job once more. */
+int mz_py_step(mz_py *p, uchar *flat, int om, struct mafAli **result)
+{
+    struct mafAli *a1 = p->a1, *a2 = p->a2;
+    const int K = p->K, L = p->L, M = p->M, N = p->N, M_all = p->M_all, N_all = p->N_all;
+    int i;
+
+    if (p->stage == 1 && p->v == 1) {
+        p->merged = cols_wrap(flat, om, K + L);
+        *result = mafBuild(p->merged, K + L, om, a1, p->cbeg1, a2, p->cbeg2, 0);
+        mz_py_free(p);
+        return MZ_PY_DONE;
+    }
+    if (p->stage == 1) {
         /* second stage: align a1's reference row (dashes squeezed out) against the merged block.
          * Its band is the union of two estimates: where a1's other rows went (via map1 o map4a) and
          * where a2's rows went (via map2 o map4b). */
-        uchar **ref1 = cols_new(M_all, 1), **ref2 = cols_new(N_all, 1), **merged2;
         int *m3a, *m4a, *m3b, *m4b, *LBa, *RBa, *LBb, *RBb;
         int M3 = M_all, N3 = N_all;
+        const int M_new = om;
 
-        for (i = 1; i <= M_all; ++i) ref1[i][0] = (uchar)a1->components->text[cbeg1 + i - 1];
-        m3a = rmColDash(ref1, &M3, 1);
+        p->merged = cols_wrap(flat, om, K + L);
+        p->ref1 = cols_new(M_all, 1); p->ref2 = cols_new(N_all, 1);
+        for (i = 1; i <= M_all; ++i) p->ref1[i][0] = (uchar)a1->components->text[p->cbeg1 + i - 1];
+        m3a = rmColDash(p->ref1, &M3, 1);
         /* NOTE (reference mz_preyama.c:279): rows 1..K are scanned although A now has rows 0..K-1, so
          * "row K" of a column is really row 0 of the next column (and, for the last column, the byte
          * after the data: a stale pre-compaction byte, or the spare non-dash of cols_new()).  The
          * reference's outputs depend on it; reproduced literally. */
-        m4a = mapping(A, 1, K, 1, M, merged, 0, K - 1, 1, M_new);
+        m4a = mapping(p->A, 1, K, 1, M, p->merged, 0, K - 1, 1, M_new);
         LBa = (int *)xmalloc(((size_t)M3 + 1) * sizeof(int));
         RBa = (int *)xmalloc(((size_t)M3 + 1) * sizeof(int));
         for (i = 0; i <= M3; ++i) { LBa[i] = 0; RBa[i] = M_new; }
         for (i = 1; i <= M_all; ++i) {
             int t1 = m3a[i], t2;
-            if (map1[i] == -1) continue;
-            t2 = m4a[map1[i]];
+            if (p->map1[i] == -1) continue;
+            t2 = m4a[p->map1[i]];
             if (t1 != -1 && t2 != -1) bound_note(LBa, RBa, t1, t2, M_new);
         }
-        smooth(LBa, RBa, M3, M_new, radius);
+        smooth(LBa, RBa, M3, M_new, p->radius);
         free(m3a); free(m4a);
 
-        for (i = 1; i <= N_all; ++i) ref2[i][0] = (uchar)a2->components->text[cbeg2 + i - 1];
-        m3b = rmColDash(ref2, &N3, 1);
-        m4b = mapping(B, 0, L - 1, 1, N, merged, K, K + L - 1, 1, M_new);
+        for (i = 1; i <= N_all; ++i) p->ref2[i][0] = (uchar)a2->components->text[p->cbeg2 + i - 1];
+        m3b = rmColDash(p->ref2, &N3, 1);
+        m4b = mapping(p->B, 0, L - 1, 1, N, p->merged, K, K + L - 1, 1, M_new);
         LBb = (int *)xmalloc(((size_t)N3 + 1) * sizeof(int));
         RBb = (int *)xmalloc(((size_t)N3 + 1) * sizeof(int));
         for (i = 0; i <= N3; ++i) { LBb[i] = 0; RBb[i] = M_new; }
@@ -270,21 +322,43 @@ struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, 
             /* NOTE (reference mz_preyama.c:318-326): map2[i] is not tested for -1 here, so a removed
              * a2 column reads the word in front of the map; on glibc/x86-64 that is the upper half of
              * the chunk header, i.e. 0.  Reproduced as the value 0. */
-            int t1 = m3b[i], t2 = map2[i] == -1 ? 0 : m4b[map2[i]];
+            int t1 = m3b[i], t2 = p->map2[i] == -1 ? 0 : m4b[p->map2[i]];
             if (t1 != -1 && t2 != -1) bound_note(LBb, RBb, t1, t2, M_new);
         }
-        smooth(LBb, RBb, N3, M_new, radius);
+        smooth(LBb, RBb, N3, M_new, p->radius);
         if (M3 != N3) mz_fatalf("M3 not equals N3!!\n");
         for (i = 0; i <= M3; ++i) {
             if (LBa[i] < LBb[i]) LBb[i] = LBa[i];
             if (RBa[i] > RBb[i]) RBb[i] = RBa[i];
         }
-        yama(ref1, 1, M3, merged, K + L, M_new, LBb, RBb, &merged2, &M_new);
-        result = mafBuild(merged2, K + L + 1, M_new, a1, cbeg1, a2, cbeg2, 0);
-        free(m3b); free(m4b); free(LBa); free(RBa); free(LBb); free(RBb);
-        cols_free(ref1); cols_free(ref2); cols_free(merged2);
+        free(m3b); free(m4b); free(LBa); free(RBa);
+        free(p->LB); free(p->RB);
+        p->LB = LBb; p->RB = RBb;                           /* band of the second job */
+        p->stage = 2;
+        p->job.K = 1; p->job.L = K + L; p->job.M = M3; p->job.N = M_new;
+        p->job.A = p->ref1[1]; p->job.B = p->merged[1]; p->job.LB = LBb; p->job.RB = RBb;
+        return MZ_PY_JOB;
     }
-    cols_free(A); cols_free(B); cols_free(merged);
-    free(map1); free(map2);
+    p->merged2 = cols_wrap(flat, om, K + L + 1);
+    *result = mafBuild(p->merged2, K + L + 1, om, a1, p->cbeg1, a2, p->cbeg2, 0);
+    mz_py_free(p);
+    return MZ_PY_DONE;
+}
+
+/* one job on the GPU; failures end the program with the reference's messages (mz_host.c) */
+void mz_py_run_one(mz_job *job, uchar **flat, int *om);
+
+struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int v, FILE *fpw2)
+{
+    mz_py p;
+    struct mafAli *result = NULL;
+    uchar *flat;
+    int om, st;
+
+    st = mz_py_begin(&p, a1, a2, beg, end, radius, v, fpw2);
+    while (st == MZ_PY_JOB) {
+        mz_py_run_one(&p.job, &flat, &om);
+        st = mz_py_step(&p, flat, om, &result);
+    }
     return result;
 }
