@@ -1,0 +1,25 @@
+/* include/mz_multiz.h -- the multiz driver with all of its pairwise merges run as GPU batches
+ * (SURVEY.md section 8, row f1).  Replaces the main loop of reference multiz.c:60-177 and its command
+ * line (:180-294); output is byte-identical to the stock binary's.
+ */
+#ifndef MZAMD_MZ_MULTIZ_H
+#define MZAMD_MZ_MULTIZ_H
+
+#include <stdio.h>
+#include "maf.h"
+
+/* All blocks of a MAF file, in file order (reference maf.c mafReadAll(); `verbose` echoes comment lines to
+ * stdout as the stock reader does).  Errors end the program with the reader's messages. */
+struct mafAli *mz_maf_read_all(const char *path, int verbose);
+
+/* Merge two position-sorted block lists that share their top (reference) row, contig by contig in the order
+ * of list1 (reference multiz.c:267-275 + multiz()).  Merged blocks go to `out`, unused parts of the inputs to
+ * out1 / out2 (NULL: dropped); blocks of contigs present in one list only stay in *list1 / *list2.  Every
+ * pre_yama() of the run is enumerated first and aligned in one (v == 1) or two (v == 0) GPU batches. */
+int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
+                    FILE *out, FILE *out1, FILE *out2);
+
+/* the multiz command line: [R=?] [M=?] file1 file2 v [out1 out2] [nohead] [all] */
+int mz_multiz_main(int argc, char **argv);
+
+#endif

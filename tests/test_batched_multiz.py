@@ -1,0 +1,98 @@
+"""the batched multiz driver (multiz_amd/mz_multiz = mz_multiz_main() of
+libmzamd.so: own MAF reader, own walk over the block lists, every pre_yama() of the run aligned in one or two
+GPU batches) against the stock reference binary (oracle/_ref/multiz_ref) on the same MAF files: identical
+bytes on stdout and in both leftover files, for v = 1 and v = 0, with and without [out1 out2], with R= / M=
+flags, several contigs, single-row blocks and contigs that only one file has."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "multiz_ref")
+OUR_BIN = os.path.join(ROOT, "multiz_amd", "mz_multiz")
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.path.exists(REF_BIN) and os.path.exists(OUR_BIN)), reason="binaries not built")]
+
+
+def run(binary, args, workdir, tag, outs):
+    # the driver echoes its argv into the output header, so both runs get identical argument strings
+    d = os.path.join(workdir, tag)
+    os.makedirs(d)
+    p = subprocess.run([binary] + args, capture_output=True, timeout=600, cwd=d)
+    assert p.returncode in (0, 1), p.stderr.decode()[-2000:]
+    # (a run that yama() ends with a fatal message must fail the same way, after the same partial output)
+    return (p.stdout, p.returncode, p.stderr) + tuple(open(os.path.join(d, o), "rb").read() for o in outs)
+
+
+def both(tmp_path, args, outs=()):
+    want = run(REF_BIN, args, str(tmp_path), "ref", outs)
+    got = run(OUR_BIN, args, str(tmp_path), "gpu", outs)
+    for w, g in zip(want, got):
+        assert g == w
+    return want
+
+
+def two_files(tmp_path, seed, rows, nblocks=30, stride2=300):
+    rng = np.random.default_rng(seed)
+    ref = inputs.ACGT[rng.integers(0, 4, size=nblocks * 260 + 300)]
+    inputs.write_maf(str(tmp_path / "a.maf"), inputs.random_maf_file(rng, ref, nblocks, rows[0], "p"))
+    inputs.write_maf(str(tmp_path / "b.maf"), inputs.random_maf_file(rng, ref, nblocks, rows[1], "q", stride=stride2))
+
+
+@pytest.mark.parametrize("v", [1, 0])
+@pytest.mark.parametrize("rows", [(2, 2), (3, 2), (2, 4), (1, 3)])
+def test_matches_stock_binary_with_leftover_files(tmp_path, v, rows):
+    two_files(tmp_path, 77 + 1000 * v + 10 * rows[0] + rows[1], rows)
+    want = both(tmp_path, ["../a.maf", "../b.maf", str(v), "u1", "u2"], ("u1", "u2"))
+    if rows[0] > 1:
+        assert want[0].count(b"\na score=") >= 10           # the run really merged blocks
+
+
+@pytest.mark.parametrize("v", [1, 0])
+def test_matches_stock_binary_all_sinks_on_stdout(tmp_path, v):
+    # without [out1 out2] merged blocks and unused parts interleave on stdout: the order must be replayed
+    two_files(tmp_path, 500 + v, (3, 3))
+    want = both(tmp_path, ["../a.maf", "../b.maf", str(v)])
+    assert want[0].count(b"\na score=") >= 20
+
+
+@pytest.mark.parametrize("flags", [["R=10"], ["M=40"], ["R=5", "M=12"], ["R=7"], []])
+def test_flags_and_trailing_words(tmp_path, flags):
+    two_files(tmp_path, 900 + len(flags), (2, 3), nblocks=20)
+    both(tmp_path, flags + ["../a.maf", "../b.maf", "1", "u1", "u2", "nohead"], ("u1", "u2"))
+    both_dir = tmp_path / "second"
+    both_dir.mkdir()
+    for f in ("a.maf", "b.maf"):
+        os.link(str(tmp_path / f), str(both_dir / f))
+    both(both_dir, flags + ["../a.maf", "../b.maf", "0", "all"])
+
+
+def test_several_contigs_and_orphans(tmp_path):
+    # blocks of three reference contigs in file 1, two of them (in another order) plus a fourth in file 2
+    rng = np.random.default_rng(4242)
+    blocks1, blocks2 = [], []
+    for name, n1, n2 in (("ref.chrA", 8, 8), ("ref.chrB", 6, 0), ("ref.chrC", 7, 9)):
+        ref = inputs.ACGT[rng.integers(0, 4, size=10 * 260 + 300)]
+        for blocks, n, tag in ((blocks1, n1, "p"), (blocks2, n2, "q")):
+            bl = inputs.random_maf_file(rng, ref, n, 3, tag) if n else []
+            for b in bl:
+                b.rows[0].src = name
+            blocks.extend(bl)
+    ref = inputs.ACGT[rng.integers(0, 4, size=5 * 260 + 300)]
+    extra = inputs.random_maf_file(rng, ref, 4, 2, "z")
+    for b in extra:
+        b.rows[0].src = "ref.chrD"
+    blocks2 = blocks2[8:] + extra + blocks2[:8]            # chrC, chrD, chrA
+    inputs.write_maf(str(tmp_path / "a.maf"), blocks1)
+    inputs.write_maf(str(tmp_path / "b.maf"), blocks2)
+    both(tmp_path, ["../a.maf", "../b.maf", "1", "u1", "u2"], ("u1", "u2"))
+    d2 = tmp_path / "second"
+    d2.mkdir()
+    for f in ("a.maf", "b.maf"):
+        os.link(str(tmp_path / f), str(d2 / f))
+    both(d2, ["../a.maf", "../b.maf", "0"])
