@@ -69,7 +69,9 @@ enum {
 enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 /* FAST with tag-encoded picks */,
        MZ_MODE_PACK = 4 /* FASTT arithmetic, four pairs per wave (16 lanes x 3 rows each) */,
        MZ_MODE_ROW = 5 /* FASTT arithmetic, lane = column, one band row per iteration (bands <= 63 wide) */,
-       MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */ };
+       MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */,
+       MZ_MODE_ROWR = 7, MZ_MODE_COLR = 8 /* ROW / COL for scores too large for the 2^30 ring lift: the prefix
+                                             maximum runs on lanes rotated to the band start (two ds_bpermute) */ };
 
 typedef struct mz_dev_batch {
     int32_t n;

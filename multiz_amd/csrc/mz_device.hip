@@ -190,6 +190,22 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                         }
                     }
                 }
+                // larger scores (C3: 10+10 rows): the 2^30 lift of the ring periods no longer fits, so the prefix
+                // maximum runs on lanes rotated to the band start instead.  Tagged states need |4*score| < 2^30;
+                // a path of at most M+N steps moves by at most K*L*(go + max(ge, max|score|)) per step.
+                if ((mode == MZ_MODE_FAST || mode == MZ_MODE_FASTT) && c_sc.row_on && c_sc.tag_ok &&
+                    (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * ((long long)M + N + 2) < (1LL << 28)) {
+                    if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
+                        mode = MZ_MODE_ROWR;
+                        edgeLo = rL; edgeHi = rN;
+                        szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
+                    } else if (col_ok && 2 * L * (c_sc.maxS + c_sc.go) <= 32767) {
+                        mode = MZ_MODE_COLR;
+                        edgeLo = RB[1 < M ? 1 : M]; edgeHi = LB[M];
+                        szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
+                        szPrep = COL_PREP_DWORDS(N);
+                    }
+                }
                 if (mode == MZ_MODE_PACK) {
                     szTb = (long long)(((M + N) >> 4) + 1) * 144;
                     szPrep = (long long)(((M + 47) / 48) * 48 + 96) * 16 + 6LL * (((N + 1 + 63) / 64) * 64 + 64);
@@ -1247,7 +1263,7 @@ typedef int int8v __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int count)
 {
     const int p = first + blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_COL) return;
+    if (b.status[p] != MZ_OK || (b.mode[p] != MZ_MODE_COL && b.mode[p] != MZ_MODE_COLR)) return;
     const int M = b.M[p], N = b.N[p];
     const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
     int *tlo = (int *)(b.prep + b.offPrep[p]), *thi = tlo + (N + 1);
@@ -1262,7 +1278,7 @@ __global__ __launch_bounds__(WAVE) void k_rowprep(mz_dev_batch b, int first, int
 // The row record: 16 dwords, built for 64 rows at a time by the 64 lanes (row_stage_rows) in LDS and read back
 // by every lane of the wave (broadcast reads) one row ahead of its use; interior rows read 12 dwords.
 //   a = {lo32, wid32, rIx, rCxA}  b = {rCxB (= rDx), rCy, rCz, cDe}  c = {penDye - cDe, w01, w23, w45}
-//   d = {rIy, rIz, dA | nA << 8 | last << 16, -}    (rIy, rIz are pair constants except on the last row)
+//   d = {rIy, rIz, dA | nA << 8 | last << 16, 4*(LB[r]&63)}    (rIy, rIz are pair constants except on the last row)
 // History: the records were first read with scalar loads from a prep pass in HBM (SGPR operands, no LDS).  That
 // made the loop wait ~0.8 us per scalar-cache miss, cost a 3 GB prep kernel per batch competing with the DP, and
 // -- with compact records derived by scalar code -- saturated the CU's shared scalar unit.
@@ -1327,7 +1343,7 @@ __device__ __forceinline__ void row_stage_rows(int blk, int lane, const RowSrc &
     d[0] = make_int4(32 * lo, 32 * (hi - lo), last ? 0 : pack2(-K * g1, -dA * g1), pack2((nA - dA) * g1, -a11 * g1));
     d[1] = make_int4(pack2(-a00 * g1, 0), pack2((nA - a00 - dA) * g1, 0), pack2((nA - dA) * g1, -dA * g1), cDe);
     d[2] = make_int4(4 * (go * L * (nA - a00) + ge * L * nA) - cDe, pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]));
-    d[3] = make_int4(last ? 0 : pack2(-K * g1, 0), last ? 0 : pack2(-K * g1, -K * g1), dA | (nA << 8) | ((int)last << 16), 0);
+    d[3] = make_int4(last ? 0 : pack2(-K * g1, 0), last ? 0 : pack2(-K * g1, -K * g1), dA | (nA << 8) | ((int)last << 16), 4 * (lo & (WAVE - 1)));
 }
 
 // the record of row r from the staged block (every lane reads the same address: LDS broadcast)
@@ -1338,6 +1354,8 @@ __device__ __forceinline__ void row_rec_read(RowRec &R, const int4 *s_rec, int r
     R.a = s[0]; R.b = s[1]; R.c = s[2];
     if (FULL) R.d = s[3];
 }
+// ROT kernels also need the band's start lane in interior rows
+__device__ __forceinline__ int row_rec_s4(const int4 *s_rec, int r) { return s_rec[((r - 1) & (WAVE - 1)) * (RREC / 4) + 3].w; }
 
 struct RowState {
     int c32;                      // 32 * the column this lane holds
@@ -1429,8 +1447,10 @@ struct RowCtx { int K, L, N32, KL4go, rIy, rIz; };     // rIy, rIz: the I-state 
 // one row of the band; EDGE = the row can hold column 0, 1 or N, or is row M (COL: or is row 1).
 // COL = transposed problem: the D slot holds the reference's I state (tag 1) and the I slot its D state
 // (tag 0), so that one max still resolves the reference's tie order C > I > D.
-template <bool EDGE, bool COL>
-__device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, const RowCtx &J, const int4 *s_ring, uint32_t *tbw, int lane)
+// ROT: no ring lift; the open candidates are rotated so that the band starts at lane 0 (s4 = 4 * start lane),
+// scanned, and rotated back
+template <bool EDGE, bool COL, bool ROT>
+__device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, int r, const RowCtx &J, const int4 *s_ring, uint32_t *tbw, int lane)
 {
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
     const Tri dg = S.l;                                // (r-1, c-1), rotated at the end of row r-1
@@ -1490,15 +1510,21 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int r, co
     int g, Pl;
     if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
         const bool last = R_last(R) != 0;
-        const int lift = ((c32 ^ R_lo32(R)) >> 11) == 0 ? ROW_LIFT : 0;       // lower ring period
+        const int lift = (!ROT && ((c32 ^ R_lo32(R)) >> 11) == 0) ? ROW_LIFT : 0;   // lower ring period
         Pl = last ? S.Q - lift : S.Pl;
         g = (base & ~3) - (S.xIPl - S.Pl) + (last ? J.KL4go : 0) - Pl;
     } else {
         Pl = S.Pl;
         g = (base & ~3) - S.xIPl;
     }
-    g = prefix_max64(g);
-    g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
+    if (ROT) {
+        g = __builtin_amdgcn_ds_bpermute((4 * lane + s4) & (4 * WAVE - 4), g);      // lane i <- lane (i + s) & 63
+        g = prefix_max64(g);
+        g = __builtin_amdgcn_ds_bpermute((4 * lane - s4) & (4 * WAVE - 4), g);      // and back
+    } else {
+        g = prefix_max64(g);
+        g = max(g, __builtin_amdgcn_readlane(g, WAVE - 1) - ROW_LIFT);   // the wrapped tail continues the lower period
+    }
     nI = active ? g + Pl : NEGT + TI;
     const int lI = ror1(nI);
     z = dot2_keep(EDGE ? R.d.y : J.rIz, uA, lI);
@@ -1525,18 +1551,23 @@ __device__ __forceinline__ int row_find_cross(const int4 *s_rec, int blk, int la
     return m ? blk * WAVE + 1 + (int)__builtin_ctzll(m) : MZ_BIG;
 }
 
+template <bool ROT>
 __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, int r, int lane, ColSrc &cols, const int4 *s_rec, int4 *s_ring)
 {
     if (r == Q.rcross) {                               // scalar compare: the row was located when the block was staged
-        int2 *e = (int2 *)((char *)s_ring + (((Q.next32 >> 5) + lane) & (FRING - 1)) * 32 + 16);
-        int2 v = *e;
-        v.x -= ROW_LIFT; v.y -= ROW_LIFT;
-        *e = v;
+        if (!ROT) {
+            int2 *e = (int2 *)((char *)s_ring + (((Q.next32 >> 5) + lane) & (FRING - 1)) * 32 + 16);
+            int2 v = *e;
+            v.x -= ROW_LIFT; v.y -= ROW_LIFT;
+            *e = v;
+        }
         row_stage_cols((Q.next32 >> 5) + WAVE, 0, lane, cols, s_ring);
         __syncthreads();
-        const int lift = ((S.c32 ^ Q.next32) >> 11) == 0 ? ROW_LIFT : 0;
-        S.Pl -= lift;
-        S.xIPl -= lift;
+        if (!ROT) {
+            const int lift = ((S.c32 ^ Q.next32) >> 11) == 0 ? ROW_LIFT : 0;
+            S.Pl -= lift;
+            S.xIPl -= lift;
+        }
         Q.next32 += 32 * WAVE;
         Q.rcross = row_find_cross(s_rec, (r - 1) >> 6, lane, Q.next32);
     }
@@ -1551,7 +1582,7 @@ __device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int 
 // rows r0..r1 of one phase, block of 64 staged rows by block; within a block two rows per iteration so that
 // the record registers alternate (the next row's record is read from LDS while the current row is computed).
 // Pairs start on even rows, so only the second row of a pair can close a 16-row traceback group.
-template <bool EDGE, bool COL>
+template <bool EDGE, bool COL, bool ROT>
 __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1, int lane, const RowCtx &J,
                                          const RowSrc &src, ColSrc &cols, int4 *s_rec, int4 *s_ring, uint32_t *tbw)
 {
@@ -1568,8 +1599,8 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
         RowRec Ra, Rb;
         row_rec_read<EDGE>(Ra, s_rec, r);
         if (r & 1) {                                   // odd first row on its own
-            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
-            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            row_pre<ROT>(S, Q, r, lane, cols, s_rec, s_ring);
+            row_step<EDGE, COL, ROT>(S, Ra, ROT ? row_rec_s4(s_rec, r) : 0, r, J, s_ring, tbw, lane);
             if ((r & 15) == 15) row_store(S, tbw, r, lane);
             ++r;
             if (r > last) continue;
@@ -1577,16 +1608,16 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
         }
         for (; r + 1 <= last; r += 2) {
             row_rec_read<EDGE>(Rb, s_rec, r + 1);
-            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
-            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            row_pre<ROT>(S, Q, r, lane, cols, s_rec, s_ring);
+            row_step<EDGE, COL, ROT>(S, Ra, ROT ? row_rec_s4(s_rec, r) : 0, r, J, s_ring, tbw, lane);
             if (r + 2 <= last) row_rec_read<EDGE>(Ra, s_rec, r + 2);
-            row_pre(S, Q, r + 1, lane, cols, s_rec, s_ring);
-            row_step<EDGE, COL>(S, Rb, r + 1, J, s_ring, tbw, lane);
+            row_pre<ROT>(S, Q, r + 1, lane, cols, s_rec, s_ring);
+            row_step<EDGE, COL, ROT>(S, Rb, ROT ? row_rec_s4(s_rec, r + 1) : 0, r + 1, J, s_ring, tbw, lane);
             if (((r + 1) & 15) == 15) row_store(S, tbw, r + 1, lane);
         }
         if (r <= last) {
-            row_pre(S, Q, r, lane, cols, s_rec, s_ring);
-            row_step<EDGE, COL>(S, Ra, r, J, s_ring, tbw, lane);
+            row_pre<ROT>(S, Q, r, lane, cols, s_rec, s_ring);
+            row_step<EDGE, COL, ROT>(S, Ra, ROT ? row_rec_s4(s_rec, r) : 0, r, J, s_ring, tbw, lane);
             if ((r & 15) == 15) row_store(S, tbw, r, lane);
             ++r;
         }
@@ -1600,7 +1631,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool COL>
+template <bool COL, bool ROT>
 __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int lane, int4 *s_rec, int4 *s_ring)
 {
     constexpr int TD = COL ? 1 : 0, TI = COL ? 0 : 1;
@@ -1633,7 +1664,7 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 
     RowLoop Q;
     Q.next32 = 32 * WAVE;
-    row_stage_cols(0, ROW_LIFT, lane, cols, s_ring);
+    row_stage_cols(0, ROT ? 0 : ROW_LIFT, lane, cols, s_ring);
     row_stage_cols(WAVE, 0, lane, cols, s_ring);
     row_stage_rows(0, lane, src, s_rec);
     __syncthreads();
@@ -1652,9 +1683,9 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 
     // rows 1..e1 edge, e1+1..e2-1 interior, e2..M edge (transposed: row 1 is always an edge row)
     const int e1 = min(max(rL, COL ? 1 : 0), M), e2 = max(rN, e1 + 1);
-    row_rows<true, COL>(S, Q, 1, e1, lane, J, src, cols, s_rec, s_ring, tbw);
-    row_rows<false, COL>(S, Q, e1 + 1, e2 - 1, lane, J, src, cols, s_rec, s_ring, tbw);
-    row_rows<true, COL>(S, Q, e2, M, lane, J, src, cols, s_rec, s_ring, tbw);
+    row_rows<true, COL, ROT>(S, Q, 1, e1, lane, J, src, cols, s_rec, s_ring, tbw);
+    row_rows<false, COL, ROT>(S, Q, e1 + 1, e2 - 1, lane, J, src, cols, s_rec, s_ring, tbw);
+    row_rows<true, COL, ROT>(S, Q, e2, M, lane, J, src, cols, s_rec, s_ring, tbw);
 
     if ((M & 15) != 15) {                              // flush the partial group
         const int sh = 2 * (15 - (M & 15));
@@ -1675,8 +1706,10 @@ __global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int 
     const int p = first + blockIdx.x, lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int mode = b.mode[p];
-    if (mode == MZ_MODE_ROW)      dp_row_body<false>(b, p, lane, s_rec, s_ring);
-    else if (mode == MZ_MODE_COL) dp_row_body<true>(b, p, lane, s_rec, s_ring);
+    if (mode == MZ_MODE_ROW)       dp_row_body<false, false>(b, p, lane, s_rec, s_ring);
+    else if (mode == MZ_MODE_COL)  dp_row_body<true, false>(b, p, lane, s_rec, s_ring);
+    else if (mode == MZ_MODE_ROWR) dp_row_body<false, true>(b, p, lane, s_rec, s_ring);
+    else if (mode == MZ_MODE_COLR) dp_row_body<true, true>(b, p, lane, s_rec, s_ring);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2352,7 +2385,7 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
-    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode == MZ_MODE_ROW || mode == MZ_MODE_COL;
+    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode >= MZ_MODE_ROW;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -2371,14 +2404,14 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
             const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
             const unsigned tg = (tbw[((long long)(t >> 4) * 9 + j * 3 + sidx) * 16 + (q & 15)] >> (2 * (t & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
-        } else if (mode == MZ_MODE_COL) {
+        } else if (mode == MZ_MODE_COL || mode == MZ_MODE_COLR) {
             // transposed row-parallel kernel: one entry per COLUMN, lane = row & 63; its D slot (stream 1)
             // holds the picks of the reference's I state and its I slot (stream 2) those of D.  Column 0 is
             // not stored: only D is reachable there (mz_yama.c:211), and it comes from D.
             const int sidx = node == MZ_FC ? 0 : node == MZ_FI ? 1 : 2;
             const unsigned tg = c == 0 ? 0u : (tbw[((c >> 4) * 3 + sidx) * WAVE + (r & (WAVE - 1))] >> (2 * (c & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
-        } else if (mode == MZ_MODE_ROW) {
+        } else if (mode == MZ_MODE_ROW || mode == MZ_MODE_ROWR) {
             // row-parallel kernel: word ((r>>4)*3 + s)*64 + (c & 63), bits 2*(r&15)
             const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
             const unsigned tg = (tbw[((r >> 4) * 3 + sidx) * WAVE + (c & (WAVE - 1))] >> (2 * (r & 15))) & 3;

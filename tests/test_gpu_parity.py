@@ -184,7 +184,8 @@ def test_every_kernel_family_is_exercised(mz):
                                 (2, 3, 70, 64, 31, "diag"), (2, 2, 64, 70, 31, "diag"), (4, 4, 150, 150, 12, "wander"),
                                 (2, 2, 150, 230, 25, "wander"), (2, 2, 230, 150, 25, "wander"), (5, 2, 90, 400, 30, "diag"),
                                 (2, 5, 400, 90, 30, "diag"), (2, 2, 500, 500, 60, "diag"), (1, 1, 63, 63, 31, "diag"),
-                                (2, 2, 40, 45, 10, "diag"), (6, 6, 129, 128, 30, "diag")):
+                                (2, 2, 40, 45, 10, "diag"), (6, 6, 129, 128, 30, "diag"),
+                                (12, 10, 700, 640, 30, "diag"), (10, 12, 640, 700, 30, "diag")):   # rotate-scan modes 7 / 8
         for _ in range(6):
             A, B, LB, RB = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth,
                                             dash=float(rng.choice([0.0, 0.08, 0.3])), odd=float(rng.choice([0.0, 0.05])))
@@ -196,8 +197,8 @@ def test_every_kernel_family_is_exercised(mz):
     db.run()
     res = db.results()
     assert (res["status"] == 0).all()
-    hist = np.bincount(res["mode"], minlength=7)
-    assert hist[5] > 0 and hist[6] > 0 and hist[:5].sum() > 0, hist
+    hist = np.bincount(res["mode"], minlength=9)
+    assert hist[5] > 0 and hist[6] > 0 and hist[7] + hist[8] > 0 and hist[:5].sum() > 0, hist
     host_out = db.out.cpu().numpy()
     for i, (A, B, LB, RB) in enumerate(pairs):
         want = mo.yama(A, B, LB, RB)
