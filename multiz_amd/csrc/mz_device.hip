@@ -2376,7 +2376,13 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
 #define WALK_LANES 64            // pairs per wave (measured: 16 per wave is no faster -- the chase is bound by its own dependent loads -- and costs four times the instruction issue beside the DP)
-__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
+#define WALK_TILE 196            // dwords per pair: 2 groups x 3 streams x 2 chunks x 16 lanes, padded (16-byte aligned, spreads the banks)
+// TILE: cache the traceback around the current position in LDS (row-parallel layouts).  It halves the walk of a
+// batch of few, long pairs (C3: 2.7 -> 1.2 ms) but fetches ~48 bytes per step: with tens of thousands of pairs
+// (C2) the chase is no faster, and its 49 KB of LDS per wave and 5 GB of extra reads slow the DP running beside
+// it in the pipelined form.  The launcher picks by batch size.
+template <bool TILE>
+__device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int count, int *s_tile)
 {
     if (threadIdx.x >= WALK_LANES) return;
     const int p = first + blockIdx.x * WALK_LANES + threadIdx.x;
@@ -2386,6 +2392,9 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
     const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode >= MZ_MODE_ROW;
+    const bool rowfam = mode >= MZ_MODE_ROW, colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
+    int *tile = TILE ? s_tile + threadIdx.x * WALK_TILE : s_tile;   // this pair's traceback tile (row-parallel layouts)
+    int tile_g = -1, tile_ch = 0;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -2404,17 +2413,43 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
             const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
             const unsigned tg = (tbw[((long long)(t >> 4) * 9 + j * 3 + sidx) * 16 + (q & 15)] >> (2 * (t & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
-        } else if (mode == MZ_MODE_COL || mode == MZ_MODE_COLR) {
-            // transposed row-parallel kernel: one entry per COLUMN, lane = row & 63; its D slot (stream 1)
-            // holds the picks of the reference's I state and its I slot (stream 2) those of D.  Column 0 is
-            // not stored: only D is reachable there (mz_yama.c:211), and it comes from D.
-            const int sidx = node == MZ_FC ? 0 : node == MZ_FI ? 1 : 2;
-            const unsigned tg = c == 0 ? 0u : (tbw[((c >> 4) * 3 + sidx) * WAVE + (r & (WAVE - 1))] >> (2 * (c & 15))) & 3;
-            stb = tg | (tg << 2) | (tg << 4);
-        } else if (mode == MZ_MODE_ROW || mode == MZ_MODE_ROWR) {
-            // row-parallel kernel: word ((r>>4)*3 + s)*64 + (c & 63), bits 2*(r&15)
-            const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
-            const unsigned tg = (tbw[((r >> 4) * 3 + sidx) * WAVE + (c & (WAVE - 1))] >> (2 * (r & 15))) & 3;
+        } else if (rowfam) {
+            // row-parallel kernels: entry of (r,c) = bits 2*(u&15) of word ((u>>4)*3 + s)*64 + (w & 63), with
+            // (u,w) = (r,c) and streams C,D,I for ROW; (u,w) = (c,r) and streams C,I,D for the transposed COL
+            // (its D slot holds the picks of the reference's I state).  COL does not store column 0: only D
+            // is reachable there (mz_yama.c:211), and it comes from D.
+            // The chase used to pay one dependent HBM/L2 load per step (~0.8 us); the 2 x 16 lanes x 3 streams
+            // around the current position, for the current 16-row group and the next one down, are fetched at
+            // once (48 independent 16-byte loads) into a private LDS tile, which then serves >= 16 steps.
+            const int u = colfam ? c : r, w = colfam ? r : c;
+            const int g = u >> 4, l = w & (WAVE - 1), ch = l >> 4;
+            const int sidx = node == MZ_FC ? 0 : node == (colfam ? MZ_FI : MZ_FD) ? 1 : 2;
+            unsigned tg = 0;
+            if (!TILE) {
+                if (!(colfam && c == 0)) tg = (tbw[(g * 3 + sidx) * WAVE + l] >> (2 * (u & 15))) & 3;
+            } else if (!(colfam && c == 0)) {
+                // tile = groups tile_g and tile_g-1, lane chunks tile_ch and tile_ch-1.  When ANY pair of the
+                // wave has left its tile, EVERY pair re-centres its own (a wave-uniform branch): otherwise, with
+                // 64 unsynchronised pairs, some lane would sit in the reload -- and its latency -- at every step.
+                int gs = tile_g - g, slot = (ch == tile_ch) ? 0 : (ch == ((tile_ch - 1) & 3)) ? 1 : -1;
+                const bool miss = (unsigned)gs > 1u || slot < 0;
+                if (__builtin_amdgcn_ballot_w64(miss) != 0) {
+                    tile_g = g; tile_ch = ch; gs = 0; slot = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int gq = g - q > 0 ? g - q : 0;
+                                const int4 *src = (const int4 *)(tbw + (gq * 3 + s) * WAVE + ((ch - k) & 3) * 16);
+                                int4 *dst = (int4 *)(tile + q * 96 + s * 32 + k * 16);
+                                const int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                                dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+                            }
+                }
+                tg = ((unsigned)tile[gs * 96 + sidx * 32 + slot * 16 + (l & 15)] >> (2 * (u & 15))) & 3;
+            }
             stb = tg | (tg << 2) | (tg << 4);
         } else if (tagged) {
             // 2-bit tag streams: word ((t>>4)*3 + s)*64 + lane, s = 0/1/2 for the C/D/I pick; read only
@@ -2444,6 +2479,15 @@ __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int co
     if (status == MZ_OK && (r != 0 || c != 0)) status = MZ_E_TRACEBACK;
     b.om[p] = n;
     if (status != MZ_OK) b.status[p] = status;
+}
+__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
+{
+    walk_body<false>(b, first, count, NULL);
+}
+__global__ __launch_bounds__(WAVE) void k_walk_tile(mz_dev_batch b, int first, int count)
+{
+    __shared__ __attribute__((aligned(16))) int s_tile[WALK_LANES * WALK_TILE];   // 49 KB
+    walk_body<true>(b, first, count, s_tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2556,7 +2600,10 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    if (count <= 16384)      // few pairs: the chase itself is the bottleneck, see walk_body
+        hipLaunchKernelGGL(k_walk_tile, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    else
+        hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "walk launch");
     return 0;
 }
