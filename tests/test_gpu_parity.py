@@ -208,6 +208,45 @@ def test_every_kernel_family_is_exercised(mz):
         assert np.array_equal(got, want.cols), (i, int(res["mode"][i]))
 
 
+def test_large_score_magnitudes(mz):
+    # columns whose dash pattern flips from one column to the next make every row pair open a gap at every step:
+    # final scores of -1e7 .. -9e7, within a small factor of the magnitude bounds under which the plan admits
+    # the tagged / row-parallel (ring-lift and rotate-scan) kernels.  Every kernel set must still match the oracle.
+    from multiz_amd import synth
+
+    def flip_pair(K, L, M, N, R, pat):
+        r, i = np.arange(M)[:, None], np.arange(K)[None, :]
+        A = np.where(((r + i) % 2 == 0) if pat == 0 else ((r // 2 + i) % 2 == 0), ord("A"), ord("-")).astype(np.uint8)
+        c, j = np.arange(N)[:, None], np.arange(L)[None, :]
+        B = np.where((c + j) % 2 == 1, ord("C"), ord("-")).astype(np.uint8)
+        for X in (A, B):
+            X[(X == 45).all(axis=1), 0] = ord("G")
+        LB, RB = mo.smooth(*inputs.diag_band(M, N), M, N, R)
+        return A, B, LB, RB
+
+    pairs = [flip_pair(K, L, M, N, 30, pat)
+             for (K, L, M, N) in ((8, 8, 740, 740), (8, 8, 700, 760), (16, 16, 700, 700), (20, 20, 900, 860),
+                                  (30, 30, 420, 400), (4, 4, 2900, 2900), (12, 10, 1500, 1400))
+             for pat in (0, 1)]
+    want = [mo.yama(*p) for p in pairs]
+    assert min(int(w.final.min()) for w in want) < -8e7
+    batch = synth.pack_pairs(pairs)
+    seen = np.zeros(9, dtype=np.int64)
+    for which in (2, 1, 0):
+        _kernels(mz, which)
+        db = mz.DevBatch(batch)
+        db.run()
+        res = db.results()
+        assert (res["status"] == 0).all()
+        seen += np.bincount(res["mode"], minlength=9)
+        out = db.out.cpu().numpy()
+        for i, (p, w) in enumerate(zip(pairs, want)):
+            m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+            assert m_ == w.OM, (which, i, int(res["mode"][i]))
+            assert np.array_equal(out[o0: o0 + m_ * (p[0].shape[1] + p[1].shape[1])].reshape(m_, -1), w.cols), (which, i, int(res["mode"][i]))
+    assert seen[5] and seen[6] and seen[7] and seen[2] + seen[3] and seen[0], seen
+
+
 def test_pipelined_batches_rotating_workspaces(mz):
     # mz_dev_run_async(): walk + emit of batch k overlap plan + DP of batch k+1 on a second stream; two
     # alternating workspaces.  After mz_dev_wait() both must hold exactly what the serial form produces.
