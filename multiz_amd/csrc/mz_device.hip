@@ -156,11 +156,13 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
             } else if (wf_ok) {
                 // fast kernel: connected band + every reachable score above -2^29 (so that sentinel
                 // states, which sit at about -2^30, can never win a comparison) + factorable gap_open
-                const bool small = (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 29);
+                // |score| of a reachable state: a path has at most M+N steps and a step moves the score by at most
+                // K*L*(go + ge) (gap step: every row pair opens and extends) or K*L*(go + max|sigma|) (aligned step)
+                const long long reach = (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * ((long long)M + N + 2);
+                const bool small = reach < (1LL << 29);
                 mode = (conn && small && c_sc.g1 > 0) ? MZ_MODE_FAST : MZ_MODE_WF64;
                 // tagged variant: one more bit of headroom, doubled int16 vectors must still fit
-                if (mode == MZ_MODE_FAST && c_sc.tag_ok &&
-                    (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 28) &&
+                if (mode == MZ_MODE_FAST && c_sc.tag_ok && reach < (1LL << 28) &&
                     2 * K * (c_sc.maxS + c_sc.go) <= 32767)
                     mode = MZ_MODE_FASTT;
                 if (mode == MZ_MODE_FASTT && pk_ok && c_sc.pack_ok) mode = MZ_MODE_PACK;
@@ -191,10 +193,8 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                     }
                 }
                 // larger scores (C3: 10+10 rows): the 2^30 lift of the ring periods no longer fits, so the prefix
-                // maximum runs on lanes rotated to the band start instead.  Tagged states need |4*score| < 2^30;
-                // a path of at most M+N steps moves by at most K*L*(go + max(ge, max|score|)) per step.
-                if ((mode == MZ_MODE_FAST || mode == MZ_MODE_FASTT) && c_sc.row_on && c_sc.tag_ok &&
-                    (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * ((long long)M + N + 2) < (1LL << 28)) {
+                // maximum runs on lanes rotated to the band start instead.  Tagged states need |4*score| < 2^30.
+                if ((mode == MZ_MODE_FAST || mode == MZ_MODE_FASTT) && c_sc.row_on && c_sc.tag_ok && reach < (1LL << 28)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROWR;
                         edgeLo = rL; edgeHi = rN;
