@@ -27,9 +27,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# HBM bytes of one k_dp_fast launch on the default c2 batch from the PMC passes in profiles/
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950 note in
-# MI355X_MICROARCH.md section HBM).  Measured, never estimated; valid for the default c2 batch only.
+# HBM bytes of one launch of the dominant kernel on the default c2 batch, from the PMC passes in profiles/
+# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs).  Measured, never estimated; valid for the default
+# c2 batch only.
 # k_dp_row on the c2 batch, profiles/r1e_pmc_summary.txt: FETCH_SIZE 359 496 KB (narrow coalesced reads are
 # counted at one half on gfx950: x2) + WRITE_SIZE 2 438 497 KB
 TRAFFIC_BYTES_PER_LAUNCH = (2 * 359496 + 2438497) * 1024
@@ -53,8 +53,8 @@ def fnv_rows(cols, om):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)    # (a step is ~6 ms; the pipeline's fill and drain cost ~2.5 ms per run)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=["c2", "c3"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
