@@ -23,6 +23,10 @@
 #include "../../include/mz_scores.h"
 #include "../../include/mz_multiz.h"
 #include "mz_py.h"
+#include <time.h>
+
+/* MZ_TIMING=1: phase times of a run on stderr */
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 __attribute__((noreturn)) void mz_fatalf(const char *fmt, ...);
 __attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o);
@@ -444,8 +448,16 @@ int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int rad
         free(chr);
         walk(&R, &wk1, &wk2, v, radius, min_output_wid);
     }
-    run_merges(&R);
-    replay(&R, out, out1, out2, min_output_wid);
+    {
+        const int timing = getenv("MZ_TIMING") != NULL, nmerge = R.nmg;
+        const double t0 = now_s();
+        double t1, t2;
+        run_merges(&R);
+        t1 = now_s();
+        replay(&R, out, out1, out2, min_output_wid);
+        t2 = now_s();
+        if (timing) fprintf(stderr, "mz_multiz: %d merges; yama batches + stage 2/3 %.3f s, replay %.3f s\n", nmerge, t1 - t0, t2 - t1);
+    }
     return 0;
 }
 
@@ -494,10 +506,17 @@ int mz_multiz_main(int argc, char **argv)
     if (v != 0 && v != 1) mz_fatalf("v can only be value of 0, 1 ");
 
     if (!nohead) { fprintf(stdout, "##maf version=1 scoring=%s\n", "multiz"); printf("# %s\n", args); }
-    init_scores70();
-    l1 = mz_maf_read_all(argv[1], 1);
-    l2 = mz_maf_read_all(argv[2], 1);
-    mz_multiz_lists(&l1, &l2, v, radius, minw, stdout, f1, f2);
+    {
+        const double t0 = now_s();
+        double t1, t2;
+        init_scores70();
+        l1 = mz_maf_read_all(argv[1], 1);
+        l2 = mz_maf_read_all(argv[2], 1);
+        t1 = now_s();
+        mz_multiz_lists(&l1, &l2, v, radius, minw, stdout, f1, f2);
+        t2 = now_s();
+        if (getenv("MZ_TIMING")) fprintf(stderr, "mz_multiz: read %.3f s, walk + merges + replay %.3f s\n", t1 - t0, t2 - t1);
+    }
 
     for (a = l1; a; a = a->next)                            /* contigs that only one file has */
         if (f1 && (row2 == 0 || a->components->next != NULL)) mafWrite(f1, a);
