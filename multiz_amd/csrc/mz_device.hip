@@ -73,6 +73,13 @@ __device__ __forceinline__ int dot2_keep(int a, int b, int acc)
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
     return d;
 }
+// the same with the row vector in a scalar register
+__device__ __forceinline__ int dot2_keep_s(int a, int b, int acc)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(acc));
+    return d;
+}
 // lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1)
 __device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }
 
@@ -1457,8 +1464,8 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, i
     // column left the band: take column c+64.  Neither (r-1, c+64) nor (r-1, c+63) was in row r-1's band
     // (its width is at most 63), so a re-armed lane's C and D are sentinels in this row: instead of resetting
     // its "up" and "diagonal" registers, the lane is masked out of C and D below.
-    const bool fresh = S.c32 < R_lo32(R);
-    if (fresh) {
+    const bool stays = S.c32 >= R_lo32(R);             // (one compare: the re-arm below runs on its complement)
+    if (!stays) {
         S.c32 += 32 * WAVE;
         row_load_col(S, s_ring);
     }
@@ -1497,7 +1504,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, i
         nD = ((mD & ~3) | TD) - R_cDe(R);
     }
     const bool active = (unsigned)(c32 - R_lo32(R)) <= (unsigned)R_wid32(R);
-    const bool activeCD = active && !fresh;
+    const bool activeCD = active && stays;
     nC = activeCD ? nC : NEGT + 2;
     nD = activeCD ? nD : NEGT + TD;
 
@@ -1505,7 +1512,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, i
     // Lanes right of the band need no masking here: they come last in ring order.
     const int lC = ror1(nC), lD = ror1(nD);
     x = dot2_keep(R_rIx(R), uA, lC);                   // lC, lD, lI stay live: they are row r+1's diagonal
-    y = dot2_keep(EDGE ? R.d.x : J.rIy, uA, lD);
+    y = EDGE ? dot2_keep(R.d.x, uA, lD) : dot2_keep_s(J.rIy, uA, lD);
     const int base = max(x, y);
     int g, Pl;
     if (EDGE) {                                        // row M pays no gap-open (mz_yama.c:123): Q instead of P
@@ -1527,7 +1534,7 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, i
     }
     nI = active ? g + Pl : NEGT + TI;
     const int lI = ror1(nI);
-    z = dot2_keep(EDGE ? R.d.y : J.rIz, uA, lI);
+    z = EDGE ? dot2_keep(R.d.y, uA, lI) : dot2_keep_s(J.rIz, uA, lI);
     mI = max(base, z);
 
     S.p.C = nC; S.p.D = nD; S.p.I = nI;
@@ -1699,7 +1706,7 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
     }
 }
 
-__global__ __launch_bounds__(WAVE) void k_dp_row(mz_dev_batch b, int first, int count)
+__global__ __launch_bounds__(WAVE, 5) void k_dp_row(mz_dev_batch b, int first, int count)
 {
     __shared__ int4 s_ring[2 * FRING];                 // 4 KB: column records, 128-entry ring
     __shared__ int4 s_rec[WAVE * (RREC / 4)];          // 4 KB: row records of the current block of 64 rows
