@@ -176,32 +176,31 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 edgeLo = rL + 1;
                 edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
                 szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
-                if (mode == MZ_MODE_FASTT && c_sc.row_on &&
-                    (long long)K * L * (c_sc.go + c_sc.ge + 258) * ((long long)M + N + 2) < (1LL << 26) &&
-                    (long long)K * L * (c_sc.go + c_sc.ge) < (1LL << 20)) {
-                    if (row_ok) {
+                // Row-parallel kernels.  Their scores and running sums are re-based every 64 rows / columns, so what
+                // must fit is one window: ~320 steps of at most K*L*(go + max(ge, max|sigma|)) each, times 4 for the
+                // tags, within 2^27 (the ring lift is 2^30) -- whatever M and N are.
+                const bool fam = conn && c_sc.g1 > 0 && c_sc.tag_ok && c_sc.row_on;
+                if (fam && mode != MZ_MODE_PACK && (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 27)) {
+                    if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROW;
                         edgeLo = rL;                            // rows <= rL can hold column 0 or 1
                         edgeHi = rN;                            // rows >= rN hold column N
                         szTb = (long long)((M >> 4) + 1) * 3 * WAVE;
-                    } else if (2 * L * (c_sc.maxS + c_sc.go) <= 32767) {
+                    } else if (col_ok && 2 * L * (c_sc.maxS + c_sc.go) <= 32767) {
                         // the same kernel on the transposed problem (A and B, D and I exchanged): the band
                         // column by column must be at most 63 rows high
                         // (column c lies in rows r and r+63 iff LB[r+63] <= c <= RB[r]: checked in the row loop)
-                        const int cL = RB[1 < M ? 1 : M];       // last column whose first row is 0 or 1
-                        const int cN = LB[M];                   // first column that reaches row M
-                        if (col_ok) {
-                            mode = MZ_MODE_COL;
-                            edgeLo = cL;
-                            edgeHi = cN;
-                            szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
-                            szPrep = COL_PREP_DWORDS(N);
-                        }
+                        mode = MZ_MODE_COL;
+                        edgeLo = RB[1 < M ? 1 : M];             // last column whose first row is 0 or 1
+                        edgeHi = LB[M];                         // first column that reaches row M
+                        szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
+                        szPrep = COL_PREP_DWORDS(N);
                     }
                 }
-                // larger scores (C3: 10+10 rows): the 2^30 lift of the ring periods no longer fits, so the prefix
-                // maximum runs on lanes rotated to the band start instead.  Tagged states need |4*score| < 2^30.
-                if ((mode == MZ_MODE_FAST || mode == MZ_MODE_FASTT) && c_sc.row_on && c_sc.tag_ok && reach < (1LL << 28)) {
+                // more rows (K*L above ~200): one window no longer fits beside the 2^30 lift of the ring periods, so
+                // the prefix maximum runs on lanes rotated to the band start instead (same re-basing).
+                if (mode != MZ_MODE_ROW && mode != MZ_MODE_COL && mode != MZ_MODE_PACK && fam &&
+                    (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 29)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROWR;
                         edgeLo = rL; edgeHi = rN;
@@ -1378,7 +1377,8 @@ struct RowState {
 // band's left edge is in, see row_pre), built from the raw bytes of B (column vectors,
 // class counts, and the running sums P, Q of the max-plus recurrence, carried from chunk to chunk): ~100
 // instructions per 64 columns, cheaper than a round trip of 32 bytes per column through HBM.
-struct ColSrc { const uint8_t *B; int L, N, K4go, K4ge, g2, xI0, carryP, carryQ; };   // K4go = 4*K*go, xI0 = 4*go*K*L - TI
+struct ColSrc { const uint8_t *B; int L, N, K4go, K4ge, g2, xI0, carryP, carryQ; };   // K4go = 4*K*go, xI0 = 4*go*K*L - TI;
+                                                  // carryP/Q: running sums at the last staged column, relative to the current base (row_pre)
 __device__ __forceinline__ void row_stage_cols(int first, int lift, int lane, ColSrc &Z, int4 *ring)
 {
     const int cc = first + lane;
@@ -1544,7 +1544,8 @@ __device__ __forceinline__ void row_step(RowState &S, const RowRec &R, int s4, i
     S.wI = __builtin_amdgcn_alignbit(mI, S.wI, 2);
 }
 
-struct RowLoop { int next32, rcross; };                // 32 * first column of the next 64-column period; first staged row at or beyond it
+struct RowLoop { int next32, rcross; long long offset; };   // 32 * first column of the next 64-column period; first staged
+                                                            // row at or beyond it; what re-basing has taken off the scores (x4)
 
 // bookkeeping before a row (record R), one scalar compare per row.  When the band's left edge enters the next
 // 64-column period k: the ring's copy of period k (still "upper", unlifted) is lifted in place, period k+1 is
@@ -1562,22 +1563,44 @@ template <bool ROT>
 __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, int r, int lane, ColSrc &cols, const int4 *s_rec, int4 *s_ring)
 {
     if (r == Q.rcross) {                               // scalar compare: the row was located when the block was staged
-        if (!ROT) {
-            int2 *e = (int2 *)((char *)s_ring + (((Q.next32 >> 5) + lane) & (FRING - 1)) * 32 + 16);
-            int2 v = *e;
-            v.x -= ROW_LIFT; v.y -= ROW_LIFT;
-            *e = v;
-        }
+        // The running sums P, Q only ever enter as differences between columns of the same row, so they are
+        // re-based here: the sums at the first column of the new period k become the new zero (ring copy of
+        // period k, the lanes already holding its columns, the staging carry).  They stay within three periods'
+        // worth of steps whatever N is.
+        const int4 y0 = s_ring[2 * ((Q.next32 >> 5) & (FRING - 1)) + 1];     // {xI+P, P, c45, Q} of column 64k
+        const int dP = y0.y, dQ = y0.w, sub = dP + (ROT ? 0 : ROW_LIFT);
+        int4 *e = s_ring + 2 * (((Q.next32 >> 5) + lane) & (FRING - 1)) + 1;
+        int4 v = *e;
+        v.x -= sub; v.y -= sub; v.w -= dQ;
+        __syncthreads();                               // every lane has read column 64k's entry before it changes
+        *e = v;
+        cols.carryP -= __builtin_amdgcn_readfirstlane(dP);
+        cols.carryQ -= __builtin_amdgcn_readfirstlane(dQ);
         row_stage_cols((Q.next32 >> 5) + WAVE, 0, lane, cols, s_ring);
         __syncthreads();
-        if (!ROT) {
-            const int lift = ((S.c32 ^ Q.next32) >> 11) == 0 ? ROW_LIFT : 0;
-            S.Pl -= lift;
-            S.xIPl -= lift;
+        if (((S.c32 ^ Q.next32) >> 11) == 0) {         // lanes that already hold a column of period k
+            S.Pl -= sub; S.xIPl -= sub; S.Q -= dQ;
         }
         Q.next32 += 32 * WAVE;
         Q.rcross = row_find_cross(s_rec, (r - 1) >> 6, lane, Q.next32);
     }
+}
+
+// Scores only ever enter as differences too (every pick compares candidates that carry the same history), so
+// the frontier is re-based once per block of 64 rows: the best state of the wave becomes the new zero and the
+// amount goes into a 64-bit running offset.  Tagged int32 states then hold any length of alignment; what bounds
+// them is the score range of one 64-row window (k_plan).  Sentinels are left alone.
+#define ROW_REBASE_FLOOR (-(1 << 30))
+__device__ __forceinline__ int rebase1(int v, int d) { return v > ROW_REBASE_FLOOR ? v - d : v; }
+__device__ __forceinline__ void row_rebase(RowState &S, RowLoop &Q)
+{
+    int m = max(max(S.p.C, S.p.D), S.p.I);
+    m = prefix_max64(m);
+    const int d = __builtin_amdgcn_readlane(m, WAVE - 1) & ~3;
+    if (d <= ROW_REBASE_FLOOR) return;                  // (no reachable state in the frontier: cannot happen in a connected band)
+    S.p.C = rebase1(S.p.C, d); S.p.D = rebase1(S.p.D, d); S.p.I = rebase1(S.p.I, d);
+    S.l.C = rebase1(S.l.C, d); S.l.D = rebase1(S.l.D, d); S.l.I = rebase1(S.l.I, d);
+    Q.offset += d;
 }
 
 __device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int r, int lane)
@@ -1597,6 +1620,7 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
     r1 = __builtin_amdgcn_readfirstlane(r1);
     for (int r = r0; r <= r1; ) {
         if (((r - 1) & (WAVE - 1)) == 0 && r > 1) {    // first row of a block: every record of the block before is consumed
+            row_rebase(S, Q);
             __syncthreads();
             row_stage_rows((r - 1) >> 6, lane, src, s_rec);
             __syncthreads();
@@ -1670,7 +1694,7 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
 #undef UNI
 
     RowLoop Q;
-    Q.next32 = 32 * WAVE;
+    Q.next32 = 32 * WAVE; Q.offset = 0;
     row_stage_cols(0, ROT ? 0 : ROW_LIFT, lane, cols, s_ring);
     row_stage_cols(WAVE, 0, lane, cols, s_ring);
     row_stage_rows(0, lane, src, s_rec);
@@ -1700,9 +1724,9 @@ __device__ __forceinline__ void dp_row_body(const mz_dev_batch &b, int p, int la
         o[0] = S.wC >> sh; o[WAVE] = S.wD >> sh; o[2 * WAVE] = S.wI >> sh;
     }
     if (lane == (N & (WAVE - 1))) {                    // the reference's (C,D,I) at (M,N), unscaled
-        b.final3[3 * p + 0] = S.p.C >> 2;
-        b.final3[3 * p + 1] = (COL ? S.p.I : S.p.D) >> 2;
-        b.final3[3 * p + 2] = (COL ? S.p.D : S.p.I) >> 2;
+        b.final3[3 * p + 0] = (int)((S.p.C + Q.offset) >> 2);
+        b.final3[3 * p + 1] = (int)(((COL ? S.p.I : S.p.D) + Q.offset) >> 2);
+        b.final3[3 * p + 2] = (int)(((COL ? S.p.D : S.p.I) + Q.offset) >> 2);
     }
 }
 
