@@ -1245,18 +1245,19 @@ __device__ __forceinline__ void dp_tag_body(const mz_dev_batch &b, int p, int la
 // makes the band start at lane s = LB[r] & 63: lanes >= s (the lower ring period) are lifted by 2^30
 // so that they ignore lanes < s, and lanes < s (the wrapped tail) take the lower period's total from
 // lane 63.  Values are exact integers, so nI and all three pick flags (computed afterwards from the
-// final neighbours, as tag_step does) equal the wavefront kernel's.  Needs, beyond FASTT's conditions:
-// RB[r]-LB[r] <= 62 for every row, K*L*(go+ge+258)*(M+N+2) < 2^26 and K*L*(go+ge) < 2^20 (so that
-// |P| < 2^28 and the 2^30 lift separates the ring periods without overflow).
+// final neighbours, as tag_step does) equal the wavefront kernel's.
+// Scores and running sums are re-based as the kernel advances (row_rebase, row_pre), so the tagged int32
+// states hold alignments of any length; the conditions (k_plan) are a connected band, int16 row vectors,
+// RB[r]-LB[r] <= 62 for every row and one 64-row WINDOW of scores within 2^27 beside the 2^30 lift.
+// ROT variants (MZ_MODE_ROWR/COLR, more rows per block): no lift; the candidates are rotated with
+// ds_bpermute so that the band starts at lane 0, scanned and rotated back.
 // Traceback: 2-bit tag streams per lane as in FASTT, but one entry per ROW:
 //     tbw[((r>>4)*3 + s)*64 + (c & 63)], bits 2*(r&15).
-// ------------------------------------------------------------------------------------------
-// Work split: k_rowprep (one wave per pair, ahead of the DP) writes one 16-dword record per row of A
-// and one 8-dword record per column of B (with the running sums P, Q) to the pair's slice of b.prep.
-// k_dp_row then does nothing but the DP: the row record is uniform across the wave, so it is read with
-// scalar loads into SGPRs (no LDS traffic, no vector registers) one row ahead; column records are copied
-// 64 at a time into a 128-entry LDS ring from which a lane re-arms.  4 KB of LDS and ~64 VGPRs per wave:
-// eight waves per SIMD, which matters because the loop is latency-bound, not issue-bound, below that.
+// Everything is built inside the kernel from the raw column bytes: row records (16 dwords) 64 rows at a
+// time into a 4 KB LDS block that every lane reads back (broadcast) one row ahead; column records (8 dwords)
+// 64 columns at a time into a 128-entry LDS ring from which a lane re-arms.  k_rowprep only scatters the
+// transposed band bounds of the COL pairs.  (Earlier versions read prep records from HBM with scalar loads:
+// see DESIGN.md section 4.2 for why that lost.)
 // ------------------------------------------------------------------------------------------
 #define ROW_LIFT (1 << 30)
 
