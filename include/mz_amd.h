@@ -67,7 +67,7 @@ enum {
  *           below 2^29 -- where guards that can only touch unreachable (sentinel) states are
  *           dropped; outputs are identical ("fast path equivalence") */
 enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 /* FAST with tag-encoded picks */,
-       MZ_MODE_PACK = 4 /* FASTT arithmetic, four pairs per wave (16 lanes x 3 rows each) */,
+       MZ_MODE_RESERVED4 = 4 /* (was an experimental four-pairs-per-wave kernel; removed) */,
        MZ_MODE_ROW = 5 /* FASTT arithmetic, lane = column, one band row per iteration (bands <= 63 wide) */,
        MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */,
        MZ_MODE_ROWR = 7, MZ_MODE_COLR = 8 /* ROW / COL for scores too large for the 2^30 ring lift: the prefix
@@ -90,14 +90,14 @@ typedef struct mz_dev_batch {
     int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
-    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] packed pairs */
-    int32_t *packList;     /* indices of the MZ_MODE_PACK pairs, in batch order (n entries)           */
+    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5..7] spare */
+    int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */
     uint32_t *tbw;
     uint8_t  *script;
     uint8_t  *out;
-    uint32_t *prep;        /* packed kernel only: precomputed row records and column entries          */
+    uint32_t *prep;        /* MZ_MODE_COL / COLR pairs: the band column by column (2 ints per column)   */
     int64_t capTb, capScript, capOut, capPrep;     /* capacities in the same units as the sizes */
     int32_t *om;           /* OM per pair                          */
     int32_t *final3;       /* C,D,I at (M,N), 3 per pair           */
@@ -108,7 +108,7 @@ typedef struct mz_score_model {
     int32_t gap_open;      /* the single non-zero value of gop[] (mz_scores.c:78-79)              */
     int32_t gap_extend;
     int32_t g1, g2;        /* gap_open = g1*g2 with both <= 258 (int16 dot-product operands); 0 = none */
-    int32_t pack;          /* 1: let the plan pick the experimental packed kernel (MZ_MODE_PACK)          */
+    int32_t pack;          /* spare                                                                       */
     int32_t row;           /* 1 (default): let the plan pick the row-parallel kernel (MZ_MODE_ROW)        */
 } mz_score_model;
 
@@ -132,10 +132,6 @@ int  mz_set_scores(const int *ss_flat, const int *gop16, int gap_extend);
 /* 0: run every pair on the exact kernels (all guards of mz_yama.c evaluated literally); 1 (default):
  * let the plan pick the fast kernel for well-formed pairs.  Outputs are identical either way. */
 void mz_enable_fast(int on);
-/* 1: allow the experimental packed kernel (four pairs per wave; MZ_MODE_PACK) for eligible pairs.  Off by
- * default: on MI355X it is slower than the one-pair-per-wave kernels.  MZ_PACK=1 in the
- * environment has the same effect.  Outputs are identical either way. */
-void mz_enable_pack(int on);
 /* 0: keep the plan from choosing the row-parallel kernel (MZ_MODE_ROW; default on; MZ_NO_ROW=1 in the
  * environment also disables it).  Outputs are identical either way. */
 void mz_enable_row(int on);

@@ -165,11 +165,8 @@ class DevBatch:
         self.tbw = torch.empty(tb + 64, dtype=torch.int32, device=self.dev)
         self.script = torch.empty(sc + 64, dtype=torch.uint8, device=self.dev)
         self.out = torch.empty(ou + 64, dtype=torch.uint8, device=self.dev)
-        # row records + column records of the row-parallel / packed kernels (k_plan's szPrep, rounded up)
-        # prep: transposed band bounds of the COL pairs (2 ints per column); the opt-in packed kernel wants its
-        # row/column records (20 dwords per padded row + 7 per padded column)
-        mx = np.maximum(M, N)
-        pr = int(((((mx + 47) // 48) * 48 + 96) * 20 + 8 * (((mx + 127) // 64) * 64 + 128) + 64).sum())
+        # prep: the transposed band bounds of the MZ_MODE_COL pairs, 2 ints per column (k_plan's szPrep, rounded up)
+        pr = int((2 * (N + 1) + 64).sum())
         self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)
         self.c.tbw, self.c.script, self.c.out, self.c.prep = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr(), self.prep.data_ptr()
         self.c.capTb, self.c.capScript, self.c.capOut, self.c.capPrep = tb + 64, sc + 64, ou + 64, pr + 64

@@ -36,7 +36,7 @@
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
 #define COL_PREP_DWORDS(N) (2LL * ((N) + 1))           // transposed band bounds of a COL pair
 
-struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int pack_ok; int row_on; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
         else {
             const int need = N < 10 ? N : 10;
             int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
-            int wf_ok = 1, conn = 1, pk_ok = 1, row_ok = 1, col_ok = 1;
+            int wf_ok = 1, conn = 1, row_ok = 1, col_ok = 1;
             int rL = 0, rN = M;             // last row with LB[r] <= 1, first row with RB[r] == N
             for (int r = lane; r <= M; r += WAVE) {
                 const int lo = LB[r], hi = RB[r];
@@ -142,14 +142,12 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 // neighbour's row r+65 need it: RB[r] - LB[r+64] <= 62
                 if (r + WAVE <= M && hi - LB[r + WAVE] > 62) wf_ok = 0;
                 if (r > 0 && lo > RB[r-1]) conn = 0;          // row r would not touch row r-1's band
-                if (r + 46 <= M && hi - LB[r + 46] > 44) pk_ok = 0;   // packed kernel: 48 rows in flight per pair
                 if (hi - lo > 62) row_ok = 0;                  // row-parallel kernel: one row of the band per wave
                 if (r + 63 <= M && LB[r + 63] <= hi) col_ok = 0;   // transposed: a column would span 64 rows
                 if (lo <= 1) rL = max(rL, r);
                 if (hi == N) rN = min(rN, r);
             }
             conn = wave_min(conn);
-            pk_ok = wave_min(pk_ok);
             row_ok = wave_min(row_ok);
             col_ok = wave_min(col_ok);
             rL = -wave_min(-rL);
@@ -172,7 +170,6 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 if (mode == MZ_MODE_FAST && c_sc.tag_ok && reach < (1LL << 28) &&
                     2 * K * (c_sc.maxS + c_sc.go) <= 32767)
                     mode = MZ_MODE_FASTT;
-                if (mode == MZ_MODE_FASTT && pk_ok && c_sc.pack_ok) mode = MZ_MODE_PACK;
                 edgeLo = rL + 1;
                 edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
                 szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 // must fit is one window: ~320 steps of at most K*L*(go + max(ge, max|sigma|)) each, times 4 for the
                 // tags, within 2^27 (the ring lift is 2^30) -- whatever M and N are.
                 const bool fam = conn && c_sc.g1 > 0 && c_sc.tag_ok && c_sc.row_on;
-                if (fam && mode != MZ_MODE_PACK && (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 27)) {
+                if (fam && (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 27)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROW;
                         edgeLo = rL;                            // rows <= rL can hold column 0 or 1
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 }
                 // more rows (K*L above ~200): one window no longer fits beside the 2^30 lift of the ring periods, so
                 // the prefix maximum runs on lanes rotated to the band start instead (same re-basing).
-                if (mode != MZ_MODE_ROW && mode != MZ_MODE_COL && mode != MZ_MODE_PACK && fam &&
+                if (mode != MZ_MODE_ROW && mode != MZ_MODE_COL && fam &&
                     (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 29)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROWR;
@@ -211,10 +208,6 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                         szTb = (long long)((N >> 4) + 1) * 3 * WAVE;
                         szPrep = COL_PREP_DWORDS(N);
                     }
-                }
-                if (mode == MZ_MODE_PACK) {
-                    szTb = (long long)(((M + N) >> 4) + 1) * 144;
-                    szPrep = (long long)(((M + 47) / 48) * 48 + 96) * 16 + 6LL * (((N + 1 + 63) / 64) * 64 + 64);
                 }
             } else {
                 mode = MZ_MODE_STRIP;
@@ -249,7 +242,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
     }
 }
 
-// Exclusive prefix sums of the per-pair sizes, the failure count and the list of packed-kernel pairs.
+// Exclusive prefix sums of the per-pair sizes and the failure count.
 // Three small launches: per-block totals, scan of the block totals, per-block scan + write.
 #define SCAN_Q 6
 #define SCAN_B 256          // small blocks: these kernels run beside the DP and must fit into whatever slots are free
@@ -258,7 +251,7 @@ __device__ __forceinline__ void scan_load(const mz_dev_batch &b, int i, long lon
     if (i < b.n) {
         const bool ok = b.status[i] == MZ_OK;
         v[0] = b.szTb[i]; v[1] = b.szScript[i]; v[2] = b.szOut[i]; v[3] = b.szPrep[i];
-        v[4] = !ok; v[5] = ok && b.mode[i] == MZ_MODE_PACK;
+        v[4] = !ok; v[5] = 0;                            // (sixth sequence: spare)
     } else {
 #pragma unroll
         for (int q = 0; q < SCAN_Q; ++q) v[q] = 0;
@@ -302,7 +295,7 @@ __global__ __launch_bounds__(64) void k_scan2(mz_dev_batch b, int nblk)
     if (q >= SCAN_Q) return;
     long long run = 0;
     for (int k = 0; k < nblk; ++k) { const long long y = b.scanAux[(long long)k * SCAN_Q + q]; b.scanAux[(long long)k * SCAN_Q + q] = run; run += y; }
-    b.totals[q == 4 ? 3 : q == 5 ? 5 : q == 3 ? 4 : q] = run;      // [0..2] tb/script/out, [3] failed, [4] prep, [5] packed pairs
+    b.totals[q == 4 ? 3 : q == 5 ? 5 : q == 3 ? 4 : q] = run;      // [0..2] tb/script/out, [3] failed, [4] prep, [5] spare
 }
 __global__ __launch_bounds__(SCAN_B) void k_scan3(mz_dev_batch b)
 {
@@ -314,7 +307,6 @@ __global__ __launch_bounds__(SCAN_B) void k_scan3(mz_dev_batch b)
     if (i >= b.n) return;
     const int64_t *base = b.scanAux + (long long)blockIdx.x * SCAN_Q;
     b.offTb[i] = base[0] + ex[0]; b.offScript[i] = base[1] + ex[1]; b.offOut[i] = base[2] + ex[2]; b.offPrep[i] = base[3] + ex[3];
-    if (v[5]) b.packList[base[5] + ex[5]] = i;
 }
 
 // after the scan: a pair whose slices do not fit the caller's workspace is failed, loudly
@@ -1745,495 +1737,6 @@ __global__ __launch_bounds__(WAVE, 5) void k_dp_row(mz_dev_batch b, int first, i
 }
 
 // ------------------------------------------------------------------------------------------
-// packed kernel (MZ_MODE_PACK): FOUR block pairs per wave, 16 lanes per pair, 3 DP rows per lane.
-//
-// Why: one wave already saturates its SIMD's VALU pipe and a radius-30 band has only ~31-34 rows
-// live on an anti-diagonal, so the one-pair-per-wave kernels leave half the lanes computing
-// throw-away cells.  Here a pair gets 48 row slots (16 lanes x 3 consecutive rows), i.e. ~2/3 of
-// the slots are live, and the lane-to-lane DPP hand-over is paid once per three cells.
-//
-// Lane li (0..15) of a group owns row blocks q = li, li+16, ... (rows 3q+1..3q+3; row 0 rides as
-// the last row of a virtual block -1 on lane 15).  Within a lane row j reads "row above" from
-// row j-1's registers; row 0 of the lane gets it from the previous lane's last row by DPP
-// row_ror:1.  Arithmetic, tags and traceback streams are those of the tagged fast kernel.
-//
-// With four pairs' state in LDS only one wave fits per SIMD, so nothing may stall it: a parallel
-// pre-pass kernel (k_prep) writes every row record and column entry to HBM once, and this kernel
-// pulls them into LDS with asynchronous global_load_lds (row records: per-lane slot for the
-// lane's NEXT block, issued when the current block is armed, ~100 steps ahead; column entries:
-// 64 columns per group, one block ahead).  Arrival is confirmed by data (row tag / cleared word),
-// never by a blanket vmcnt wait.
-// ------------------------------------------------------------------------------------------
-#define PK_R   3                  // rows per lane
-#define PK_H   48                 // rows per pair in flight = rows per super-block
-#define PK_RING 128               // column ring entries per pair (6 dword arrays)
-#define PK_REC 16                 // dwords per row record (4 x 16 B)
-
-struct PackRow {
-    int lo4, wid4, rIx, rIy, rIz, rCxA, rCxB, rCy, rCz, rDx, cDe, penDye, w01, w23, w45;
-    int nd;                       // nA | dA << 16 (never 0: doubles as the arrival word); EDGE derives kC, extD from it
-};
-
-// ---- pre-pass: row records (rows 1..Mpad, dead beyond M) and column entries (0..Npad-1) of a pair
-__global__ __launch_bounds__(WAVE) void k_prep(mz_dev_batch b)
-{
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (b.status[p] != MZ_OK || b.mode[p] != MZ_MODE_PACK) return;
-    const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p];
-    const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
-    const int *LB = b.poolLB + b.offBand[p], *RB = b.poolRB + b.offBand[p];
-    const int Mpad = ((M + 47) / 48) * 48 + 96, Npad = ((N + 1 + 63) / 64) * 64 + 64;
-    int4 *recs = (int4 *)(b.prep + b.offPrep[p]);
-    int *cols = (int *)(b.prep + b.offPrep[p] + (long long)Mpad * PK_REC);
-    const int go = c_sc.go, ge = c_sc.ge, g1 = 2 * c_sc.g1, g2 = 2 * c_sc.g2;
-
-    for (int rr = 1 + lane; rr <= Mpad; rr += WAVE) {
-        int4 *d = recs + (long long)(rr - 1) * 4;
-        if (rr > M) {
-            d[0] = make_int4(MZ_BIG, 0, 0, 0);
-            d[1] = d[2] = make_int4(0, 0, 0, 0);
-            d[3] = make_int4(0, 0, 0, 0x7fff7fff);
-            continue;
-        }
-        const uint8_t *col = A + (long long)(rr - 1) * K;
-        unsigned cnt = 0;
-        int dA = 0, a00 = 0, a11 = 0, other = 0;
-        for (int i = 0; i < K; ++i) {
-            const unsigned ch = col[i];
-            const bool dash = ch == '-';
-            const bool pdash = (rr > 1) ? (col[i - K] == '-') : false;
-            const int cl = byte_class(ch);
-            cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
-            other += cl == 5;
-            dA += dash;
-            a00 += (!dash) & (!pdash);
-            a11 += dash & pdash;
-        }
-        const int nA = K - dA;
-        int cn[6] = { (int)(cnt & 0xff), (int)((cnt >> 8) & 0xff), (int)((cnt >> 16) & 0xff), (int)(cnt >> 24), dA, other };
-        int w[6];
-#pragma unroll
-        for (int l = 0; l < 6; ++l) {
-            int acc = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc += cn[k] * c_sc.S6[k * 6 + l];
-            w[l] = 2 * (acc - go * dA);
-        }
-        const bool last = rr >= M;
-        const int lo = LB[rr], hi = RB[rr];
-        d[0] = make_int4(4 * lo, 4 * (hi - lo), last ? 0 : pack2(-K * g1, -dA * g1), last ? 0 : pack2(-K * g1, 0));
-        d[1] = make_int4(last ? 0 : pack2(-K * g1, -K * g1), pack2((nA - dA) * g1, -a11 * g1), pack2(-a00 * g1, 0),
-                         pack2((nA - a00 - dA) * g1, 0));
-        d[2] = make_int4(pack2((nA - dA) * g1, -dA * g1), pack2(-a00 * g1, 0), 4 * (go + ge) * nA * L,
-                         4 * (go * L * (nA - a00) + ge * L * nA));
-        d[3] = make_int4(pack2(w[0], w[1]), pack2(w[2], w[3]), pack2(w[4], w[5]), nA | (dA << 16));
-    }
-    for (int cc = lane; cc < Npad; cc += WAVE) {
-        int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 4 * go * K * L - 1;
-        if (cc >= 1 && cc <= N) {
-            const uint8_t *col = B + (long long)(cc - 1) * L;
-            unsigned cnt = 0;
-            int dB = 0, b00 = 0, b11 = 0, other = 0;
-            for (int j = 0; j < L; ++j) {
-                const unsigned ch = col[j];
-                const bool dash = ch == '-';
-                const bool pdash = (cc > 1) ? (col[j - L] == '-') : false;
-                const int cl = byte_class(ch);
-                cnt += (cl < 4) ? (1u << (cl << 3)) : 0u;
-                other += cl == 5;
-                dB += dash;
-                b00 += (!dash) & (!pdash);
-                b11 += dash & pdash;
-            }
-            e0 = pack2(-g2 * dB, -g2 * b00);
-            e1 = pack2(-g2 * b11, 0);
-            e2 = pack2(2 * (cnt & 0xff), 2 * ((cnt >> 8) & 0xff));
-            e3 = pack2(2 * ((cnt >> 16) & 0xff), 2 * (cnt >> 24));
-            e4 = pack2(2 * dB, 2 * other);
-            e5 += 4 * ge * K * (L - dB);
-        }
-        cols[cc] = e0; cols[Npad + cc] = e1; cols[2 * Npad + cc] = e2;
-        cols[3 * Npad + cc] = e3; cols[4 * Npad + cc] = e4; cols[5 * Npad + cc] = e5;
-    }
-}
-
-typedef const void __attribute__((address_space(1))) *gptr_t;
-typedef void __attribute__((address_space(3))) *lptr_t;
-// lane i <- lane i-1 within each group of 16 lanes, lane 0 <- lane 15 (DPP row_ror:1)
-__device__ __forceinline__ int rror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x121, 0xF, 0xF, false); }
-
-struct PackState {
-    PackRow R[PK_R];
-    Tri X[PK_R], Y[PK_R];         // row states: alternately "after the previous step" / "two steps ago -> new"
-    Tri u0, u1;                   // previous lane's last row: alternately one / two steps ago
-    unsigned w[PK_R][3];          // 2-bit flag streams per row: C, D, I picks
-    int r4;                       // 4 * first row of the lane's current block
-    int q;                        // the lane's current block (rows 3q+1..3q+3); -1 = the row-0 block
-    int thr4;                     // 4 * (next column at which this group's ring needs service), BIG when done
-    int nbR, nbO;                 // column blocks requested / confirmed so far for this group
-    int N4;                       // 4 * N of this lane's pair
-    int Tend;                     // last step of this lane's pair (0 for an empty group)
-    int M, goL4, geL4, kI4;       // EDGE only: rows, 4*go*L, 4*ge*L, 4*go*K*L of this lane's pair
-};
-
-// one cell of the packed kernel: exactly the tagged cell.  row = DP row of the cell (EDGE only)
-struct ColEnt { int uA, uB, c01, c23, c45, xI; };
-__device__ __forceinline__ ColEnt pack_col(const int *ring, int c4)
-{
-    const int *e = (const int *)((const char *)ring + (c4 & (4 * PK_RING - 4)));
-    ColEnt v;
-    v.uA = e[0]; v.uB = e[PK_RING]; v.c01 = e[2 * PK_RING]; v.c23 = e[3 * PK_RING]; v.c45 = e[4 * PK_RING]; v.xI = e[5 * PK_RING];
-    return v;
-}
-
-template <bool EDGE>
-__device__ __forceinline__ void pack_cell(const PackRow &R, const PackState &S, int row, int c4, const ColEnt &E,
-                                          const Tri &left, const Tri &up, const Tri &dg, Tri &out,
-                                          unsigned &wC, unsigned &wD, unsigned &wI)
-{
-    const int uA = E.uA, uB = E.uB, c01 = E.c01, c23 = E.c23, c45 = E.c45, xI = E.xI;
-    int x, y, z, mI, mC, mD, nI, nC, nD;
-
-    x = dot2(R.rIx, uA, left.C);
-    y = dot2(R.rIy, uA, left.D);
-    z = dot2(R.rIz, uA, left.I);
-    mI = max(max(x, y), z);
-    nI = (mI & ~3) - xI;
-    if (EDGE) nI += (row == 0 || row == S.M) ? S.kI4 : 0;             // rows 0 and M pay no gap-open (mz_yama.c:123)
-
-    x = dot2(R.rCxB, uB, dot2(R.rCxA, uA, dg.C));
-    y = dot2(R.rCy, uA, dg.D);
-    z = dot2(R.rCz, uA, dg.I);
-    if (EDGE) {
-        const bool g = c4 > 4;                                        // no gap-open entering column 1 (mz_yama.c:173)
-        x = g ? x : dg.C; y = g ? y : dg.D; z = g ? z : dg.I;
-        mC = max(max(x, y), z);
-        nC = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, (mC & ~3) | 2))) + (g ? 0 : S.goL4 * (R.nd >> 16));
-    } else {
-        mC = max(max(x, y), z);
-        nC = dot2(R.w01, c01, dot2(R.w23, c23, dot2(R.w45, c45, (mC & ~3) | 2)));
-    }
-
-    if (EDGE) {
-        const bool g = (c4 > 0) & (c4 < S.N4);                        // none in column 0 or N (mz_yama.c:211)
-        const int extD = S.geL4 * (R.nd & 0xffff);
-        x = dot2(R.rDx, uA, up.C - (R.cDe - extD));
-        y = up.D - (R.penDye - extD);
-        z = up.I - (R.cDe - extD);
-        x = g ? x : up.C; y = g ? y : up.D; z = g ? z : up.I;
-        mD = max(max(x, y), z);
-        nD = (mD & ~3) - extD;
-    } else {
-        x = dot2(R.rDx, uA, up.C - R.cDe);
-        y = up.D - R.penDye;
-        z = up.I - R.cDe;
-        mD = max(max(x, y), z);
-        nD = mD & ~3;
-    }
-    const bool active = (unsigned)(c4 - R.lo4) <= (unsigned)R.wid4;
-    out.C = active ? nC : NEGT + 2;
-    out.D = active ? nD : NEGT;
-    out.I = active ? nI : NEGT + 1;
-    if (EDGE && row == 0) { out.C = NEGT + 2; out.D = NEGT; }        // row 0: C = D = NEG (mz_yama.c:83-94)
-    wC = __builtin_amdgcn_alignbit(mC, wC, 2);
-    wD = __builtin_amdgcn_alignbit(mD, wD, 2);
-    wI = __builtin_amdgcn_alignbit(mI, wI, 2);
-}
-
-// LDS read the compiler does not order against outstanding global_load_lds traffic (it would otherwise put
-// s_waitcnt vmcnt(0) in front: the arrival of these bytes was already confirmed through the flag word)
-__device__ __forceinline__ void lds_read_rec(const int4 *rec, int4 &a, int4 &b, int4 &c, int4 &d)
-{
-    const unsigned addr = (unsigned)(unsigned long long)(lptr_t)rec;
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr) : "memory");
-}
-
-__device__ __forceinline__ void pack_load_row(PackRow &R, const int4 *rec)
-{
-    int4 a, b, c, d;
-    lds_read_rec(rec, a, b, c, d);
-    R.lo4 = a.x; R.wid4 = a.y; R.rIx = a.z; R.rIy = a.w;
-    R.rIz = b.x; R.rCxA = b.y; R.rCxB = b.z; R.rCy = b.w;
-    R.rCz = c.x; R.rDx = c.y; R.cDe = c.z; R.penDye = c.w;
-    R.w01 = d.x; R.w23 = d.y; R.w45 = d.z; R.nd = d.w;
-}
-
-// Row records are consumed strictly in row order (blocks are armed in order), so each pair keeps a FIFO of
-// two 12-row chunks (4 blocks each) in LDS: chunk c = rows 12c+1..12c+12 lives in half (c & 1).
-#define PK_CH 12
-// asynchronously copy chunk c of a pair (768 contiguous bytes = 48 x 16 B) into its half of the FIFO
-__device__ __forceinline__ void pack_request_chunk(const int4 *grecs, int c, int4 *fifo, int lane)
-{
-    int4 *dst = fifo + (c & 1) * (PK_CH * 4);
-    ((volatile int *)dst)[PK_CH * 16 - 1] = 0;         // arrival word: nd of the chunk's last record (never 0 in HBM)
-    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
-    if (lane < PK_CH * 4)
-        __builtin_amdgcn_global_load_lds((gptr_t)(grecs + (long long)c * (PK_CH * 4) + lane), (lptr_t)dst, 16, 0, 0);
-}
-__device__ __forceinline__ void pack_confirm_chunk(int c, int4 *fifo, int *errflag)
-{
-    const volatile int *flag = (const volatile int *)(fifo + (c & 1) * (PK_CH * 4)) + (PK_CH * 16 - 1);
-    for (int spin = 0; *flag == 0; ++spin) {
-        if (spin > (1 << 22)) { *errflag = MZ_E_TRACEBACK; break; }                // never hang the GPU
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-
-__device__ __forceinline__ const int4 *uniform_ptr(const int4 *p, int srclane)
-{
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)p, srclane);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)p >> 32), srclane);
-    return (const int4 *)(((unsigned long long)hi << 32) | lo);
-}
-
-// one step of all four pairs.  X = states after the previous step, Y = states two steps ago (overwritten
-// with the new ones); Un receives the previous lane's last row of the previous step, Uo holds the one before.
-template <bool EDGE>
-__device__ __forceinline__ void pack_step(PackState &S, Tri (&X)[PK_R], Tri (&Y)[PK_R], Tri &Un, const Tri &Uo, int t,
-                                          int lane, const int4 *recs, const int *cols, int Npad,
-                                          int4 *rowsAll, int *ring, int *ringAll, uint32_t *tbp, int *errflag)
-{
-    const int c4 = 4 * t - S.r4;                       // 4 * column of the lane's first row
-    // column entries of the three cells first: their LDS latency overlaps the bookkeeping below (a lane that
-    // re-arms in this step reads entries it will not use: its new rows are not live yet)
-    ColEnt E[PK_R];
-#pragma unroll
-    for (int j = 0; j < PK_R; ++j) E[j] = pack_col(ring, c4 - 4 * j);
-    Un.C = rror1(X[PK_R - 1].C); Un.D = rror1(X[PK_R - 1].D); Un.I = rror1(X[PK_R - 1].I);
-
-    // ---- a lane whose last row has computed its last cell takes its next block (rows + 48).  Blocks are
-    //      armed in order, at most one per pair per step; block q is read from the FIFO, chunk q/4.
-    const bool fin = c4 - 4 * (PK_R - 1) > S.R[PK_R - 1].lo4 + S.R[PK_R - 1].wid4;
-    const unsigned long long mfin = __ballot(fin);
-    if (mfin) {
-        for (unsigned long long m0 = mfin; m0;) {      // entering a chunk: it must have landed (requested 4+ blocks ago)
-            const int src = __ffsll((long long)m0) - 1, g = src >> 4;
-            m0 &= ~(0xFFFFULL << (16 * g));
-            const int q = __builtin_amdgcn_readlane(S.q, src) + 16;
-            if ((q & 3) == 0) pack_confirm_chunk(q >> 2, rowsAll + g * (2 * PK_CH * 4), errflag);
-        }
-        if (fin) {
-            S.q += 16;
-            const int4 *rec = rowsAll + (lane >> 4) * (2 * PK_CH * 4) + ((3 * S.q) % (2 * PK_CH)) * 4;
-#pragma unroll
-            for (int j = 0; j < PK_R; ++j) {
-                pack_load_row(S.R[j], rec + j * 4);
-                X[j].C = Y[j].C = NEGT + 2; X[j].D = Y[j].D = NEGT; X[j].I = Y[j].I = NEGT + 1;
-            }
-            S.r4 += 4 * PK_H;
-        }
-        for (unsigned long long m0 = mfin; m0;) {      // a chunk's last block has been read: refill its half
-            const int src = __ffsll((long long)m0) - 1, g = src >> 4;
-            m0 &= ~(0xFFFFULL << (16 * g));
-            const int q = __builtin_amdgcn_readlane(S.q, src);
-            if ((q & 3) == 3) pack_request_chunk(uniform_ptr(recs, src), (q >> 2) + 2, rowsAll + g * (2 * PK_CH * 4), lane);
-        }
-    }
-    const int c4n = 4 * t - S.r4;
-
-    // ---- this pair's column ring (128 entries): block k (columns 64k..64k+63) is requested when the lead
-    //      column reaches 64k-10 (by then the slots it overwrites are out of use: at most ~50 columns are
-    //      in flight) and confirmed just before the lead column enters it.  Wave-uniform loop over groups.
-    {
-        const bool want = (c4n >= S.thr4) & (c4n >= S.R[0].lo4);
-        unsigned long long m = __ballot(want);
-        while (m) {
-            const int hit = __ffsll((long long)m) - 1, g = hit >> 4;
-            m &= ~(0xFFFFULL << (16 * g));
-            const int src = g * 16;                    // any lane of the group carries its scalars
-            const int lead = __builtin_amdgcn_readlane(c4n, hit) >> 2;
-            int nbR = __builtin_amdgcn_readlane(S.nbR, src), nbO = __builtin_amdgcn_readlane(S.nbO, src);
-            const int npad = __builtin_amdgcn_readlane(Npad, src);
-            const int *gcols = (const int *)uniform_ptr((const int4 *)cols, src);
-            int *gring = ringAll + g * (6 * PK_RING);
-            if (nbO < nbR && lead >= nbO * WAVE - 1) {  // about to enter block nbO: it must have landed
-                const int lastc = (nbO * WAVE + WAVE - 1) & (PK_RING - 1);
-                for (int spin = 0; ((volatile int *)gring)[5 * PK_RING + lastc] == 0; ++spin) {
-                    if (spin > (1 << 22)) { *errflag = MZ_E_TRACEBACK; break; }    // never hang the GPU
-                    __builtin_amdgcn_s_sleep(4);
-                }
-                nbO += 1;
-            }
-            if (nbR * WAVE < npad && lead >= nbR * WAVE - 10) {
-                const int c0 = nbR * WAVE;
-                gring[5 * PK_RING + ((c0 + lane) & (PK_RING - 1))] = 0;            // arrival words (xI is never 0)
-                __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0)
-#pragma unroll
-                for (int f = 0; f < 6; ++f)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(gcols + (long long)f * npad + c0 + lane),
-                                                     (lptr_t)(gring + f * PK_RING + (c0 & (PK_RING - 1))), 4, 0, 0);
-                nbR += 1;
-            }
-            if ((lane >> 4) == g) {
-                S.nbR = nbR; S.nbO = nbO;
-                const int tR = nbR * WAVE < npad ? nbR * WAVE - 10 : MZ_BIG >> 2;
-                const int tO = nbO < nbR ? nbO * WAVE - 1 : MZ_BIG >> 2;
-                S.thr4 = 4 * min(tR, tO);
-            }
-        }
-    }
-
-    // ---- the three cells of this lane, last row first (row j reads row j-1's registers)
-    const int row0 = (S.r4 >> 2);
-#pragma unroll
-    for (int j = PK_R - 1; j >= 0; --j) {
-        const Tri &up = j ? X[j - 1] : Un;
-        const Tri &dg = j ? Y[j - 1] : Uo;
-        Tri nw;
-        pack_cell<EDGE>(S.R[j], S, row0 + j, c4n - 4 * j, E[j], X[j], up, dg, nw, S.w[j][0], S.w[j][1], S.w[j][2]);
-        Y[j] = nw;
-    }
-    if ((t & 15) == 15 && t <= S.Tend) {               // (a finished pair's slice must not be written past its end)
-        uint32_t *gp = tbp + (long long)(t >> 4) * (9 * 16);
-#pragma unroll
-        for (int j = 0; j < PK_R; ++j) {
-            gp[(j * 3 + 0) * 16] = S.w[j][0]; gp[(j * 3 + 1) * 16] = S.w[j][1]; gp[(j * 3 + 2) * 16] = S.w[j][2];
-        }
-    }
-}
-
-// a pair has just computed (M,N) at step t: flush its flag streams, publish (C,D,I)(M,N)
-#define PK_FINISH(Z, tt) do { \
-        if (((tt) & 15) != 15) { \
-            const int sh_ = 2 * (15 - ((tt) & 15)); \
-            uint32_t *gp_ = tbp + (long long)((tt) >> 4) * (9 * 16); \
-            gp_[0 * 16] = S.w[0][0] >> sh_; gp_[1 * 16] = S.w[0][1] >> sh_; gp_[2 * 16] = S.w[0][2] >> sh_; \
-            gp_[3 * 16] = S.w[1][0] >> sh_; gp_[4 * 16] = S.w[1][1] >> sh_; gp_[5 * 16] = S.w[1][2] >> sh_; \
-            gp_[6 * 16] = S.w[2][0] >> sh_; gp_[7 * 16] = S.w[2][1] >> sh_; gp_[8 * 16] = S.w[2][2] >> sh_; \
-        } \
-        if (finj == 0) { final3[0] = Z[0].C >> 2; final3[1] = Z[0].D >> 2; final3[2] = Z[0].I >> 2; } \
-        if (finj == 1) { final3[0] = Z[1].C >> 2; final3[1] = Z[1].D >> 2; final3[2] = Z[1].I >> 2; } \
-        if (finj == 2) { final3[0] = Z[2].C >> 2; final3[1] = Z[2].D >> 2; final3[2] = Z[2].I >> 2; \
-        } } while (0)
-
-template <bool EDGE>
-__device__ __forceinline__ void pack_steps(PackState &S, int t0, int t1, int te0, int te1, int te2, int te3, int Tend, int finj,
-                                           int lane, int *final3, int *errflag, const int4 *recs, const int *cols, int Npad,
-                                           int4 *s_rows, int *ring, int *s_ring, uint32_t *tbp)
-{
-    t0 = __builtin_amdgcn_readfirstlane(t0);
-    t1 = __builtin_amdgcn_readfirstlane(t1);
-    int t = t0;
-    // odd steps: X -> Y, u1 <- ; even steps: Y -> X, u0 <-
-#define PK_ODD(tt)  do { pack_step<EDGE>(S, S.X, S.Y, S.u1, S.u0, (tt), lane, recs, cols, Npad, s_rows, ring, s_ring, tbp, errflag); \
-                         if (((tt) == te0 || (tt) == te1 || (tt) == te2 || (tt) == te3) && (tt) == Tend) PK_FINISH(S.Y, (tt)); } while (0)
-#define PK_EVEN(tt) do { pack_step<EDGE>(S, S.Y, S.X, S.u0, S.u1, (tt), lane, recs, cols, Npad, s_rows, ring, s_ring, tbp, errflag); \
-                         if (((tt) == te0 || (tt) == te1 || (tt) == te2 || (tt) == te3) && (tt) == Tend) PK_FINISH(S.X, (tt)); } while (0)
-    if (!(t & 1) && t <= t1) { PK_EVEN(t); ++t; }
-    for (; t + 1 <= t1; t += 2) { PK_ODD(t); PK_EVEN(t + 1); }
-    if (t <= t1) PK_ODD(t);
-#undef PK_ODD
-#undef PK_EVEN
-}
-
-__global__ __launch_bounds__(WAVE, 1) void k_dp_pack(mz_dev_batch b)
-{
-    __shared__ __attribute__((aligned(16))) int4 s_rows[4 * 2 * PK_CH * 4];     // 6 KB: 4 pairs x FIFO of 2 chunks x 12 records
-    __shared__ __attribute__((aligned(16))) int  s_ring[4 * 6 * PK_RING];       // 24 KB
-
-    const int lane = threadIdx.x, grp = lane >> 4, li = lane & 15;
-    const int npack = (int)b.totals[5];
-    if (blockIdx.x * 4 >= npack) return;
-    const int slotp = blockIdx.x * 4 + grp;
-    const bool have = slotp < npack;
-    const int p = have ? b.packList[slotp] : b.packList[blockIdx.x * 4];
-    const int M = b.M[p], N = b.N[p];
-    const int Mpad = ((M + 47) / 48) * 48 + 96, Npad = ((N + 1 + 63) / 64) * 64 + 64;
-    const int4 *recs = (const int4 *)(b.prep + b.offPrep[p]);
-    const int *cols = (const int *)(b.prep + b.offPrep[p] + (long long)Mpad * PK_REC);
-    uint32_t *tbp = b.tbw + b.offTb[p] + li;
-    int *ring = s_ring + grp * (6 * PK_RING);
-    const int Tend = have ? M + N : 0;
-    int eLo = min(max(b.edgeLo[p], b.poolRB[b.offBand[p]] + 1), Tend);
-    int eHi = max(b.edgeHi[p], eLo + 1);
-    if (!have) { eLo = 0; eHi = MZ_BIG; }
-
-    PackState S;
-    S.N4 = 4 * N; S.Tend = Tend; S.M = M;
-    S.goL4 = 4 * c_sc.go * b.L[p]; S.geL4 = 4 * c_sc.ge * b.L[p]; S.kI4 = 4 * c_sc.go * b.K[p] * b.L[p];
-
-    // ---- prologue: column blocks 0 and 1 of every pair; the first 15 blocks of rows (rows 1..45) pass through
-    //      the FIFO in two rounds (chunks 0,1 then 2,3), after which chunk 4 is requested
-    for (int g = 0; g < 4; ++g) {
-        const int npad = __builtin_amdgcn_readlane(Npad, g * 16);
-        const int *gcols = (const int *)uniform_ptr((const int4 *)cols, g * 16);
-        int *gring = s_ring + g * (6 * PK_RING);
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int f = 0; f < 6; ++f)
-                __builtin_amdgcn_global_load_lds((gptr_t)(gcols + (long long)f * npad + blk * WAVE + lane),
-                                                 (lptr_t)(gring + f * PK_RING + blk * WAVE), 4, 0, 0);
-    }
-    S.nbR = S.nbO = 2;
-    S.thr4 = (2 * WAVE < Npad) ? 4 * (2 * WAVE - 10) : MZ_BIG;  // blocks 0 and 1 are in; block 2 is requested near column 118
-
-    const int q0 = li == 15 ? -1 : li;                 // first block; row 0 is the last row of block -1
-    S.q = q0;
-    S.r4 = 4 * (3 * q0 + 1);
-#pragma unroll
-    for (int j = 0; j < PK_R; ++j) {
-        PackRow &R = S.R[j];
-        R.lo4 = MZ_BIG; R.wid4 = 0;
-        R.rIx = R.rIy = R.rIz = R.rCxA = R.rCxB = R.rCy = R.rCz = R.rDx = 0;
-        R.cDe = R.penDye = R.w01 = R.w23 = R.w45 = 0; R.nd = 0x7fff7fff;
-        S.X[j].C = S.Y[j].C = NEGT + 2; S.X[j].D = S.Y[j].D = NEGT; S.X[j].I = S.Y[j].I = NEGT + 1;
-        S.w[j][0] = S.w[j][1] = S.w[j][2] = 0;
-    }
-    for (int round = 0; round < 2; ++round) {
-        for (int g = 0; g < 4; ++g) {
-            const int4 *grecs = uniform_ptr(recs, g * 16);
-            pack_request_chunk(grecs, 2 * round, s_rows + g * (2 * PK_CH * 4), lane);
-            pack_request_chunk(grecs, 2 * round + 1, s_rows + g * (2 * PK_CH * 4), lane);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0070);            // vmcnt(0): everything requested so far has landed
-        __syncthreads();
-        if (q0 >= 8 * round && q0 < 8 * round + 8) {   // blocks 0..7 sit in chunks 0,1; blocks 8..15 in chunks 2,3
-#pragma unroll
-            for (int j = 0; j < PK_R; ++j)
-                pack_load_row(S.R[j], s_rows + grp * (2 * PK_CH * 4) + ((3 * q0) % (2 * PK_CH) + j) * 4);
-        }
-        __syncthreads();
-    }
-    for (int g = 0; g < 4; ++g)                        // blocks 8..11 (chunk 2) are consumed: its half takes chunk 4
-        pack_request_chunk(uniform_ptr(recs, g * 16), 4, s_rows + g * (2 * PK_CH * 4), lane);
-    if (q0 < 0) {                                      // row 0: no penalties at all, extension only
-        PackRow &R = S.R[PK_R - 1];
-        R.lo4 = 0; R.wid4 = 4 * b.poolRB[b.offBand[p]]; R.nd = 0;
-        S.X[PK_R - 1].C = 2; S.X[PK_R - 1].D = 0; S.X[PK_R - 1].I = 1;      // grid point (0,0)
-    }
-    S.u0.C = NEGT + 2; S.u0.D = NEGT; S.u0.I = NEGT + 1;
-    S.u1 = S.u0;
-    if (!have) {                                       // empty group: all rows dead, never refills
-#pragma unroll
-        for (int j = 0; j < PK_R; ++j) { S.R[j].lo4 = MZ_BIG; S.R[j].wid4 = 0; }
-        S.thr4 = MZ_BIG;
-    }
-
-    // wave-uniform schedule
-    int Tmax = 0, eLoMax = 0, eHiMin = MZ_BIG;
-    const int te0 = __builtin_amdgcn_readlane(Tend, 0), te1 = __builtin_amdgcn_readlane(Tend, 16),
-              te2 = __builtin_amdgcn_readlane(Tend, 32), te3 = __builtin_amdgcn_readlane(Tend, 48);
-    Tmax = max(max(te0, te1), max(te2, te3));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        eLoMax = max(eLoMax, __builtin_amdgcn_readlane(eLo, g * 16));
-        eHiMin = min(eHiMin, __builtin_amdgcn_readlane(eHi, g * 16));
-    }
-    // the lane that will hold row M when its pair ends, and which of its rows that is
-    const int qM = (M - 1) / 3, finj = (have && (qM & 15) == li) ? (M - 1) - 3 * qM : -1;
-
-    // three phases, each a plain loop of one step variant (mixing variants inside one loop makes the
-    // register allocator shuffle the ~100 live values at every merge)
-    const int tA = min(eLoMax, Tmax), tB = min(max(eHiMin - 1, tA), Tmax);
-    int *final3 = b.final3 + 3 * p, *errflag = b.status + p;
-    pack_steps<true>(S, 1, tA, te0, te1, te2, te3, Tend, finj, lane, final3, errflag, recs, cols, Npad, s_rows, ring, s_ring, tbp);
-    pack_steps<false>(S, tA + 1, tB, te0, te1, te2, te3, Tend, finj, lane, final3, errflag, recs, cols, Npad, s_rows, ring, s_ring, tbp);
-    pack_steps<true>(S, tB + 1, Tmax, te0, te1, te2, te3, Tend, finj, lane, final3, errflag, recs, cols, Npad, s_rows, ring, s_ring, tbp);
-}
-
-// ------------------------------------------------------------------------------------------
 // strip-mined DP kernel (MZ_MODE_STRIP): any legal band.
 //
 // Rows are processed 64 at a time (lane <-> row of the strip); a strip sweeps the columns
@@ -2423,7 +1926,7 @@ __device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int 
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
-    const bool tagged = mode == MZ_MODE_FASTT || mode == MZ_MODE_PACK || mode >= MZ_MODE_ROW;
+    const bool tagged = mode == MZ_MODE_FASTT || mode >= MZ_MODE_ROW;
     const bool rowfam = mode >= MZ_MODE_ROW, colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
     int *tile = TILE ? s_tile + threadIdx.x * WALK_TILE : s_tile;   // this pair's traceback tile (row-parallel layouts)
     int tile_g = -1, tile_ch = 0;
@@ -2439,12 +1942,6 @@ __device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int 
         const int r_was = r;
         if (r == 0) {
             stb = MZ_FI << 4;                              // row 0 bytes, mz_yama.c:92
-        } else if (mode == MZ_MODE_PACK) {
-            // packed kernel: word ((t>>4)*9 + j*3 + s)*16 + i with row r = 3q+1+j on lane i = q & 15
-            const int t = r + c, q = (r - 1) / 3, j = (r - 1) - 3 * q;
-            const int sidx = node == MZ_FC ? 0 : node == MZ_FD ? 1 : 2;
-            const unsigned tg = (tbw[((long long)(t >> 4) * 9 + j * 3 + sidx) * 16 + (q & 15)] >> (2 * (t & 15))) & 3;
-            stb = tg | (tg << 2) | (tg << 4);
         } else if (rowfam) {
             // row-parallel kernels: entry of (r,c) = bits 2*(u&15) of word ((u>>4)*3 + s)*64 + (w & 63), with
             // (u,w) = (r,c) and streams C,D,I for ROW; (u,w) = (c,r) and streams C,I,D for the transposed COL
@@ -2561,7 +2058,6 @@ __global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int co
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
 static char g_err[256];
-static int s_pack_enabled;      // set by mzk_upload_scores(): whether the plan may choose MZ_MODE_PACK
 static int fail(hipError_t e, const char *what)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -2581,9 +2077,7 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.g2 = m->g2;
     h.maxS = 0;
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
-    h.pack_ok = m->pack;
     h.row_on = m->row;
-    s_pack_enabled = m->pack;
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
@@ -2618,10 +2112,6 @@ extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
 extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    if (s_pack_enabled && first == 0) {          // experimental packed kernel: whole batch with the first slice
-        hipLaunchKernelGGL(k_prep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b);
-        hipLaunchKernelGGL(k_dp_pack, dim3((b->n + 3) / 4), dim3(WAVE), 0, (hipStream_t)stream, *b);
-    }
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);

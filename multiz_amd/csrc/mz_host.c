@@ -158,7 +158,6 @@ static int ensure_init(void)
 /* ------------------------------------------------------------------ scores */
 
 static int g_no_fast;                      /* mz_enable_fast(0): exact kernels only */
-static int g_pack;                         /* mz_enable_pack(1): experimental packed kernel */
 static int g_no_row;                       /* mz_enable_row(0): no row-parallel kernel */
 
 static int class_of(int ch)
@@ -199,7 +198,7 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     /* gap_open = g1*g2, both small enough that 127*g fits an int16 dot-product operand; the fast
      * kernel needs it (MZ_NO_FAST=1 in the environment disables that kernel: exact kernel only) */
     m->g1 = m->g2 = 0;
-    m->pack = g_pack || (getenv("MZ_PACK") && atoi(getenv("MZ_PACK")) != 0);
+    m->pack = 0;
     m->row = !g_no_row && !(getenv("MZ_NO_ROW") && atoi(getenv("MZ_NO_ROW")) != 0);
     if (!g_no_fast && (!getenv("MZ_NO_FAST") || atoi(getenv("MZ_NO_FAST")) == 0)) {
         if (m->gap_open == 0) { m->g1 = 1; m->g2 = 0; }
@@ -232,13 +231,6 @@ void mz_enable_fast(int on)
 {
     g_no_fast = !on;
     G.scores_ok = 0;                       /* force the score model (which carries g1,g2) to be re-sent */
-    mz_scores_explicit = 0;
-}
-
-void mz_enable_pack(int on)
-{
-    g_pack = on != 0;
-    G.scores_ok = 0;
     mz_scores_explicit = 0;
 }
 

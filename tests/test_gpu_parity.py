@@ -17,7 +17,6 @@ def mz():
     m.api.init(0)
     yield m
     m.lib().mz_enable_fast(1)
-    m.lib().mz_enable_pack(0)
     m.lib().mz_enable_row(1)
 
 
@@ -149,6 +148,7 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
     from multiz_amd import synth
     c = synth.CONFIGS[cfg]
     batch = synth.make_batch(pairs, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=7)
+    _kernels(mz, 2)
     db = mz.DevBatch(batch)
     db.run()
     res = db.results()
@@ -253,6 +253,7 @@ def test_pipelined_batches_rotating_workspaces(mz):
     from multiz_amd import synth
     c = synth.CONFIGS["c2"]
     batch = synth.make_batch(2000, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=123)
+    _kernels(mz, 2)
     ref = mz.DevBatch(batch)
     ref.run()
     r0 = ref.results()
@@ -280,6 +281,7 @@ def test_long_block_regime(mz):
     # configs[4] shape (R=30, ~100k x 100k columns): traceback spills to HBM (6 MB per pair)
     from multiz_amd import synth
     batch = synth.make_batch(3, 2, 2, 95000, 105000, 30, first_pair=3)
+    _kernels(mz, 2)
     db = mz.DevBatch(batch)
     db.run()
     res = db.results()
@@ -304,29 +306,6 @@ def test_empty_and_tiny_batches(mz):
     A = np.frombuffer(b"A", dtype=np.uint8).reshape(1, 1)
     r = mz.yama_one(A, A, np.array([0, 0], dtype=np.int32), np.array([1, 1], dtype=np.int32))
     assert r.status == 0 and r.OM == 1 and bytes(r.cols.ravel()) == b"AA"
-
-
-@pytest.mark.parametrize("seed", [5, 6])
-def test_packed_kernel_matches_oracle(mz, golden, seed):
-    # the opt-in packed kernel (four pairs per wave, LDS-DMA fed): same outputs as every other kernel
-    mz.lib().mz_enable_fast(1)
-    mz.lib().mz_enable_pack(1)
-    try:
-        pairs = [(c["A"], c["B"], c["LB"], c["RB"]) for c in golden] + _random_pairs(seed, 300)
-        _check(mz.yama_batch(pairs), pairs, exact_scores=False)
-        from multiz_amd import synth
-        batch = synth.make_batch(37, 2, 2, 900, 1100, 30, first_pair=seed)          # 37: a partly filled last wave
-        db = mz.DevBatch(batch)
-        db.run()
-        res = db.results()
-        assert (res["status"] == 0).all() and (res["mode"] == 4).all()
-        om, hs, _, bad = mo.yama_batch(batch, variant=1, threads=4)
-        host_out = db.out.cpu().numpy()
-        for i in range(37):
-            m_, o0 = int(res["om"][i]), int(res["offOut"][i])
-            assert m_ == om[i] and _hash(host_out[o0: o0 + m_ * 4], m_) == int(hs[i]), i
-    finally:
-        mz.lib().mz_enable_pack(0)
 
 
 def _check(res, pairs, tags=None, exact_scores=True):
