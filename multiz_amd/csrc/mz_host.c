@@ -389,8 +389,13 @@ int mz_dev_wait(void *stream)
 
 /* ------------------------------------------------------------------ host-buffer batch */
 
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
+    const int timing = getenv("MZ_TIMING") != NULL;
+    double t0 = now_s(), t1, t2, t3, t4;
     mz_dev_batch b;
     size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
     char *h, *d;
@@ -428,22 +433,30 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 #undef SLICE
     {
         size_t oa = 0, ob = 0, oband = 0;
-        for (p = 0; p < n; ++p) {
+        for (p = 0; p < n; ++p) {                            /* offsets first ... */
             const mz_job *j = &jobs[p];
             int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
             hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
             hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband;
-            if (ok) {
-                memcpy(hA + oa, j->A, (size_t)j->K * j->M);
-                memcpy(hB + ob, j->B, (size_t)j->L * j->N);
-                memcpy(hLB + oband, j->LB, 4 * ((size_t)j->M + 1));
-                memcpy(hRB + oband, j->RB, 4 * ((size_t)j->M + 1));
-                oa += (size_t)j->K * j->M; ob += (size_t)j->L * j->N; oband += (size_t)j->M + 1;
+            if (ok) { oa += (size_t)j->K * j->M; ob += (size_t)j->L * j->N; oband += (size_t)j->M + 1; }
+            else oband += 1;
+        }
+        /* ... then the copies into the pinned staging block, on all host threads (a single thread moves
+         * ~14 GB/s: 18 ms for the 240 MB of a 20 000-pair C2 batch, three times the GPU work) */
+#pragma omp parallel for schedule(static) if (n > 256)
+        for (p = 0; p < n; ++p) {
+            const mz_job *j = &jobs[p];
+            if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
+                memcpy(hA + hoA[p], j->A, (size_t)j->K * j->M);
+                memcpy(hB + hoB[p], j->B, (size_t)j->L * j->N);
+                memcpy(hLB + hoBand[p], j->LB, 4 * ((size_t)j->M + 1));
+                memcpy(hRB + hoBand[p], j->RB, 4 * ((size_t)j->M + 1));
             } else {
-                hLB[oband] = hRB[oband] = 0; oband += 1;
+                hLB[hoBand[p]] = hRB[hoBand[p]] = 0;
             }
         }
     }
+    t1 = now_s();
     HIPCK(hipMemcpyAsync(G.d_in.p, G.h_in.p, in_bytes, hipMemcpyHostToDevice, G.stream));
 
     if (dev_reserve(&G.d_plan, mz_dev_plan_bytes(n))) return -1;
@@ -452,6 +465,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     if (mzk_plan(&b, G.stream)) return set_err("%s", mzk_last_error());
     HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, G.stream));
     HIPCK(hipStreamSynchronize(G.stream));
+    t2 = now_s();
 
     if (dev_reserve(&G.d_tb, 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script, (size_t)totals[1] + 256) ||
         dev_reserve(&G.d_out, (size_t)totals[2] + 256) || dev_reserve(&G.d_prep, 4 * (size_t)totals[4] + 256))
@@ -482,21 +496,31 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
         if (totals[2] > 0)
             HIPCK(hipMemcpyAsync(rout, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, G.stream));
         HIPCK(hipStreamSynchronize(G.stream));
-        for (p = 0; p < n; ++p) {
-            mz_out *o = &outs[p];
-            o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
-            o->score[0] = o->score[1] = o->score[2] = 0;
-            if (rs[p] != MZ_OK) { failed++; continue; }
-            o->OM = ro[p];
-            o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
-            {
-                size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
-                o->cols = (unsigned char *)malloc(nb ? nb : 1);
-                if (!o->cols) return set_err("out of memory for %zu output bytes", nb);
-                memcpy(o->cols, rout + roff[p], nb);
+        t3 = now_s();
+        {
+            int oom = 0;
+#pragma omp parallel for schedule(static) reduction(+:failed) reduction(|:oom) if (n > 256)
+            for (p = 0; p < n; ++p) {
+                mz_out *o = &outs[p];
+                o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
+                o->score[0] = o->score[1] = o->score[2] = 0;
+                if (rs[p] != MZ_OK) { failed++; continue; }
+                o->OM = ro[p];
+                o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
+                {
+                    size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
+                    o->cols = (unsigned char *)malloc(nb ? nb : 1);
+                    if (!o->cols) { oom = 1; continue; }
+                    memcpy(o->cols, rout + roff[p], nb);
+                }
             }
+            if (oom) return set_err("out of memory for the output columns");
         }
     }
+    t4 = now_s();
+    if (timing)
+        fprintf(stderr, "mz_yama_batch(%d): pack %.2f ms, H2D + plan %.2f ms, kernels + D2H %.2f ms, unpack %.2f ms\n", n,
+                1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3));
     return failed;
 }
 
