@@ -173,11 +173,12 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 edgeLo = rL + 1;
                 edgeHi = min(rN + N, M + LB[M]);          // first step that can touch column N or row M
                 szTb = max((long long)(((M + N) >> 2) + 1) * WAVE, (long long)(((M + N) >> 4) + 1) * 3 * WAVE);
-                // Row-parallel kernels.  Their scores and running sums are re-based every 64 rows / columns, so what
-                // must fit is one window: ~320 steps of at most K*L*(go + max(ge, max|sigma|)) each, times 4 for the
-                // tags, within 2^27 (the ring lift is 2^30) -- whatever M and N are.
+                // Row-parallel kernels.  Their scores are re-based every 32 rows and their running sums every 64
+                // columns, so what must fit is one window: ~240 steps (band width + 2 x 32 rows + band width) of at
+                // most K*L*(go + max(ge, max|sigma|)) each, times 4 for the tags, within 2^27 (the ring lift is 2^30)
+                // -- whatever M and N are.
                 const bool fam = conn && c_sc.g1 > 0 && c_sc.tag_ok && c_sc.row_on;
-                if (fam && (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 27)) {
+                if (fam && (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 960 < (1LL << 27)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROW;
                         edgeLo = rL;                            // rows <= rL can hold column 0 or 1
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
                 // more rows (K*L above ~200): one window no longer fits beside the 2^30 lift of the ring periods, so
                 // the prefix maximum runs on lanes rotated to the band start instead (same re-basing).
                 if (mode != MZ_MODE_ROW && mode != MZ_MODE_COL && fam &&
-                    (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 1280 < (1LL << 29)) {
+                    (long long)K * L * (c_sc.go + max(c_sc.ge, c_sc.maxS)) * 960 < (1LL << 29)) {
                     if (row_ok && 2 * K * (c_sc.maxS + c_sc.go) <= 32767) {
                         mode = MZ_MODE_ROWR;
                         edgeLo = rL; edgeHi = rN;
@@ -1580,9 +1581,9 @@ __device__ __forceinline__ void row_pre(RowState &S, RowLoop &Q, int r, int lane
 }
 
 // Scores only ever enter as differences too (every pick compares candidates that carry the same history), so
-// the frontier is re-based once per block of 64 rows: the best state of the wave becomes the new zero and the
+// the frontier is re-based every 32 rows: the best state of the wave becomes the new zero and the
 // amount goes into a 64-bit running offset.  Tagged int32 states then hold any length of alignment; what bounds
-// them is the score range of one 64-row window (k_plan).  Sentinels are left alone.
+// them is the score range of one window of rows (k_plan).  Sentinels are left alone.
 #define ROW_REBASE_FLOOR (-(1 << 30))
 __device__ __forceinline__ int rebase1(int v, int d) { return v > ROW_REBASE_FLOOR ? v - d : v; }
 __device__ __forceinline__ void row_rebase(RowState &S, RowLoop &Q)
@@ -1602,7 +1603,8 @@ __device__ __forceinline__ void row_store(const RowState &S, uint32_t *tbw, int 
     o[0] = S.wC; o[WAVE] = S.wD; o[2 * WAVE] = S.wI;
 }
 
-// rows r0..r1 of one phase, block of 64 staged rows by block; within a block two rows per iteration so that
+// rows r0..r1 of one phase, block of 64 staged rows by block (in halves: scores are re-based every 32 rows);
+// within a half two rows per iteration so that
 // the record registers alternate (the next row's record is read from LDS while the current row is computed).
 // Pairs start on even rows, so only the second row of a pair can close a 16-row traceback group.
 template <bool EDGE, bool COL, bool ROT>
@@ -1612,14 +1614,14 @@ __device__ __forceinline__ void row_rows(RowState &S, RowLoop &Q, int r0, int r1
     r0 = __builtin_amdgcn_readfirstlane(r0);
     r1 = __builtin_amdgcn_readfirstlane(r1);
     for (int r = r0; r <= r1; ) {
+        if (((r - 1) & 31) == 0 && r > 1) row_rebase(S, Q);          // every 32 rows (the score window of k_plan)
         if (((r - 1) & (WAVE - 1)) == 0 && r > 1) {    // first row of a block: every record of the block before is consumed
-            row_rebase(S, Q);
             __syncthreads();
             row_stage_rows((r - 1) >> 6, lane, src, s_rec);
             __syncthreads();
             Q.rcross = row_find_cross(s_rec, (r - 1) >> 6, lane, Q.next32);
         }
-        const int last = min(r1, ((r - 1) | (WAVE - 1)) + 1);       // last row of this block within [r0, r1]
+        const int last = min(r1, ((r - 1) | 31) + 1);                // last row of this half block within [r0, r1]
         RowRec Ra, Rb;
         row_rec_read<EDGE>(Ra, s_rec, r);
         if (r & 1) {                                   // odd first row on its own
@@ -2024,15 +2026,20 @@ __global__ __launch_bounds__(WAVE) void k_walk_tile(mz_dev_batch b, int first, i
 // iteration; column m takes A[i] or dashes on top of B[j] or dashes, where (i, j) are the
 // running counts of A- and B-advancing ops up to m.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int count)
+// WIDE: blocks of more than 8 rows in all go through LDS (below); narrow ones write their few bytes directly --
+// the 16 KB of LDS would only cost them occupancy.
+template <bool WIDE>
+__device__ __forceinline__ void emit_body(const mz_dev_batch &b, int first, int count, uint8_t *s_cols)
 {
     const int p = first + blockIdx.x, lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p], n = b.om[p];
+    if ((K + L > 8) != WIDE) return;
     const uint8_t *A = b.poolA + b.offA[p], *B = b.poolB + b.offB[p];
     const uint8_t *ops = b.script + b.offScript[p];
     uint8_t *out = b.out + b.offOut[p];
     const unsigned long long below = (lane == 63) ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL);
+    const int W = K + L;
     int ia = 0, jb = 0;                                     // columns of A / B consumed so far
     for (int base = 0; base < n; base += WAVE) {
         const int m = base + lane;
@@ -2042,16 +2049,46 @@ __global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int co
         const unsigned long long mA = __ballot(adA), mB = __ballot(adB);
         const int i = ia + __popcll(mA & below);            // 1-based column of A (if adA)
         const int j = jb + __popcll(mB & below);
-        if (live) {
-            uint8_t *col = out + (long long)m * (K + L);
-            const uint8_t *ca = A + (long long)(i - 1) * K, *cb = B + (long long)(j - 1) * L;
-            for (int k = 0; k < K; ++k) col[k] = adA ? ca[k] : (uint8_t)'-';
-            for (int k = 0; k < L; ++k) col[K + k] = adB ? cb[k] : (uint8_t)'-';
+        if (!WIDE) {
+            if (live) {
+                uint8_t *col = out + (long long)m * W;
+                const uint8_t *ca = A + (long long)(i - 1) * K, *cb = B + (long long)(j - 1) * L;
+                for (int k = 0; k < K; ++k) col[k] = adA ? ca[k] : (uint8_t)'-';
+                for (int k = 0; k < L; ++k) col[K + k] = adB ? cb[k] : (uint8_t)'-';
+            }
+        } else {
+            // the 64 columns of this round are assembled in LDS (byte stores) and leave as consecutive dwords:
+            // a lane writing its own K+L bytes straight to HBM costs one scattered byte store per row of the block
+            if (live) {
+                uint8_t *col = s_cols + lane * W;
+                const uint8_t *ca = A + (long long)(i - 1) * K, *cb = B + (long long)(j - 1) * L;
+                for (int k = 0; k < K; ++k) col[k] = adA ? ca[k] : (uint8_t)'-';
+                for (int k = 0; k < L; ++k) col[K + k] = adB ? cb[k] : (uint8_t)'-';
+            }
+            __syncthreads();
+            {
+                const int nbytes = min(WAVE, n - base) * W;                // base * W is a multiple of 64: dword aligned
+                uint32_t *g = (uint32_t *)(out + (long long)base * W);
+                const uint32_t *s = (const uint32_t *)s_cols;
+                for (int w = lane; w < (nbytes >> 2); w += WAVE) g[w] = s[w];
+                if (lane < (nbytes & 3)) out[(long long)base * W + (nbytes & ~3) + lane] = s_cols[(nbytes & ~3) + lane];
+            }
+            __syncthreads();
         }
         ia += __popcll(mA);
         jb += __popcll(mB);
     }
     if (lane == 0 && (ia != M || jb != N)) b.status[p] = MZ_E_EMIT;   // mz_yama.c:310-312
+}
+
+__global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int count)
+{
+    emit_body<false>(b, first, count, NULL);
+}
+__global__ __launch_bounds__(WAVE) void k_emit_wide(mz_dev_batch b, int first, int count)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_cols[WAVE * 254];   // 64 output columns of up to 127 + 127 rows
+    emit_body<true>(b, first, count, s_cols);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2133,6 +2170,7 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
 {
     if (count <= 0) return 0;
     hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "emit launch");
     return 0;
 }
