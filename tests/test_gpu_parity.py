@@ -185,7 +185,7 @@ def test_every_kernel_family_is_exercised(mz):
                                 (2, 2, 150, 230, 25, "wander"), (2, 2, 230, 150, 25, "wander"), (5, 2, 90, 400, 30, "diag"),
                                 (2, 5, 400, 90, 30, "diag"), (2, 2, 500, 500, 60, "diag"), (1, 1, 63, 63, 31, "diag"),
                                 (2, 2, 40, 45, 10, "diag"), (6, 6, 129, 128, 30, "diag"),
-                                (16, 14, 300, 280, 30, "diag"), (14, 16, 280, 300, 30, "diag")):   # rotate-scan modes 7 / 8
+                                (20, 16, 300, 280, 30, "diag"), (16, 20, 280, 300, 30, "diag")):   # rotate-scan modes 7 / 8
         for _ in range(6):
             A, B, LB, RB = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth,
                                             dash=float(rng.choice([0.0, 0.08, 0.3])), odd=float(rng.choice([0.0, 0.05])))
