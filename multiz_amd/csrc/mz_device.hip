@@ -2029,9 +2029,9 @@ __global__ __launch_bounds__(WAVE) void k_walk_tile(mz_dev_batch b, int first, i
 // WIDE: blocks of more than 8 rows in all go through LDS (below); narrow ones write their few bytes directly --
 // the 16 KB of LDS would only cost them occupancy.
 template <bool WIDE>
-__device__ __forceinline__ void emit_body(const mz_dev_batch &b, int first, int count, uint8_t *s_cols)
+__device__ __forceinline__ void emit_body(const mz_dev_batch &b, int p, uint8_t *s_cols)
 {
-    const int p = first + blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     if (b.status[p] != MZ_OK) return;
     const int K = b.K[p], L = b.L[p], M = b.M[p], N = b.N[p], n = b.om[p];
     if ((K + L > 8) != WIDE) return;
@@ -2083,12 +2083,14 @@ __device__ __forceinline__ void emit_body(const mz_dev_batch &b, int first, int 
 
 __global__ __launch_bounds__(WAVE) void k_emit(mz_dev_batch b, int first, int count)
 {
-    emit_body<false>(b, first, count, NULL);
+    emit_body<false>(b, first + blockIdx.x, NULL);
 }
+// (a fixed grid striding over the batch: a batch without wide blocks then costs a few thousand waves that exit at
+// once, not one 16 KB LDS allocation per pair queued behind the DP)
 __global__ __launch_bounds__(WAVE) void k_emit_wide(mz_dev_batch b, int first, int count)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_cols[WAVE * 254];   // 64 output columns of up to 127 + 127 rows
-    emit_body<true>(b, first, count, s_cols);
+    for (int p = first + blockIdx.x; p < first + count; p += gridDim.x) emit_body<true>(b, p, s_cols);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2170,7 +2172,7 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
 {
     if (count <= 0) return 0;
     hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_emit_wide, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "emit launch");
     return 0;
 }
