@@ -96,3 +96,46 @@ def test_several_contigs_and_orphans(tmp_path):
     for f in ("a.maf", "b.maf"):
         os.link(str(tmp_path / f), str(d2 / f))
     both(d2, ["../a.maf", "../b.maf", "0"])
+
+
+def test_reader_oddities(tmp_path):
+    # comment lines (echoed by the stock reader), i/e/q lines (skipped), amplifier=/copy= tags on the "a" line,
+    # tabs and extra blanks, lowercase and N bases, a trailing block without a final blank line
+    rng = np.random.default_rng(31)
+    ref = inputs.ACGT[rng.integers(0, 4, size=12 * 260 + 300)]
+    b1 = inputs.random_maf_file(rng, ref, 10, 3, "p")
+    b2 = inputs.random_maf_file(rng, ref, 10, 3, "q", stride=300)
+    from oracle.mzoracle import format_block, score_range
+
+    def write(path, blocks, decorate):
+        with open(path, "w") as f:
+            f.write("##maf version=1 scoring=blastz\n# a comment right after the header\n")
+            for k, b in enumerate(blocks):
+                b.score = score_range(b, 0, b.textSize)
+                text = format_block(b)
+                if decorate:
+                    lines = text.split("\n")
+                    if k % 3 == 0:
+                        lines[0] = lines[0] + " copy=1" if len(b.rows) > 1 else lines[0]
+                    if k % 3 == 1 and len(b.rows) > 2:
+                        lines[0] = lines[0] + "\tamplifier=2"
+                    if k % 2 == 0 and len(b.rows) > 1:
+                        lines.insert(2, "i " + b.rows[1].src + " N 0 C 0")
+                        lines.insert(3, "q " + b.rows[1].src + " " + "9" * b.textSize)
+                    if k % 4 == 2:
+                        lines.insert(len(lines) - 2, "e dog.chr7 100 50 + 1000 I")
+                    text = "\n".join(lines)
+                    if k % 5 == 4:
+                        text = "# comment between blocks " + str(k) + "\n" + text
+                f.write(text)
+            if not decorate:
+                f.write("##eof maf\n")
+
+    write(str(tmp_path / "a.maf"), b1, True)
+    write(str(tmp_path / "b.maf"), b2, False)
+    both(tmp_path, ["../a.maf", "../b.maf", "1", "u1", "u2"], ("u1", "u2"))
+    d2 = tmp_path / "second"
+    d2.mkdir()
+    for f in ("a.maf", "b.maf"):
+        os.link(str(tmp_path / f), str(d2 / f))
+    both(d2, ["../b.maf", "../a.maf", "0"])
