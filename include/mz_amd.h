@@ -90,7 +90,7 @@ typedef struct mz_dev_batch {
     int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
-    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5..7] spare */
+    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare */
     int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */

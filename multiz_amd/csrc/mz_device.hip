@@ -252,7 +252,7 @@ __device__ __forceinline__ void scan_load(const mz_dev_batch &b, int i, long lon
     if (i < b.n) {
         const bool ok = b.status[i] == MZ_OK;
         v[0] = b.szTb[i]; v[1] = b.szScript[i]; v[2] = b.szOut[i]; v[3] = b.szPrep[i];
-        v[4] = !ok; v[5] = 0;                            // (sixth sequence: spare)
+        v[4] = !ok; v[5] = ok && b.mode[i] < MZ_MODE_ROW;       // pairs left to the wavefront kernels (k_dp)
     } else {
 #pragma unroll
         for (int q = 0; q < SCAN_Q; ++q) v[q] = 0;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void k_scan2(mz_dev_batch b, int nblk)
     if (q >= SCAN_Q) return;
     long long run = 0;
     for (int k = 0; k < nblk; ++k) { const long long y = b.scanAux[(long long)k * SCAN_Q + q]; b.scanAux[(long long)k * SCAN_Q + q] = run; run += y; }
-    b.totals[q == 4 ? 3 : q == 5 ? 5 : q == 3 ? 4 : q] = run;      // [0..2] tb/script/out, [3] failed, [4] prep, [5] spare
+    b.totals[q == 4 ? 3 : q == 5 ? 5 : q == 3 ? 4 : q] = run;      // [0..2] tb/script/out, [3] failed, [4] prep, [5] wavefront-kernel pairs
 }
 __global__ __launch_bounds__(SCAN_B) void k_scan3(mz_dev_batch b)
 {
@@ -1730,6 +1730,7 @@ __global__ __launch_bounds__(WAVE, 5) void k_dp_row(mz_dev_batch b, int first, i
     __shared__ int4 s_ring[2 * FRING];                 // 4 KB: column records, 128-entry ring
     __shared__ int4 s_rec[WAVE * (RREC / 4)];          // 4 KB: row records of the current block of 64 rows
     const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (blockIdx.x == 0 && lane == 0) b.totals[6] = 0;       // the pair counter of k_dp, launched next on this stream
     if (b.status[p] != MZ_OK) return;
     const int mode = b.mode[p];
     if (mode == MZ_MODE_ROW)       dp_row_body<false, false>(b, p, lane, s_rec, s_ring);
@@ -1892,11 +1893,19 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
     __shared__ int s_pad[MZ_LDS_PAD];
     if (b.n < 0) s_pad[threadIdx.x] = 1;
 #endif
-    // a fixed grid of waves strides over the batch: when the row-parallel kernels took every pair (the usual
-    // case) this launch costs a few microseconds instead of one dispatched-and-exited wave per pair
+    // a fixed grid of waves takes pairs from a shared counter (totals[6], zeroed by k_dp_row, which always runs
+    // just before on the same stream): when the
+    // row-parallel kernels took every pair (the usual case) this launch costs a few microseconds instead of one
+    // dispatched-and-exited wave per pair, and when they did not the waves still balance dynamically
     const int lane = threadIdx.x;
     int *s_rec = (int *)smem;
-    for (int p = first + blockIdx.x; p < first + count; p += gridDim.x) {
+    unsigned long long *next = (unsigned long long *)&b.totals[6];
+    if (b.totals[5] == 0) return;                       // nothing for these kernels in this batch (no atomics either)
+    for (;;) {
+        int p = 0;
+        if (lane == 0) p = first + (int)atomicAdd(next, 1ULL);
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p >= first + count) break;
         if (b.status[p] != MZ_OK) continue;
         const int mode = b.mode[p];
         if (mode == MZ_MODE_FASTT)      dp_tag_body(b, p, lane, s_rec, s_rec + 2 * WAVE * TREC);
