@@ -392,7 +392,7 @@ int mz_dev_wait(void *stream)
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
+static int yama_batch_chunk(int n, const mz_job *jobs, mz_out *outs)
 {
     const int timing = getenv("MZ_TIMING") != NULL;
     double t0 = now_s(), t1, t2, t3, t4;
@@ -521,6 +521,31 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     if (timing)
         fprintf(stderr, "mz_yama_batch(%d): pack %.2f ms, H2D + plan %.2f ms, kernels + D2H %.2f ms, unpack %.2f ms\n", n,
                 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3));
+    return failed;
+}
+
+/* A batch of any size: chunks of at most 64 Ki pairs / ~1 GB of input columns run one after the other through
+ * the same staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
+ * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit. */
+int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
+{
+    static int max_pairs;
+    int done = 0, failed = 0;
+    if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 65536; }
+    while (done < n) {
+        size_t bytes = 0;
+        int m = 0, rc;
+        while (done + m < n && m < max_pairs && bytes < ((size_t)1 << 30)) {
+            const mz_job *j = &jobs[done + m];
+            if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1)
+                bytes += (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1);
+            ++m;
+        }
+        rc = yama_batch_chunk(m, jobs + done, outs + done);
+        if (rc < 0) return rc;
+        failed += rc;
+        done += m;
+    }
     return failed;
 }
 

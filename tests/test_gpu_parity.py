@@ -1,6 +1,7 @@
 """Parity tests proper: the HIP path, called through the C ABI (libmzamd.so), against the CPU oracle
 and the committed golden vectors.  Integer/byte work: the bar is bit-exact."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -324,3 +325,38 @@ def _check(res, pairs, tags=None, exact_scores=True):
             assert r.score.max() == want.final.max(), tag
             live = want.final > -(1 << 29)
             assert np.array_equal(r.score[live], want.final[live]), tag
+
+
+def test_host_batches_are_chunked(tmp_path):
+    # mz_yama_batch() runs big batches in chunks through the same staging buffers (MZ_CHUNK_PAIRS=7 here, read
+    # once per process, hence the subprocess): results must not depend on the chunking
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import inputs
+import multiz_amd as mz
+from oracle import mzoracle as mo
+mz.api.init(0)
+rng = np.random.default_rng(99)
+pairs = []
+while len(pairs) < 40:
+    K, L, M, N = int(rng.integers(1, 6)), int(rng.integers(1, 6)), int(rng.integers(20, 300)), int(rng.integers(20, 300))
+    p = inputs.make_pair(rng, K, L, M, N, 30, "diag", mo.smooth)
+    if mo.check(M, N, p[2], p[3])[0] == 0:
+        pairs.append(p)
+pairs.insert(13, (pairs[0][0], pairs[0][1], pairs[0][2][::-1].copy(), pairs[0][3]))     # one illegal band in the middle
+res = mz.yama_batch(pairs)
+for i, (p, r) in enumerate(zip(pairs, res)):
+    if i == 13:
+        assert r.status != 0
+        continue
+    w = mo.yama(*p)
+    assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), i
+print("chunked ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MZ_CHUNK_PAIRS="7")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0 and b"chunked ok" in p.stdout, p.stderr.decode()[-2000:]
