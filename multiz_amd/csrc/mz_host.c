@@ -73,7 +73,9 @@ static struct {
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
-    gbuf h_in, d_in, d_plan, d_tb, d_script, d_out, d_prep, h_res;
+    gbuf h_in[2], d_in[2], d_plan[2], d_tb[2], d_script[2], d_out[2], d_prep[2], h_res[2];   /* two sets: chunk pipeline */
+    hipStream_t bstream[2];                /* one stream per set (mz_yama_batch) */
+    hipEvent_t bdone[2];
 } G;
 
 static int dev_reserve(gbuf *b, size_t need)
@@ -114,6 +116,10 @@ int mz_init(int device)
         HIPCK(hipStreamCreateWithPriority(&G.stream2, hipStreamNonBlocking, prio));
         HIPCK(hipStreamCreateWithPriority(&G.stream3, hipStreamNonBlocking, prio));
     }
+    for (i = 0; i < 2; ++i) {
+        HIPCK(hipStreamCreateWithFlags(&G.bstream[i], hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
+    }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
     G.device = device;
@@ -130,12 +136,18 @@ static int g_ws_victim;
 void mz_finalize(void)
 {
     int i;
-    gbuf *d[] = { &G.d_in, &G.d_plan, &G.d_tb, &G.d_script, &G.d_out, &G.d_prep };
+    int s;
     if (!G.ready) return;
     hipStreamSynchronize(G.stream);
-    for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
-    if (G.h_in.p)  { hipHostFree(G.h_in.p);  G.h_in.p = NULL;  G.h_in.cap = 0; }
-    if (G.h_res.p) { hipHostFree(G.h_res.p); G.h_res.p = NULL; G.h_res.cap = 0; }
+    for (s = 0; s < 2; ++s) {
+        gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s] };
+        hipStreamSynchronize(G.bstream[s]);
+        for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+        if (G.h_in[s].p)  { hipHostFree(G.h_in[s].p);  G.h_in[s].p = NULL;  G.h_in[s].cap = 0; }
+        if (G.h_res[s].p) { hipHostFree(G.h_res[s].p); G.h_res[s].p = NULL; G.h_res[s].cap = 0; }
+        hipStreamDestroy(G.bstream[s]);
+        hipEventDestroy(G.bdone[s]);
+    }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
     for (i = 0; i < MZ_WS_MAX; ++i) if (g_ws[i].used) { hipEventDestroy(g_ws[i].done); g_ws[i].used = 0; }
@@ -392,20 +404,34 @@ int mz_dev_wait(void *stream)
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-static int yama_batch_chunk(int n, const mz_job *jobs, mz_out *outs)
+/* host threads of the pack / unpack loops: enough to saturate memory bandwidth; waking a whole 256-thread pool
+ * for a 2 ms loop costs more than it saves (and was seen to stall for 70-100 ms now and then) */
+#define MZ_COPY_THREADS 24
+
+/* one chunk of a host batch in flight: everything up to the asynchronous copy of its results is issued by
+ * chunk_submit() on the stream of buffer set `set`; chunk_collect() waits for it and fills the caller's outs */
+typedef struct chunk {
+    int set, n;
+    const mz_job *jobs;
+    mz_out *outs;
+    mz_dev_batch b;
+    int64_t out_bytes;
+    double t_pack, t_plan;
+} chunk;
+
+static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
 {
-    const int timing = getenv("MZ_TIMING") != NULL;
-    double t0 = now_s(), t1, t2, t3, t4;
+    double t0 = now_s(), t1, t2;
+    hipStream_t st = G.bstream[set];
     mz_dev_batch b;
     size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
     char *h, *d;
     int32_t *hK, *hL, *hM, *hN, *hLB, *hRB;
     int64_t *hoA, *hoB, *hoBand, totals[8];
     uint8_t *hA, *hB;
-    int p, failed = 0;
+    int p;
 
-    if (n <= 0) return 0;
-    if (ensure_init() || sync_global_scores()) return -1;
+    c->set = set; c->n = n; c->jobs = jobs; c->outs = outs;
 
     for (p = 0; p < n; ++p) {
         const mz_job *j = &jobs[p];
@@ -417,8 +443,8 @@ static int yama_batch_chunk(int n, const mz_job *jobs, mz_out *outs)
     /* one pinned staging block: [K L M N](int32 x n) [offA offB offBand](int64 x n) LB RB A B */
     hdr = al256(4 * (size_t)n) * 4 + al256(8 * (size_t)n) * 3;
     in_bytes = hdr + 2 * al256(4 * nband) + al256(bytesA) + al256(bytesB);
-    if (host_reserve(&G.h_in, in_bytes) || dev_reserve(&G.d_in, in_bytes)) return -1;
-    h = (char *)G.h_in.p; d = (char *)G.d_in.p;
+    if (host_reserve(&G.h_in[set], in_bytes) || dev_reserve(&G.d_in[set], in_bytes)) return -1;
+    h = (char *)G.h_in[set].p; d = (char *)G.d_in[set].p;
 
     memset(&b, 0, sizeof b);
     b.n = n;
@@ -443,7 +469,7 @@ static int yama_batch_chunk(int n, const mz_job *jobs, mz_out *outs)
         }
         /* ... then the copies into the pinned staging block, on all host threads (a single thread moves
          * ~14 GB/s: 18 ms for the 240 MB of a 20 000-pair C2 batch, three times the GPU work) */
-#pragma omp parallel for schedule(static) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
         for (p = 0; p < n; ++p) {
             const mz_job *j = &jobs[p];
             if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
@@ -457,70 +483,82 @@ static int yama_batch_chunk(int n, const mz_job *jobs, mz_out *outs)
         }
     }
     t1 = now_s();
-    HIPCK(hipMemcpyAsync(G.d_in.p, G.h_in.p, in_bytes, hipMemcpyHostToDevice, G.stream));
+    HIPCK(hipMemcpyAsync(G.d_in[set].p, G.h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
 
-    if (dev_reserve(&G.d_plan, mz_dev_plan_bytes(n))) return -1;
-    mz_dev_carve(&b, G.d_plan.p);
+    if (dev_reserve(&G.d_plan[set], mz_dev_plan_bytes(n))) return -1;
+    mz_dev_carve(&b, G.d_plan[set].p);
     b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
-    if (mzk_plan(&b, G.stream)) return set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, G.stream));
-    HIPCK(hipStreamSynchronize(G.stream));
+    if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
     t2 = now_s();
 
-    if (dev_reserve(&G.d_tb, 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script, (size_t)totals[1] + 256) ||
-        dev_reserve(&G.d_out, (size_t)totals[2] + 256) || dev_reserve(&G.d_prep, 4 * (size_t)totals[4] + 256))
+    if (dev_reserve(&G.d_tb[set], 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script[set], (size_t)totals[1] + 256) ||
+        dev_reserve(&G.d_out[set], (size_t)totals[2] + 256) || dev_reserve(&G.d_prep[set], 4 * (size_t)totals[4] + 256))
         return -1;
-    b.tbw = (uint32_t *)G.d_tb.p; b.script = (uint8_t *)G.d_script.p; b.out = (uint8_t *)G.d_out.p;
-    b.prep = (uint32_t *)G.d_prep.p; b.capPrep = (int64_t)(G.d_prep.cap / 4);
-    b.capTb = (int64_t)(G.d_tb.cap / 4); b.capScript = (int64_t)G.d_script.cap; b.capOut = (int64_t)G.d_out.cap;
+    b.tbw = (uint32_t *)G.d_tb[set].p; b.script = (uint8_t *)G.d_script[set].p; b.out = (uint8_t *)G.d_out[set].p;
+    b.prep = (uint32_t *)G.d_prep[set].p; b.capPrep = (int64_t)(G.d_prep[set].cap / 4);
+    b.capTb = (int64_t)(G.d_tb[set].cap / 4); b.capScript = (int64_t)G.d_script[set].cap; b.capOut = (int64_t)G.d_out[set].cap;
 
-    if (mzk_prep(&b, G.stream) || mzk_dp(&b, G.stream) || mzk_walk(&b, G.stream) || mzk_emit(&b, G.stream))
+    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st) || mzk_emit(&b, st))
         return set_err("%s", mzk_last_error());
 
     /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */
     res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256((size_t)totals[2]);
-    if (host_reserve(&G.h_res, res_bytes)) return -1;
+    if (host_reserve(&G.h_res[set], res_bytes)) return -1;
     {
-        char *r = (char *)G.h_res.p;
-        int32_t *rs = (int32_t *)r;                         r += al256(4 * (size_t)n);
-        int32_t *rb = (int32_t *)r;                         r += al256(4 * (size_t)n);
-        int32_t *ro = (int32_t *)r;                         r += al256(4 * (size_t)n);
-        int32_t *rf = (int32_t *)r;                         r += al256(12 * (size_t)n);
-        int64_t *roff = (int64_t *)r;                       r += al256(8 * (size_t)n);
-        uint8_t *rout = (uint8_t *)r;
-        HIPCK(hipMemcpyAsync(rs, b.status, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
-        HIPCK(hipMemcpyAsync(rb, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
-        HIPCK(hipMemcpyAsync(ro, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
-        HIPCK(hipMemcpyAsync(rf, b.final3, 12 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
-        HIPCK(hipMemcpyAsync(roff, b.offOut, 8 * (size_t)n, hipMemcpyDeviceToHost, G.stream));
-        if (totals[2] > 0)
-            HIPCK(hipMemcpyAsync(rout, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, G.stream));
-        HIPCK(hipStreamSynchronize(G.stream));
-        t3 = now_s();
+        char *r = (char *)G.h_res[set].p;
+        HIPCK(hipMemcpyAsync(r, b.status, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
+        HIPCK(hipMemcpyAsync(r, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
+        HIPCK(hipMemcpyAsync(r, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, st));       r += al256(4 * (size_t)n);
+        HIPCK(hipMemcpyAsync(r, b.final3, 12 * (size_t)n, hipMemcpyDeviceToHost, st));  r += al256(12 * (size_t)n);
+        HIPCK(hipMemcpyAsync(r, b.offOut, 8 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(8 * (size_t)n);
+        if (totals[2] > 0) HIPCK(hipMemcpyAsync(r, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, st));
+    }
+    HIPCK(hipEventRecord(G.bdone[set], st));
+    c->b = b; c->out_bytes = totals[2];
+    c->t_pack = t1 - t0; c->t_plan = t2 - t1;
+    return 0;
+}
+
+static int chunk_collect(chunk *c)
+{
+    const int n = c->n, set = c->set;
+    const mz_job *jobs = c->jobs;
+    mz_out *outs = c->outs;
+    char *r = (char *)G.h_res[set].p;
+    int32_t *rs = (int32_t *)r, *rb, *ro, *rf;
+    int64_t *roff;
+    uint8_t *rout;
+    int p, failed = 0, oom = 0;
+    double t0 = now_s(), t1;
+
+    r += al256(4 * (size_t)n); rb = (int32_t *)r;
+    r += al256(4 * (size_t)n); ro = (int32_t *)r;
+    r += al256(4 * (size_t)n); rf = (int32_t *)r;
+    r += al256(12 * (size_t)n); roff = (int64_t *)r;
+    r += al256(8 * (size_t)n); rout = (uint8_t *)r;
+    HIPCK(hipEventSynchronize(G.bdone[set]));
+    t1 = now_s();
+#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) reduction(+:failed) reduction(|:oom) if (n > 256)
+    for (p = 0; p < n; ++p) {
+        mz_out *o = &outs[p];
+        o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
+        o->score[0] = o->score[1] = o->score[2] = 0;
+        if (rs[p] != MZ_OK) { failed++; continue; }
+        o->OM = ro[p];
+        o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
         {
-            int oom = 0;
-#pragma omp parallel for schedule(static) reduction(+:failed) reduction(|:oom) if (n > 256)
-            for (p = 0; p < n; ++p) {
-                mz_out *o = &outs[p];
-                o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
-                o->score[0] = o->score[1] = o->score[2] = 0;
-                if (rs[p] != MZ_OK) { failed++; continue; }
-                o->OM = ro[p];
-                o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
-                {
-                    size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
-                    o->cols = (unsigned char *)malloc(nb ? nb : 1);
-                    if (!o->cols) { oom = 1; continue; }
-                    memcpy(o->cols, rout + roff[p], nb);
-                }
-            }
-            if (oom) return set_err("out of memory for the output columns");
+            size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
+            o->cols = (unsigned char *)malloc(nb ? nb : 1);
+            if (!o->cols) { oom = 1; continue; }
+            memcpy(o->cols, rout + roff[p], nb);
         }
     }
-    t4 = now_s();
-    if (timing)
-        fprintf(stderr, "mz_yama_batch(%d): pack %.2f ms, H2D + plan %.2f ms, kernels + D2H %.2f ms, unpack %.2f ms\n", n,
-                1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3));
+    if (oom) return set_err("out of memory for the output columns");
+    if (getenv("MZ_TIMING"))
+        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms\n",
+                n, 1e3 * c->t_pack, 1e3 * c->t_plan, 1e3 * (t1 - t0), 1e3 * (now_s() - t1));
     return failed;
 }
 
@@ -532,19 +570,38 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     static int max_pairs;
     int done = 0, failed = 0;
     if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 65536; }
-    while (done < n) {
-        size_t bytes = 0;
-        int m = 0, rc;
-        while (done + m < n && m < max_pairs && bytes < ((size_t)1 << 30)) {
-            const mz_job *j = &jobs[done + m];
-            if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1)
-                bytes += (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1);
-            ++m;
+    if (n <= 0) return 0;
+    if (ensure_init() || sync_global_scores()) return -1;
+    {
+        /* two chunks in flight on two buffer sets and streams: while chunk i is being packed, uploaded and
+         * planned (the host waits for its sizes), the kernels and the result copy of chunk i-1 run; while the
+         * kernels of chunk i run, chunk i-1 is unpacked */
+        chunk ck[2];
+        int have_prev = 0, cur = 0;
+        while (done < n) {
+            size_t bytes = 0;
+            int m = 0, rc;
+            while (done + m < n && m < max_pairs && bytes < ((size_t)1 << 30)) {
+                const mz_job *j = &jobs[done + m];
+                if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1)
+                    bytes += (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1);
+                ++m;
+            }
+            if (chunk_submit(&ck[cur], cur, m, jobs + done, outs + done)) return -1;
+            if (have_prev) {
+                rc = chunk_collect(&ck[cur ^ 1]);
+                if (rc < 0) return rc;
+                failed += rc;
+            }
+            have_prev = 1;
+            cur ^= 1;
+            done += m;
         }
-        rc = yama_batch_chunk(m, jobs + done, outs + done);
-        if (rc < 0) return rc;
-        failed += rc;
-        done += m;
+        if (have_prev) {
+            const int rc = chunk_collect(&ck[cur ^ 1]);
+            if (rc < 0) return rc;
+            failed += rc;
+        }
     }
     return failed;
 }
