@@ -21,5 +21,9 @@ extern int gap_open, gap_extend;
 void init_scores70(void);                                           /* reference mz_scores.c:94-107  */
 void init_scores85(void);                                           /* reference mz_scores.c:109-122 */
 double mafScoreRange(struct mafAli *maf, int start, int size);      /* reference mz_scores.c:124-152 */
+/* (ours) mafScoreRange() works from per-column class counts when ss / gop have the structure of the reference
+ * tables; the model is derived when the ss / gop POINTERS change.  Call this after pointing them at new tables
+ * and before scoring from several threads. */
+void mz_score_profile_sync(void);
 
 #endif

@@ -1928,18 +1928,15 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
 // (C2) the chase is no faster, and its 49 KB of LDS per wave and 5 GB of extra reads slow the DP running beside
 // it in the pipelined form.  The launcher picks by batch size.
 template <bool TILE>
-__device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int count, int *s_tile)
+__device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p, int *s_tile)
 {
-    if (threadIdx.x >= WALK_LANES) return;
-    const int p = first + blockIdx.x * WALK_LANES + threadIdx.x;
-    if (p >= first + count || b.status[p] != MZ_OK) return;
     const int M = b.M[p], N = b.N[p];
     const uint32_t *tbw = b.tbw + b.offTb[p];
     uint8_t *ops = b.script + b.offScript[p];
     const int mode = b.mode[p];
     const bool tagged = mode == MZ_MODE_FASTT || mode >= MZ_MODE_ROW;
     const bool rowfam = mode >= MZ_MODE_ROW, colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
-    int *tile = TILE ? s_tile + threadIdx.x * WALK_TILE : s_tile;   // this pair's traceback tile (row-parallel layouts)
+    int *tile = s_tile;                              // this pair's traceback tile (row-parallel layouts)
     int tile_g = -1, tile_ch = 0;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
@@ -2020,6 +2017,14 @@ __device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int 
     b.om[p] = n;
     if (status != MZ_OK) b.status[p] = status;
 }
+template <bool TILE>
+__device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int count, int *s_tile)
+{
+    if (threadIdx.x >= WALK_LANES) return;
+    const int p = first + blockIdx.x * WALK_LANES + threadIdx.x;
+    if (p >= first + count || b.status[p] != MZ_OK) return;
+    walk_pair<TILE>(b, p, TILE ? s_tile + threadIdx.x * WALK_TILE : s_tile);
+}
 __global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
 {
     walk_body<false>(b, first, count, NULL);
@@ -2028,6 +2033,70 @@ __global__ __launch_bounds__(WAVE) void k_walk_tile(mz_dev_batch b, int first, i
 {
     __shared__ __attribute__((aligned(16))) int s_tile[WALK_LANES * WALK_TILE];   // 49 KB
     walk_body<true>(b, first, count, s_tile);
+}
+
+// One WAVE per pair, for batches of few pairs (where a wave of 64 private chases leaves the machine empty and a
+// long pair waits ~17 us per tile refill): the 64 lanes fetch a window of WIN_G 16-row groups -- all three streams,
+// all 64 ring lanes, 12 KB contiguous -- with coalesced 16-byte loads, then every lane follows the same chain out
+// of LDS (one broadcast read per step) until it leaves the window.  Lane n & 63 keeps the op of step n, so the
+// edit script is written 64 bytes at a time.  Pairs of the wavefront kernels (other layouts) are chased by lane 0.
+#define WIN_G 16
+__global__ __launch_bounds__(WAVE) void k_walk_wave(mz_dev_batch b, int first, int count)
+{
+    __shared__ __attribute__((aligned(16))) int s_win[WIN_G * 3 * WAVE];
+    const int p = first + blockIdx.x, lane = threadIdx.x;
+    if (p >= first + count || b.status[p] != MZ_OK) return;
+    const int mode = b.mode[p];
+    if (mode < MZ_MODE_ROW) {
+        if (lane == 0) walk_pair<false>(b, p, NULL);
+        return;
+    }
+    const int M = b.M[p], N = b.N[p];
+    const uint32_t *tbw = b.tbw + b.offTb[p];
+    uint8_t *ops = b.script + b.offScript[p];
+    const bool colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
+    const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
+    int node = (fC >= fD && fC >= fI) ? MZ_FC : (fD >= fI) ? MZ_FD : MZ_FI;     // mz_yama.c:262-267
+    int r = M, c = N, n = 0, status = MZ_OK, mine = 0;
+    int gb = 1 << 30;                                   // first group of the window in LDS (none yet)
+    const int limit = M + N;
+    while (r > 0 || c > 0) {
+        if (r < 0 || c < 0 || n >= limit) { status = MZ_E_TRACEBACK; break; }
+        unsigned tg;
+        const int r_was = r;
+        if (r == 0) {
+            tg = MZ_FI;                                 // row 0 bytes, mz_yama.c:92 (untagged: see below)
+        } else if (colfam && c == 0) {
+            tg = 0;                                     // COL does not store column 0: D from D (tag 0)
+        } else {
+            const int u = colfam ? c : r, w = colfam ? r : c;
+            const int g = u >> 4;
+            const int sidx = node == MZ_FC ? 0 : node == (colfam ? MZ_FI : MZ_FD) ? 1 : 2;
+            if ((unsigned)(g - gb) >= (unsigned)WIN_G) {       // wave-uniform: every lane follows the same chain
+                gb = max(g - (WIN_G - 1), 0);
+                __syncthreads();
+                const int4 *src = (const int4 *)(tbw + (long long)gb * (3 * WAVE));
+                const int n4 = (g - gb + 1) * (3 * WAVE / 4);
+                for (int k = lane; k < n4; k += WAVE) ((int4 *)s_win)[k] = src[k];
+                __syncthreads();
+            }
+            tg = ((unsigned)s_win[((g - gb) * 3 + sidx) * WAVE + (w & (WAVE - 1))] >> (2 * (u & 15))) & 3;
+        }
+        if (lane == (n & (WAVE - 1))) mine = node;
+        ++n;
+        if ((n & (WAVE - 1)) == 0) ops[n - WAVE + lane] = (uint8_t)mine;
+        if (node == MZ_FI)      { c -= 1; }
+        else if (node == MZ_FD) { r -= 1; }
+        else                    { r -= 1; c -= 1; }
+        node = r_was > 0 ? 2 - (int)tg : (int)tg;       // tie-break tags: C=2, I=1, D=0
+        if ((unsigned)node > 2u) { status = MZ_E_TRACEBACK; break; }
+    }
+    if (lane < (n & (WAVE - 1))) ops[(n & ~(WAVE - 1)) + lane] = (uint8_t)mine;
+    if (status == MZ_OK && (r != 0 || c != 0)) status = MZ_E_TRACEBACK;
+    if (lane == 0) {
+        b.om[p] = n;
+        if (status != MZ_OK) b.status[p] = status;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2170,7 +2239,13 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    if (count <= 16384)      // few pairs: the chase itself is the bottleneck, see walk_body
+    // three walks, picked by batch size (MZ_WALK=wave|tile|direct forces one: tests, measurements)
+    static int force = -1;
+    if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 't' ? 2 : e[0] == 'd' ? 3 : 0; }
+    const int kind = force ? force : count <= 2048 ? 1 : count <= 16384 ? 2 : 3;
+    if (kind == 1)           // very few pairs: a wave each
+        hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    else if (kind == 2)      // few pairs: the chase itself is the bottleneck, see walk_pair
         hipLaunchKernelGGL(k_walk_tile, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     else
         hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);

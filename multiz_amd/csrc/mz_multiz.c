@@ -24,6 +24,7 @@
 #include "../../include/mz_multiz.h"
 #include "mz_py.h"
 #include <time.h>
+#include <malloc.h>
 
 /* MZ_TIMING=1: phase times of a run on stderr */
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -252,6 +253,8 @@ static struct mafAli *keep_from(struct mafAli *a, int beg)
     return a;
 }
 
+#define MZ_STAGE_THREADS 32     /* host threads of the per-merge stages (allocation-heavy: more does not help) */
+
 /* ------------------------------------------------------------------------------------------------ the record */
 
 enum { SINK_OUT = 0, SINK_1 = 1, SINK_2 = 2 };
@@ -264,6 +267,9 @@ typedef struct {
     mz_py py;
     struct mafAli *a1, *a2;   /* private copies: the walk goes on cutting the originals */
     struct mafAli *result;
+    int beg, end, radius, v;  /* pre_yama()'s arguments */
+    int side_ev;              /* the event that holds stage 1's side write to out2 */
+    char *text; size_t len;   /* the merged block as mafWrite() prints it (rendered by the thread that built it) */
     int state;                /* MZ_PY_JOB while a yama() call is pending; MERGE_FAILED: yama() refused the job */
     mz_job bad_job; mz_out bad_out;
 } merge;
@@ -302,17 +308,15 @@ static void rec_merge(record *R, struct mafAli *a1, struct mafAli *a2, int beg, 
 {
     event *e;
     merge *g;
-    FILE *m;
     if (R->nmg == R->capmg) { R->capmg = R->capmg ? 2 * R->capmg : 256; R->mg = (merge *)realloc(R->mg, (size_t)R->capmg * sizeof(merge)); if (!R->mg) mz_fatalf("out of memory"); }
     g = &R->mg[R->nmg];
     memset(g, 0, sizeof *g);
     g->a1 = clone_ali(a1); g->a2 = clone_ali(a2);
-    /* stage 1 now: its side write to out2 (nothing of a1 left to align, mz_preyama.c:193-196) belongs
-     * at this point of the output */
+    g->beg = beg; g->end = end; g->radius = radius; g->v = v;
+    /* stage 1 (run_merges) may write to out2 -- nothing of a1 left to align, mz_preyama.c:193-196 -- and that
+     * text belongs at this point of the output */
     e = new_event(R, SINK_2);
-    m = open_memstream(&e->text, &e->len);
-    g->state = mz_py_begin(&g->py, g->a1, g->a2, beg, end, radius, v, R->has2 ? m : NULL);
-    fclose(m);
+    g->side_ev = R->nev - 1;
     e = new_event(R, SINK_OUT);
     e->job = R->nmg++;
 }
@@ -386,26 +390,55 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
 #undef WANTED
 }
 
-/* run the pending yama() calls of every merge, wave after wave */
-static void run_merges(record *R)
+/* Stage 1 of every merge, then the pending yama() calls of all of them wave after wave.  The merges are
+ * independent of one another, so everything on the host side of the yama() batches -- column packing,
+ * rmColDash, the band walk and smooth() before, mafBuild() and mafScoreRange() after -- runs one merge per
+ * thread. */
+static void run_merges(record *R, int minw)
 {
     mz_job *jobs = (mz_job *)xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(mz_job));
     mz_out *outs = (mz_out *)xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(mz_out));
     int *who = (int *)xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(int));
+    const int nmg = R->nmg, has2 = R->has2;
+    const int timing = getenv("MZ_TIMING") != NULL;
+    double t0 = now_s(), t1;
+    int i;
+    mz_score_profile_sync();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)
+    for (i = 0; i < nmg; ++i) {
+        merge *g = &R->mg[i];
+        event *e = &R->ev[g->side_ev];
+        FILE *m = open_memstream(&e->text, &e->len);
+        g->state = mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, has2 ? m : NULL);
+        fclose(m);
+    }
+    t1 = now_s();
+    if (timing) fprintf(stderr, "mz_multiz: stage 1 of %d merges %.3f s\n", nmg, t1 - t0);
     for (;;) {
-        int n = 0, i, rc;
-        for (i = 0; i < R->nmg; ++i)
+        int n = 0, rc;
+        for (i = 0; i < nmg; ++i)
             if (R->mg[i].state == MZ_PY_JOB) { jobs[n] = R->mg[i].py.job; who[n++] = i; }
         if (n == 0) break;
+        t0 = now_s();
         rc = mz_yama_batch(n, jobs, outs);
         if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+        t1 = now_s();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
         for (i = 0; i < n; ++i) {
             merge *g = &R->mg[who[i]];
             if (outs[i].status != MZ_OK) {                  /* reported at its place in the output order, see replay() */
                 g->state = MERGE_FAILED; g->bad_job = jobs[i]; g->bad_out = outs[i];
             } else
                 g->state = mz_py_step(&g->py, outs[i].cols, outs[i].OM, &g->result);
+            if (g->state != MZ_PY_JOB && g->state != MERGE_FAILED) {    /* finished: render and release here */
+                if (g->result && g->result->components->size >= minw) {
+                    FILE *m = open_memstream(&g->text, &g->len);
+                    mafWrite(m, g->result);
+                    fclose(m);
+                }
+            }                               /* (freed in replay(), by the thread whose arena they came from) */
         }
+        if (timing) fprintf(stderr, "mz_multiz: yama batch of %d %.3f s (with GPU start-up in the first), next stage %.3f s\n", n, t1 - t0, now_s() - t1);
     }
     free(jobs); free(outs); free(who);
 }
@@ -422,7 +455,7 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
                 fflush(out); if (f1) fflush(f1); if (f2) fflush(f2);
                 mz_fatal_status(&g->bad_job, &g->bad_out);
             }
-            if (g->result && g->result->components->size >= minw) mafWrite(out, g->result);
+            if (g->text) { if (g->len) fwrite(g->text, 1, g->len, out); free(g->text); }
             mafAliFree(&g->result);
             mafAliFree(&g->a1); mafAliFree(&g->a2);
         } else if (e->text) {
@@ -452,7 +485,7 @@ int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int rad
         const int timing = getenv("MZ_TIMING") != NULL, nmerge = R.nmg;
         const double t0 = now_s();
         double t1, t2;
-        run_merges(&R);
+        run_merges(&R, min_output_wid);
         t1 = now_s();
         replay(&R, out, out1, out2, min_output_wid);
         t2 = now_s();
@@ -509,6 +542,11 @@ int mz_multiz_main(int argc, char **argv)
     {
         const double t0 = now_s();
         double t1, t2;
+        /* This program makes millions of small allocations from up to 32 threads; letting the heaps grow (and
+         * shrink) in small steps cost a fifth of the run in brk/mprotect calls and page-table locks. */
+        mallopt(M_TOP_PAD, 256 << 20);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
         init_scores70();
         l1 = mz_maf_read_all(argv[1], 1);
         l2 = mz_maf_read_all(argv[2], 1);

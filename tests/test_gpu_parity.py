@@ -360,3 +360,41 @@ print("chunked ok")
     env = dict(os.environ, MZ_CHUNK_PAIRS="7")
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, timeout=600)
     assert p.returncode == 0 and b"chunked ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+@pytest.mark.parametrize("walk", ["wave", "tile", "direct"])
+def test_every_walk_kernel(walk):
+    # the launcher picks one of three traceback walks by batch size (MZ_WALK forces one; read once per process, hence
+    # the subprocess): each must produce the reference's merged blocks for every DP layout -- row-parallel ROW / COL
+    # (lift and rotate forms), tagged and untagged wavefronts, the strip kernel -- on short and on long pairs
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import inputs
+import multiz_amd as mz
+from oracle import mzoracle as mo
+mz.api.init(0)
+rng = np.random.default_rng(2024)
+shapes = [(2, 2, 300, 310, 30, "diag"), (3, 2, 40, 700, 30, "diag"), (2, 3, 700, 40, 30, "diag"), (2, 2, 2500, 2400, 30, "diag"),
+          (4, 4, 150, 150, 12, "wander"), (2, 2, 230, 150, 25, "wander"), (2, 2, 90, 90, 60, "diag"), (1, 1, 30, 33, 30, "full"),
+          (29, 29, 200, 210, 30, "diag"), (2, 2, 5000, 5100, 30, "diag")]
+pairs = []
+for K, L, M, N, R, band in shapes * 2:
+    p = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth)
+    if mo.check(M, N, p[2], p[3])[0] == 0:
+        pairs.append(p)
+modes = set()
+for fast, row in ((1, 1), (1, 0), (0, 0)):
+    mz.lib().mz_enable_fast(fast); mz.lib().mz_enable_row(row)
+    res = mz.yama_batch(pairs)
+    for i, (p, r) in enumerate(zip(pairs, res)):
+        w = mo.yama(*p)
+        assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), (fast, row, i)
+print("walk ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MZ_WALK=walk)
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0 and b"walk ok" in p.stdout, p.stderr.decode()[-2000:]

@@ -120,3 +120,57 @@ def test_product_helpers_match_oracle(product):
     keep = mo._Keep()
     c1 = mo.block_to_c(a1, keep)
     assert product.mafScoreRange(C.byref(c1), 0, a1.textSize) == mo.score_range(a1, 0, a1.textSize)
+
+
+def test_product_score_range_profile_and_literal():
+    # The shim's mafScoreRange() (host C, no GPU involved) counts byte classes per column when the tables have the
+    # reference's structure and walks all row pairs otherwise.  Both against the oracle's literal restatement: many
+    # rows, odd bytes, sub-ranges with and without a previous column; then with a table that has no class structure.
+    import multiz_amd as m
+    lib = m.lib()
+    lib.mafScoreRange.restype = C.c_double
+    lib.mafScoreRange.argtypes = [C.POINTER(mo.MafAli), C.c_int, C.c_int]
+    lib.init_scores70()
+    rng = np.random.default_rng(31)
+    blocks = []
+    for nrows in (1, 2, 3, 7, 18, 40):
+        a1, _, _, _ = inputs.random_block_pair(rng, nrows, 1, 160)
+        for r in a1.rows[1:]:                                   # sprinkle bytes of the "other" class
+            t = bytearray(r.text.encode())
+            for k in rng.integers(0, len(t), size=6):
+                if t[k] != ord("-"):
+                    t[k] = int(rng.choice(list(b"NnXacgt")))
+            r.text = t.decode()
+        blocks.append(a1)
+    def check(sc=None):
+        for b in blocks:
+            keep = mo._Keep()
+            c = mo.block_to_c(b, keep)
+            n = b.textSize
+            for start, size in ((0, n), (0, 1), (1, n - 1), (n // 3, n // 2), (n - 1, 1)):
+                assert lib.mafScoreRange(C.byref(c), start, size) == mo.score_range(b, start, size, sc), (len(b.rows), start, size)
+    check()
+    # a private table: HOXD70 with one asymmetric entry -- not constant on classes, so the literal loop must run
+    sc = mo.scores70()
+    flat = np.ctypeslib.as_array(sc.ss).reshape(128, 128).copy()
+    flat[ord("A"), ord("c")] += 7
+    rows = (C.POINTER(C.c_int) * 128)(*[C.cast(flat[i].ctypes.data, C.POINTER(C.c_int)) for i in range(128)])
+    ss = C.POINTER(C.POINTER(C.c_int)).in_dll(lib, "ss")
+    saved = C.cast(ss, C.c_void_p).value
+    try:
+        C.c_void_p.in_dll(lib, "ss").value = C.addressof(rows)
+        for b in blocks:
+            keep = mo._Keep()
+            c = mo.block_to_c(b, keep)
+            want = 0
+            txt = [np.frombuffer(r.text.encode(), dtype=np.uint8).astype(np.int64) for r in b.rows]
+            gop = np.array(list(sc.gop), dtype=np.int64)
+            for p in range(len(txt)):
+                for q in range(p + 1, len(txt)):
+                    want += int(flat[txt[p], txt[q]].sum())
+                    d = lambda a: (a == ord("-")).astype(np.int64)
+                    want -= int(gop[(d(txt[p][:-1]) << 3) | (d(txt[q][:-1]) << 2) | (d(txt[p][1:]) << 1) | d(txt[q][1:])].sum())
+            assert lib.mafScoreRange(C.byref(c), 0, b.textSize) == float(want), len(b.rows)
+    finally:
+        C.c_void_p.in_dll(lib, "ss").value = saved
+        lib.init_scores70()
