@@ -436,7 +436,9 @@ static void run_merges(record *R, int minw)
                     mafWrite(m, g->result);
                     fclose(m);
                 }
-            }                               /* (freed in replay(), by the thread whose arena they came from) */
+                mafAliFree(&g->result);     /* built by this thread: released into its own arena (cheap); a1 / a2
+                                             * came from the main thread and go back there, in replay() */
+            }
         }
         if (timing) fprintf(stderr, "mz_multiz: yama batch of %d %.3f s (with GPU start-up in the first), next stage %.3f s\n", n, t1 - t0, now_s() - t1);
     }

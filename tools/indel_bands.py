@@ -2,7 +2,7 @@
 (mz_preyama.c:240-258 then smooth()): the band centre stands still over columns only the first block has and
 jumps over columns only the second block has.  Mode histogram, kernel times, every pair against the oracle.
 
-    python tools/indel_bands.py <pairs> <indel events per 1000 columns> [mean indel length]
+    python tools/indel_bands.py <pairs> <indel events per 1000 columns> [mean indel length] [nocheck]
 """
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -46,6 +46,7 @@ w = (batch["poolRB"].astype(np.int64) - batch["poolLB"] + 1)
 print(f"{n} pairs, {sys.argv[2]} indel events / 1000 columns, mean length {mean_len}: widest row {int(w.max())}, mean width {w.mean():.1f}")
 print("modes", np.bincount(res["mode"], minlength=9), "failed", int((res["status"] != 0).sum()),
       "kernel ms", np.round(ms / 3, 3), "GCUPS(dp)", round(cells / (ms[1] / 3 * 1e-3) / 1e9, 1), "GCUPS(serial)", round(cells / (ms.sum() / 3 * 1e-3) / 1e9, 1))
+if "nocheck" in sys.argv: sys.exit(0)
 om, hs, ccells, bad = mo.yama_batch(batch, variant=1, threads=64)
 out = db.out.cpu().numpy(); mism = 0
 for i in range(n):
