@@ -1922,13 +1922,9 @@ __global__ __launch_bounds__(WAVE) void k_dp(mz_dev_batch b, int first, int coun
 // traceback bytes; writes the edit script in reverse order.
 // ------------------------------------------------------------------------------------------
 #define WALK_LANES 64            // pairs per wave (measured: 16 per wave is no faster -- the chase is bound by its own dependent loads -- and costs four times the instruction issue beside the DP)
-#define WALK_TILE 196            // dwords per pair: 2 groups x 3 streams x 2 chunks x 16 lanes, padded (16-byte aligned, spreads the banks)
-// TILE: cache the traceback around the current position in LDS (row-parallel layouts).  It halves the walk of a
-// batch of few, long pairs (C3: 2.7 -> 1.2 ms) but fetches ~48 bytes per step: with tens of thousands of pairs
-// (C2) the chase is no faster, and its 49 KB of LDS per wave and 5 GB of extra reads slow the DP running beside
-// it in the pipelined form.  The launcher picks by batch size.
-template <bool TILE>
-__device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p, int *s_tile)
+// (An LDS-tile variant of this chase -- each pair caching the entries around its position -- was superseded by the
+// run-following walk below and removed.)
+__device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p)
 {
     const int M = b.M[p], N = b.N[p];
     const uint32_t *tbw = b.tbw + b.offTb[p];
@@ -1936,8 +1932,6 @@ __device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p, int *s_t
     const int mode = b.mode[p];
     const bool tagged = mode == MZ_MODE_FASTT || mode >= MZ_MODE_ROW;
     const bool rowfam = mode >= MZ_MODE_ROW, colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
-    int *tile = s_tile;                              // this pair's traceback tile (row-parallel layouts)
-    int tile_g = -1, tile_ch = 0;
     const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
 
     // final-cell tie order C, D, I (mz_yama.c:262-267): D wins a D/I tie here
@@ -1955,38 +1949,11 @@ __device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p, int *s_t
             // (u,w) = (r,c) and streams C,D,I for ROW; (u,w) = (c,r) and streams C,I,D for the transposed COL
             // (its D slot holds the picks of the reference's I state).  COL does not store column 0: only D
             // is reachable there (mz_yama.c:211), and it comes from D.
-            // The chase used to pay one dependent HBM/L2 load per step (~0.8 us); the 2 x 16 lanes x 3 streams
-            // around the current position, for the current 16-row group and the next one down, are fetched at
-            // once (48 independent 16-byte loads) into a private LDS tile, which then serves >= 16 steps.
             const int u = colfam ? c : r, w = colfam ? r : c;
-            const int g = u >> 4, l = w & (WAVE - 1), ch = l >> 4;
+            const int g = u >> 4, l = w & (WAVE - 1);
             const int sidx = node == MZ_FC ? 0 : node == (colfam ? MZ_FI : MZ_FD) ? 1 : 2;
             unsigned tg = 0;
-            if (!TILE) {
-                if (!(colfam && c == 0)) tg = (tbw[(g * 3 + sidx) * WAVE + l] >> (2 * (u & 15))) & 3;
-            } else if (!(colfam && c == 0)) {
-                // tile = groups tile_g and tile_g-1, lane chunks tile_ch and tile_ch-1.  When ANY pair of the
-                // wave has left its tile, EVERY pair re-centres its own (a wave-uniform branch): otherwise, with
-                // 64 unsynchronised pairs, some lane would sit in the reload -- and its latency -- at every step.
-                int gs = tile_g - g, slot = (ch == tile_ch) ? 0 : (ch == ((tile_ch - 1) & 3)) ? 1 : -1;
-                const bool miss = (unsigned)gs > 1u || slot < 0;
-                if (__builtin_amdgcn_ballot_w64(miss) != 0) {
-                    tile_g = g; tile_ch = ch; gs = 0; slot = 0;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int s = 0; s < 3; ++s)
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int gq = g - q > 0 ? g - q : 0;
-                                const int4 *src = (const int4 *)(tbw + (gq * 3 + s) * WAVE + ((ch - k) & 3) * 16);
-                                int4 *dst = (int4 *)(tile + q * 96 + s * 32 + k * 16);
-                                const int4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                                dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
-                            }
-                }
-                tg = ((unsigned)tile[gs * 96 + sidx * 32 + slot * 16 + (l & 15)] >> (2 * (u & 15))) & 3;
-            }
+            if (!(colfam && c == 0)) tg = (tbw[(g * 3 + sidx) * WAVE + l] >> (2 * (u & 15))) & 3;
             stb = tg | (tg << 2) | (tg << 4);
         } else if (tagged) {
             // 2-bit tag streams: word ((t>>4)*3 + s)*64 + lane, s = 0/1/2 for the C/D/I pick; read only
@@ -2017,86 +1984,105 @@ __device__ __forceinline__ void walk_pair(const mz_dev_batch &b, int p, int *s_t
     b.om[p] = n;
     if (status != MZ_OK) b.status[p] = status;
 }
-template <bool TILE>
-__device__ __forceinline__ void walk_body(const mz_dev_batch &b, int first, int count, int *s_tile)
+__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
 {
     if (threadIdx.x >= WALK_LANES) return;
     const int p = first + blockIdx.x * WALK_LANES + threadIdx.x;
     if (p >= first + count || b.status[p] != MZ_OK) return;
-    walk_pair<TILE>(b, p, TILE ? s_tile + threadIdx.x * WALK_TILE : s_tile);
-}
-__global__ __launch_bounds__(WAVE) void k_walk(mz_dev_batch b, int first, int count)
-{
-    walk_body<false>(b, first, count, NULL);
-}
-__global__ __launch_bounds__(WAVE) void k_walk_tile(mz_dev_batch b, int first, int count)
-{
-    __shared__ __attribute__((aligned(16))) int s_tile[WALK_LANES * WALK_TILE];   // 49 KB
-    walk_body<true>(b, first, count, s_tile);
+    walk_pair(b, p);
 }
 
-// One WAVE per pair, for batches of few pairs (where a wave of 64 private chases leaves the machine empty and a
-// long pair waits ~17 us per tile refill): the 64 lanes fetch a window of WIN_G 16-row groups -- all three streams,
-// all 64 ring lanes, 12 KB contiguous -- with coalesced 16-byte loads, then every lane follows the same chain out
-// of LDS (one broadcast read per step) until it leaves the window.  Lane n & 63 keeps the op of step n, so the
-// edit script is written 64 bytes at a time.  Pairs of the wavefront kernels (other layouts) are chased by lane 0.
+// One WAVE per pair, following RUNS instead of steps.  The 64 lanes fetch a window of WIN_G groups of the
+// traceback -- all three streams, all 64 ring lanes, 12 KB contiguous -- into LDS with coalesced 16-byte loads.
+// Then, standing on node s at (r,c), lane k looks at the entry of the same state k moves further along (k cells up
+// the diagonal for C, up the column for D, along the row for I): as long as an entry says "came from the same
+// state" the path goes straight on, so one ballot finds the end of the run and the wave advances the whole run --
+// up to 64 steps, and 64 bytes of edit script in one coalesced store -- for the price of one step.  Alignments
+// are mostly long diagonal runs; a path that turns at every step costs what a step-by-step chase costs.
+// Layouts (2-bit tie-break tags C=2, I=1, D=0, so node = 2 - tag with FC=0, FI=1, FD=2; word = (group*3 + stream)
+// * 64 + lane, bits 2*(index & 15)):
+//     ROW / ROWR   group r>>4,     lane c & 63,     index r,   streams C,D,I
+//     COL / COLR   group c>>4,     lane r & 63,     index c,   streams C,I,D   (column 0 not stored)
+//     FASTT        group (r+c)>>4, lane (r-1) & 63, index r+c, streams C,D,I
+// Row 0 is stored by none of them (all I, mz_yama.c:92).  Pairs of the untagged kernels are chased by lane 0.
 #define WIN_G 16
+template <int LAYOUT>       // 0 ROW, 1 COL, 2 FASTT
+__device__ __forceinline__ void walk_runs(const mz_dev_batch &b, int p, int lane, int *s_win)
+{
+    const int M = b.M[p], N = b.N[p];
+    const uint32_t *tbw = b.tbw + b.offTb[p];
+    uint8_t *ops = b.script + b.offScript[p];
+    const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
+    int node = (fC >= fD && fC >= fI) ? MZ_FC : (fD >= fI) ? MZ_FD : MZ_FI;     // mz_yama.c:262-267
+    const int cmin = LAYOUT == 1 ? 1 : 0;
+    int r = M, c = N, n = 0, status = MZ_OK;
+    int gb = 1 << 30;                                   // first group of the window in LDS (none yet)
+    while (r > 0 && c >= cmin) {
+        const int g = (LAYOUT == 0 ? r : LAYOUT == 1 ? c : r + c) >> 4;
+        if ((unsigned)(g - gb) >= (unsigned)WIN_G) {    // wave-uniform: every lane follows the same chain
+            gb = max(g - (WIN_G - 1), 0);
+            const int4 *src = (const int4 *)(tbw + (long long)gb * (3 * WAVE));
+            const int n4 = (g - gb + 1) * (3 * WAVE / 4);
+            __syncthreads();
+            if (n4 == WIN_G * 3 * WAVE / 4) {           // a full window: twelve loads in flight, then twelve LDS writes
+                int4 v[WIN_G * 3 / 4];
+#pragma unroll
+                for (int j = 0; j < WIN_G * 3 / 4; ++j) v[j] = src[lane + j * WAVE];
+#pragma unroll
+                for (int j = 0; j < WIN_G * 3 / 4; ++j) ((int4 *)s_win)[lane + j * WAVE] = v[j];
+            } else {                                    // the top of the pair (fewer than WIN_G groups left)
+                for (int k = lane; k < n4; k += WAVE) ((int4 *)s_win)[k] = src[k];
+            }
+            __syncthreads();
+        }
+        const int dr = node != MZ_FI, dc = node != MZ_FD;
+        const int rk = r - lane * dr, ck = c - lane * dc;
+        const int ix = LAYOUT == 0 ? rk : LAYOUT == 1 ? ck : rk + ck;
+        const int ln = LAYOUT == 0 ? ck : LAYOUT == 1 ? rk : rk - 1;
+        const int sidx = node == MZ_FC ? 0 : (node == MZ_FD) == (LAYOUT != 1) ? 1 : 2;
+        const bool valid = rk >= 1 && ck >= cmin && (ix >> 4) >= gb;
+        const unsigned word = valid ? (unsigned)s_win[(((ix >> 4) - gb) * 3 + sidx) * WAVE + (ln & (WAVE - 1))] : 0u;
+        const int tag = (word >> (2 * (ix & 15))) & 3;
+        const unsigned long long vmask = __builtin_amdgcn_ballot_w64(valid);
+        const unsigned long long stop = ~__builtin_amdgcn_ballot_w64(valid && tag == 2 - node);
+        const int L = stop ? __builtin_ctzll(stop) : WAVE;
+        const bool turn = L < WAVE && ((vmask >> L) & 1);       // lane L stands on a stored entry: the path turns there
+        const int E = L + (turn ? 1 : 0);                        // steps taken in this state
+        if (lane < E) ops[n + lane] = (uint8_t)node;
+        n += E; r -= E * dr; c -= E * dc;
+        if (turn) {
+            node = 2 - __builtin_amdgcn_readlane(tag, L);
+            if (node < 0) { status = MZ_E_TRACEBACK; break; }
+        }
+    }
+    if (status == MZ_OK) {
+        // the edges: row 0 is all I (mz_yama.c:92), column 0 all D (mz_yama.c:211) -- and the path must arrive there
+        // in that state, or the reference's walk would step outside the grid (mz_yama.c:274-276)
+        if (r < 0 || c < 0) status = MZ_E_TRACEBACK;
+        else if (r == 0 && c > 0) {
+            if (node != MZ_FI) status = MZ_E_TRACEBACK;
+            else { for (int k = lane; k < c; k += WAVE) ops[n + k] = MZ_FI; n += c; }
+        } else if (c == 0 && r > 0) {                   // (COL layouts only: the others store column 0)
+            if (node != MZ_FD) status = MZ_E_TRACEBACK;
+            else { for (int k = lane; k < r; k += WAVE) ops[n + k] = MZ_FD; n += r; }
+        }
+    }
+    if (lane == 0) {
+        b.om[p] = n;
+        if (status != MZ_OK) b.status[p] = status;
+    }
+}
+
 __global__ __launch_bounds__(WAVE) void k_walk_wave(mz_dev_batch b, int first, int count)
 {
     __shared__ __attribute__((aligned(16))) int s_win[WIN_G * 3 * WAVE];
     const int p = first + blockIdx.x, lane = threadIdx.x;
     if (p >= first + count || b.status[p] != MZ_OK) return;
     const int mode = b.mode[p];
-    if (mode < MZ_MODE_ROW) {
-        if (lane == 0) walk_pair<false>(b, p, NULL);
-        return;
-    }
-    const int M = b.M[p], N = b.N[p];
-    const uint32_t *tbw = b.tbw + b.offTb[p];
-    uint8_t *ops = b.script + b.offScript[p];
-    const bool colfam = mode == MZ_MODE_COL || mode == MZ_MODE_COLR;
-    const int fC = b.final3[3 * p], fD = b.final3[3 * p + 1], fI = b.final3[3 * p + 2];
-    int node = (fC >= fD && fC >= fI) ? MZ_FC : (fD >= fI) ? MZ_FD : MZ_FI;     // mz_yama.c:262-267
-    int r = M, c = N, n = 0, status = MZ_OK, mine = 0;
-    int gb = 1 << 30;                                   // first group of the window in LDS (none yet)
-    const int limit = M + N;
-    while (r > 0 || c > 0) {
-        if (r < 0 || c < 0 || n >= limit) { status = MZ_E_TRACEBACK; break; }
-        unsigned tg;
-        const int r_was = r;
-        if (r == 0) {
-            tg = MZ_FI;                                 // row 0 bytes, mz_yama.c:92 (untagged: see below)
-        } else if (colfam && c == 0) {
-            tg = 0;                                     // COL does not store column 0: D from D (tag 0)
-        } else {
-            const int u = colfam ? c : r, w = colfam ? r : c;
-            const int g = u >> 4;
-            const int sidx = node == MZ_FC ? 0 : node == (colfam ? MZ_FI : MZ_FD) ? 1 : 2;
-            if ((unsigned)(g - gb) >= (unsigned)WIN_G) {       // wave-uniform: every lane follows the same chain
-                gb = max(g - (WIN_G - 1), 0);
-                __syncthreads();
-                const int4 *src = (const int4 *)(tbw + (long long)gb * (3 * WAVE));
-                const int n4 = (g - gb + 1) * (3 * WAVE / 4);
-                for (int k = lane; k < n4; k += WAVE) ((int4 *)s_win)[k] = src[k];
-                __syncthreads();
-            }
-            tg = ((unsigned)s_win[((g - gb) * 3 + sidx) * WAVE + (w & (WAVE - 1))] >> (2 * (u & 15))) & 3;
-        }
-        if (lane == (n & (WAVE - 1))) mine = node;
-        ++n;
-        if ((n & (WAVE - 1)) == 0) ops[n - WAVE + lane] = (uint8_t)mine;
-        if (node == MZ_FI)      { c -= 1; }
-        else if (node == MZ_FD) { r -= 1; }
-        else                    { r -= 1; c -= 1; }
-        node = r_was > 0 ? 2 - (int)tg : (int)tg;       // tie-break tags: C=2, I=1, D=0
-        if ((unsigned)node > 2u) { status = MZ_E_TRACEBACK; break; }
-    }
-    if (lane < (n & (WAVE - 1))) ops[(n & ~(WAVE - 1)) + lane] = (uint8_t)mine;
-    if (status == MZ_OK && (r != 0 || c != 0)) status = MZ_E_TRACEBACK;
-    if (lane == 0) {
-        b.om[p] = n;
-        if (status != MZ_OK) b.status[p] = status;
-    }
+    if (mode == MZ_MODE_ROW || mode == MZ_MODE_ROWR)      walk_runs<0>(b, p, lane, s_win);
+    else if (mode == MZ_MODE_COL || mode == MZ_MODE_COLR) walk_runs<1>(b, p, lane, s_win);
+    else if (mode == MZ_MODE_FASTT)                       walk_runs<2>(b, p, lane, s_win);
+    else if (lane == 0)                                   walk_pair(b, p);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2239,14 +2225,15 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    // three walks, picked by batch size (MZ_WALK=wave|tile|direct forces one: tests, measurements)
+    // Up to 16 Ki pairs: the run-following walk, a wave per pair.  Larger batches: the step-by-step chase with a
+    // lane per pair -- latency-bound but almost free in instruction issue, which is what the DP of the neighbouring
+    // batch needs in the pipelined form; on noise-like alignments whose paths turn every two or three steps (the
+    // synthetic C2 pairs drift out of their band) 50 000 run-following waves cost the DP beside them 10 %.
+    // MZ_WALK=wave|direct forces one (tests, measurements).
     static int force = -1;
-    if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 't' ? 2 : e[0] == 'd' ? 3 : 0; }
-    const int kind = force ? force : count <= 2048 ? 1 : count <= 16384 ? 2 : 3;
-    if (kind == 1)           // very few pairs: a wave each
+    if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
+    if (force ? force == 1 : count <= 16384)
         hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    else if (kind == 2)      // few pairs: the chase itself is the bottleneck, see walk_pair
-        hipLaunchKernelGGL(k_walk_tile, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     else
         hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "walk launch");

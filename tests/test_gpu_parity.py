@@ -362,10 +362,10 @@ print("chunked ok")
     assert p.returncode == 0 and b"chunked ok" in p.stdout, p.stderr.decode()[-2000:]
 
 
-@pytest.mark.parametrize("walk", ["wave", "tile", "direct"])
+@pytest.mark.parametrize("walk", ["wave", "direct"])
 def test_every_walk_kernel(walk):
-    # the launcher picks one of three traceback walks by batch size (MZ_WALK forces one; read once per process, hence
-    # the subprocess): each must produce the reference's merged blocks for every DP layout -- row-parallel ROW / COL
+    # two traceback walks -- the run-following one (default) and the step-by-step chase (MZ_WALK=direct; read once per
+    # process, hence the subprocess): each must produce the reference's merged blocks for every DP layout -- row-parallel ROW / COL
     # (lift and rotate forms), tagged and untagged wavefronts, the strip kernel -- on short and on long pairs
     import subprocess
     import sys
@@ -383,6 +383,11 @@ shapes = [(2, 2, 300, 310, 30, "diag"), (3, 2, 40, 700, 30, "diag"), (2, 3, 700,
 pairs = []
 for K, L, M, N, R, band in shapes * 2:
     p = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth)
+    if mo.check(M, N, p[2], p[3])[0] == 0:
+        pairs.append(p)
+for K, L, M, N, R, band in ((2, 2, 400, 380, 30, "diag"), (3, 1, 200, 600, 40, "wander"), (1, 1, 120, 100, 30, "full")):
+    p = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth)       # unrelated sequences: the path turns all the time
+    p = (p[0], inputs.random_block(rng, N, L, dash=0.3, odd=0.05), p[2], p[3])
     if mo.check(M, N, p[2], p[3])[0] == 0:
         pairs.append(p)
 modes = set()
