@@ -65,5 +65,7 @@ int  mafPos2Col(struct mafComp *c, int pos, int textSize);          /* reference
 struct mafAli *mafColDashRm(struct mafAli *a);                      /* reference maf.c:339-377 */
 struct mafAli *make_part_ali_col(struct mafAli *a, int cbeg, int cend);   /* reference multi_util.c:570-618 */
 int  print_part_ali_col(struct mafAli *a, int cbeg, int cend, FILE *fp);  /* reference multi_util.c:620-629 */
+struct mafAli *mafRowDashRm(struct mafAli *a);                      /* reference maf.c:384-417 */
+struct mafAli *make_part_ali(struct mafAli *a, int cbeg, int cend); /* reference maf.c:488-523 */
 
 #endif

@@ -22,4 +22,10 @@ int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int rad
 /* the multiz command line: [R=?] [M=?] file1 file2 v [out1 out2] [nohead] [all] */
 int mz_multiz_main(int argc, char **argv);
 
+/* the multic command line (reference multic.c): [s=?] [R=?] [M=?] [C=?] file1 file2 v [out1 out2] [nohead] [all].
+ * Two block lists topped by the same reference, single coverage not required: every overlapping pair of blocks
+ * with no species in common is merged over its overlap (all of them enumerated first and aligned as GPU batches),
+ * then the stretches no merge used are printed.  Output is byte-identical to the stock binary's. */
+int mz_multic_main(int argc, char **argv);
+
 #endif

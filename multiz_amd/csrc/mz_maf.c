@@ -188,3 +188,45 @@ int print_part_ali_col(struct mafAli *ali, int cbeg, int cend, FILE *fp)
     mafAliFree(&part);
     return 0;
 }
+
+/* drop rows that are '-' throughout; NULL (block freed) when none is left (reference maf.c:384-417) */
+struct mafAli *mafRowDashRm(struct mafAli *a)
+{
+    struct mafComp **pp, *c;
+    if (!a) return NULL;
+    for (pp = &a->components; (c = *pp) != NULL; ) {
+        const char *s = c->text;
+        while (*s == '-') ++s;
+        if (*s == '\0') { *pp = c->next; c->next = NULL; mafCompFree(&c); }
+        else pp = &c->next;
+    }
+    if (!a->components) { mafAliFree(&a); return NULL; }
+    return a;
+}
+
+/* columns cbeg..cend of every row, all-dash ROWS dropped, columns kept as they are (reference maf.c:488-523;
+ * multic prints the unused stretches of its inputs with it) */
+struct mafAli *make_part_ali(struct mafAli *ali, int cbeg, int cend)
+{
+    const int width = cend - cbeg + 1;
+    struct mafAli *out = (struct mafAli *)xmalloc(sizeof *out);
+    struct mafComp *c, *nc, *tail = NULL;
+    memset(out, 0, sizeof *out);
+    for (c = ali->components; c; c = c->next) {
+        int before = 0, bases = 0, i;
+        for (i = 0; i < cbeg; ++i) before += c->text[i] != '-';
+        for (i = cbeg; i <= cend; ++i) bases += c->text[i] != '-';
+        nc = mafCpyComp(c);
+        nc->start = c->start + before;
+        nc->size = bases;
+        nc->text = (char *)xmalloc((size_t)width + 1);
+        memcpy(nc->text, c->text + cbeg, (size_t)width);
+        nc->text[width] = '\0';
+        if (tail) tail->next = nc; else out->components = nc;
+        tail = nc;
+    }
+    out->textSize = width;
+    out = mafRowDashRm(out);
+    if (out) out->score = mafScoreRange(out, 0, width);
+    return out;
+}
