@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mz_device.h"
 #include "../../include/mz_scores.h"
@@ -110,22 +111,26 @@ int mz_init(int device)
         return set_err("HIP device %d out of range (%d present)", device, count);
     HIPCK(hipSetDevice(device));
     HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
-    {   /* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs
-         * 4 % of the pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
-        int prio = getenv("MZ_HELPER_PRIO") ? atoi(getenv("MZ_HELPER_PRIO")) : 0;
-        HIPCK(hipStreamCreateWithPriority(&G.stream2, hipStreamNonBlocking, prio));
-        HIPCK(hipStreamCreateWithPriority(&G.stream3, hipStreamNonBlocking, prio));
-    }
-    for (i = 0; i < 2; ++i) {
-        HIPCK(hipStreamCreateWithFlags(&G.bstream[i], hipStreamNonBlocking));
-        HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
-    }
+    /* the helper streams (mz_dev_run_async) and the second chunk stream are created on first use: a stream costs
+     * ~9 ms of start-up and a short run -- one yama() call, one chunk -- needs none of them */
+    G.stream2 = G.stream3 = NULL;
+    G.bstream[0] = G.stream; G.bstream[1] = NULL;
+    for (i = 0; i < 2; ++i) HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
     G.device = device;
     G.ready = 1;
     G.scores_ok = 0;
     G.ss_seen = NULL;
+    return 0;
+}
+
+/* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs 4 % of the
+ * pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
+static int lazy_stream(hipStream_t *s)
+{
+    if (*s) return 0;
+    HIPCK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, getenv("MZ_HELPER_PRIO") ? atoi(getenv("MZ_HELPER_PRIO")) : 0));
     return 0;
 }
 
@@ -141,20 +146,18 @@ void mz_finalize(void)
     hipStreamSynchronize(G.stream);
     for (s = 0; s < 2; ++s) {
         gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s] };
-        hipStreamSynchronize(G.bstream[s]);
+        if (G.bstream[s]) hipStreamSynchronize(G.bstream[s]);
         for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
         if (G.h_in[s].p)  { hipHostFree(G.h_in[s].p);  G.h_in[s].p = NULL;  G.h_in[s].cap = 0; }
         if (G.h_res[s].p) { hipHostFree(G.h_res[s].p); G.h_res[s].p = NULL; G.h_res[s].cap = 0; }
-        hipStreamDestroy(G.bstream[s]);
+        if (s == 1 && G.bstream[s]) hipStreamDestroy(G.bstream[s]);
         hipEventDestroy(G.bdone[s]);
     }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
     for (i = 0; i < MZ_WS_MAX; ++i) if (g_ws[i].used) { hipEventDestroy(g_ws[i].done); g_ws[i].used = 0; }
-    hipStreamSynchronize(G.stream2);
-    hipStreamDestroy(G.stream2);
-    hipStreamSynchronize(G.stream3);
-    hipStreamDestroy(G.stream3);
+    if (G.stream2) { hipStreamSynchronize(G.stream2); hipStreamDestroy(G.stream2); }
+    if (G.stream3) { hipStreamSynchronize(G.stream3); hipStreamDestroy(G.stream3); }
     hipStreamDestroy(G.stream);
     G.ready = 0;
 }
@@ -325,7 +328,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
 {
     hipStream_t s;
     int i;
-    if (ensure_init() || sync_global_scores()) return -1;
+    if (ensure_init() || sync_global_scores() || lazy_stream(&G.stream2) || lazy_stream(&G.stream3)) return -1;
     s = (hipStream_t)pick_stream(stream);
     if (ms) {                              /* serial, one HIP event pair per phase */
         HIPCK(hipEventRecord(G.ev[0], s));
@@ -422,7 +425,7 @@ typedef struct chunk {
 static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
 {
     double t0 = now_s(), t1, t2;
-    hipStream_t st = G.bstream[set];
+    hipStream_t st;
     mz_dev_batch b;
     size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
     char *h, *d;
@@ -431,6 +434,8 @@ static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     uint8_t *hA, *hB;
     int p;
 
+    if (lazy_stream(&G.bstream[set])) return -1;
+    st = G.bstream[set];
     c->set = set; c->n = n; c->jobs = jobs; c->outs = outs;
 
     for (p = 0; p < n; ++p) {
@@ -571,7 +576,17 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     int done = 0, failed = 0;
     if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 65536; }
     if (n <= 0) return 0;
-    if (ensure_init() || sync_global_scores()) return -1;
+    {
+        const int first = !G.ready && getenv("MZ_TIMING") != NULL;
+        struct timespec t0, t1, t2;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if (ensure_init()) return -1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (sync_global_scores()) return -1;
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        if (first) fprintf(stderr, "mz_yama_batch: GPU start-up %.1f ms (HIP runtime, streams), score upload incl. code object load %.1f ms\n",
+                           1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), 1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
+    }
     {
         /* two chunks in flight on two buffer sets and streams: while chunk i is being packed, uploaded and
          * planned (the host waits for its sizes), the kernels and the result copy of chunk i-1 run; while the
