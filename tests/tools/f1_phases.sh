@@ -1,4 +1,4 @@
-# phase times of a batched multiz run: tools/f1_phases.sh [rows per file, default 3] [blocks, default 20000]
+# phase times of a batched multiz run: tests/tools/f1_phases.sh [rows per file, default 3] [blocks, default 20000]
 cd $GRAFT_REPO_ROOT
 ROWS=${1:-3}; BLOCKS=${2:-20000}
 python - $ROWS $BLOCKS <<'PY'

@@ -2,7 +2,7 @@
 (mz_preyama.c:240-258 then smooth()): the band centre stands still over columns only the first block has and
 jumps over columns only the second block has.  Mode histogram, kernel times, every pair against the oracle.
 
-    python tools/indel_bands.py <pairs> <indel events per 1000 columns> [mean indel length] [nocheck]
+    python tests/tools/indel_bands.py <pairs> <indel events per 1000 columns> [mean indel length] [nocheck]
 """
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -1,5 +1,5 @@
 """batched mz_multic against the stock multic binary on two overlapping block lists:
-    python tools/multic_bench.py [blocks per single-coverage list, default 4000] [rows per block, default 3]"""
+    python tests/tools/multic_bench.py [blocks per single-coverage list, default 4000] [rows per block, default 3]"""
 import os, sys, time, subprocess, tempfile
 import numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
