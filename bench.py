@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # HBM bytes of one launch of the dominant kernel on the default c2 batch, from the PMC passes in profiles/
 # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs).  Measured, never estimated; valid for the default
 # c2 batch only.
-# k_dp_row on the c2 batch, profiles/r1f_pmc_summary.txt: FETCH_SIZE 354 806 KB (narrow coalesced reads are
-# counted at one half on gfx950: x2) + WRITE_SIZE 2 438 499 KB
-TRAFFIC_BYTES_PER_LAUNCH = (2 * 354806 + 2438499) * 1024
+# k_dp_row on the c2 batch, profiles/r1h_pmc_summary.txt: FETCH_SIZE 355 553 KB (narrow coalesced reads are
+# counted at one half on gfx950: x2) + WRITE_SIZE 2 438 496 KB
+TRAFFIC_BYTES_PER_LAUNCH = (2 * 355553 + 2438496) * 1024
 
 
 def algorithmic_bytes(batch, om):

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(WAVE) void k_plan(mz_dev_batch b)
             int key = 0x7fffffff;           // (row << 2 | kind), kind in the reference's test order
             int wf_ok = 1, conn = 1, row_ok = 1, col_ok = 1;
             int rL = 0, rN = M;             // last row with LB[r] <= 1, first row with RB[r] == N
+#pragma unroll 4                     // (the loads of four chunks in flight: the loop is pure memory latency)
             for (int r = lane; r <= M; r += WAVE) {
                 const int lo = LB[r], hi = RB[r];
                 if (hi - lo < need) key = min(key, (r << 2) | 0);
