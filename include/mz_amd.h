@@ -165,7 +165,9 @@ size_t mz_dev_plan_bytes(int n);
 void   mz_dev_carve(mz_dev_batch *b, void *plan_mem);
 
 /* phases; all asynchronous on `stream` (hipStream_t; NULL = the library's stream) */
-int mz_dev_plan(const mz_dev_batch *b, void *stream);   /* validity + sizes + offsets        */
+int mz_dev_plan(const mz_dev_batch *b, void *stream);   /* validity + sizes + offsets (+ the COL pairs' prep records).
+                                                         * Sizing pass: capacities = INT64_MAX, prep = NULL; then read
+                                                         * totals[0,1,2,4], allocate tbw/script/out/prep and run.      */
 int mz_dev_dp(const mz_dev_batch *b, void *stream);     /* DP + traceback bytes             */
 int mz_dev_walk(const mz_dev_batch *b, void *stream);   /* traceback -> edit script, OM     */
 int mz_dev_emit(const mz_dev_batch *b, void *stream);   /* merged columns                   */

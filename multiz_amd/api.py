@@ -156,18 +156,19 @@ class DevBatch:
         for k, v in self.t.items():
             setattr(self.c, k, v.data_ptr())
         lib().mz_dev_carve(C.byref(self.c), self.plan_mem.data_ptr())
-        # sizes: traceback = 64 bytes per anti-diagonal step (wf64), script = M+N, out = (M+N)(K+L)
-        M, N = np.asarray(host["M"], dtype=np.int64), np.asarray(host["N"], dtype=np.int64)
-        K, L = np.asarray(host["K"], dtype=np.int64), np.asarray(host["L"], dtype=np.int64)
-        tb = int((((M + N) // 4 + 1) * 64).sum()) if cap_tb is None else int(cap_tb)
-        sc = int((((M + N + 3) // 4) * 4).sum())
-        ou = int(((((M + N) * (K + L) + 15) // 16) * 16).sum())
+        # Workspace sizes come from the plan itself (what mz_yama_batch() does on the host path): plan once with
+        # unlimited capacities, read the totals, allocate.  They hold for the kernel selection in force now
+        # (mz_enable_fast / mz_enable_row); cap_tb overrides the traceback size (tests of MZ_E_WORKSPACE).
+        self.c.capTb = self.c.capScript = self.c.capOut = self.c.capPrep = 1 << 62
+        _check(lib().mz_dev_plan(C.byref(self.c), self.stream_ptr()), "mz_dev_plan")
+        torch.cuda.synchronize(self.dev)
+        tot = self._view(self.c.totals, 8, np.int64)
+        tb = int(tot[0]) if cap_tb is None else int(cap_tb)
+        sc, ou, pr = int(tot[1]), int(tot[2]), int(tot[4])
         self.tbw = torch.empty(tb + 64, dtype=torch.int32, device=self.dev)
         self.script = torch.empty(sc + 64, dtype=torch.uint8, device=self.dev)
         self.out = torch.empty(ou + 64, dtype=torch.uint8, device=self.dev)
-        # prep: the transposed band bounds of the MZ_MODE_COL pairs, 2 ints per column (k_plan's szPrep, rounded up)
-        pr = int((2 * (N + 1) + 64).sum())
-        self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)
+        self.prep = torch.empty(pr + 64, dtype=torch.int32, device=self.dev)   # transposed band bounds of the COL pairs
         self.c.tbw, self.c.script, self.c.out, self.c.prep = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr(), self.prep.data_ptr()
         self.c.capTb, self.c.capScript, self.c.capOut, self.c.capPrep = tb + 64, sc + 64, ou + 64, pr + 64
         torch.cuda.synchronize(self.dev)                     # inputs complete (run_async's plan runs on a library stream)

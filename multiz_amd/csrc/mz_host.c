@@ -306,7 +306,8 @@ static void *pick_stream(void *s) { return s ? s : (void *)G.stream; }
 int mz_dev_plan(const mz_dev_batch *b, void *stream)
 {
     if (ensure_init() || sync_global_scores()) return -1;
-    return (mzk_plan(b, pick_stream(stream)) || mzk_prep(b, pick_stream(stream))) ? set_err("%s", mzk_last_error()) : 0;
+    /* prep == NULL: a sizing pass (validity, modes, sizes, offsets, totals) before the workspaces exist */
+    return (mzk_plan(b, pick_stream(stream)) || (b->prep && mzk_prep(b, pick_stream(stream)))) ? set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_dp(const mz_dev_batch *b, void *stream)
 {
