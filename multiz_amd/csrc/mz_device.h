@@ -10,11 +10,11 @@ int mzk_upload_scores(const mz_score_model *m, void *stream);
 int mzk_plan(const mz_dev_batch *b, void *stream);
 int mzk_prep(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
-int mzk_walk(const mz_dev_batch *b, void *stream);
+int mzk_walk(const mz_dev_batch *b, void *stream, int beside_dp);   /* beside_dp: another batch's DP runs at the same time */
 int mzk_emit(const mz_dev_batch *b, void *stream);
 /* the same three phases on the slice [first, first+count) of the batch */
 int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
-int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream);
+int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);
 int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream);
 const char *mzk_last_error(void);
 #ifdef __cplusplus

@@ -2223,17 +2223,18 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     CK(hipGetLastError(), "dp launch");
     return 0;
 }
-extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream)
+extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp)
 {
     if (count <= 0) return 0;
-    // Up to 16 Ki pairs: the run-following walk, a wave per pair.  Larger batches: the step-by-step chase with a
-    // lane per pair -- latency-bound but almost free in instruction issue, which is what the DP of the neighbouring
-    // batch needs in the pipelined form; on noise-like alignments whose paths turn every two or three steps (the
-    // synthetic C2 pairs drift out of their band) 50 000 run-following waves cost the DP beside them 10 %.
+    // The run-following walk, a wave per pair -- except for batches above 16 Ki pairs that run BESIDE the DP of a
+    // neighbouring batch (mz_dev_run_async, the chunks of mz_yama_batch): there the step-by-step chase with a lane
+    // per pair is used, latency-bound but almost free in instruction issue, which is what that DP needs; on
+    // alignments whose paths turn every few steps (the synthetic C2 pairs drift out of their band) 50 000
+    // run-following waves cost the DP beside them 10 %.
     // MZ_WALK=wave|direct forces one (tests, measurements).
     static int force = -1;
     if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
-    if (force ? force == 1 : count <= 16384)
+    if (force ? force == 1 : (!beside_dp || count <= 16384))
         hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     else
         hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
@@ -2249,5 +2250,5 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
     return 0;
 }
 extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)   { return mzk_dp_range(b, 0, b->n, stream); }
-extern "C" int mzk_walk(const mz_dev_batch *b, void *stream) { return mzk_walk_range(b, 0, b->n, stream); }
+extern "C" int mzk_walk(const mz_dev_batch *b, void *stream, int beside_dp) { return mzk_walk_range(b, 0, b->n, stream, beside_dp); }
 extern "C" int mzk_emit(const mz_dev_batch *b, void *stream) { return mzk_emit_range(b, 0, b->n, stream); }

@@ -317,7 +317,7 @@ int mz_dev_dp(const mz_dev_batch *b, void *stream)
 int mz_dev_walk(const mz_dev_batch *b, void *stream)
 {
     if (ensure_init()) return -1;
-    return mzk_walk(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+    return mzk_walk(b, pick_stream(stream), 0) ? set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_emit(const mz_dev_batch *b, void *stream)
 {
@@ -337,7 +337,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
         HIPCK(hipEventRecord(G.ev[1], s));
         if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[2], s));
-        if (mzk_walk(b, s)) return set_err("%s", mzk_last_error());
+        if (mzk_walk(b, s, 0)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[3], s));
         if (mzk_emit(b, s)) return set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[4], s));
@@ -345,7 +345,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
         for (i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&ms[i], G.ev[i], G.ev[i + 1]));
         return 0;
     }
-    if (mzk_plan(b, s) || mzk_prep(b, s) || mzk_dp(b, s) || mzk_walk(b, s) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(b, s) || mzk_prep(b, s) || mzk_dp(b, s) || mzk_walk(b, s, 0) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
     return 0;
 }
 
@@ -387,7 +387,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.evs[2], s));
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
-    if (mzk_walk(b, G.stream2) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
+    if (mzk_walk(b, G.stream2, 1) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(g_ws[slot].done, G.stream2));
     return 0;
 }
@@ -506,7 +506,7 @@ static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     b.prep = (uint32_t *)G.d_prep[set].p; b.capPrep = (int64_t)(G.d_prep[set].cap / 4);
     b.capTb = (int64_t)(G.d_tb[set].cap / 4); b.capScript = (int64_t)G.d_script[set].cap; b.capOut = (int64_t)G.d_out[set].cap;
 
-    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st) || mzk_emit(&b, st))
+    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit(&b, st))
         return set_err("%s", mzk_last_error());
 
     /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */
