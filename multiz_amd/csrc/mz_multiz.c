@@ -209,16 +209,50 @@ static void take_chr(struct mafAli **from, struct mafAli **to, const char *chr)
     }
 }
 
-static struct mafAli *clone_ali(const struct mafAli *a)
+/* The walk goes on cutting the blocks it holds, so every pending merge keeps private copies of its two blocks
+ * until the replay.  They are never resized or freed one by one: they come from a bump arena that is released as
+ * a whole (thirty malloc/free pairs per merge otherwise -- a sixth of a 20 000-block run). */
+typedef struct arena_chunk { struct arena_chunk *next; size_t used, cap; } arena_chunk;
+static arena_chunk *g_arena;
+
+static void *arena_alloc(size_t n)
 {
-    struct mafAli *b = (struct mafAli *)xmalloc(sizeof *b);
+    void *p;
+    n = (n + 15) & ~(size_t)15;
+    if (!g_arena || g_arena->used + n > g_arena->cap) {
+        const size_t cap = n > ((size_t)8 << 20) ? n : ((size_t)8 << 20);
+        arena_chunk *c = (arena_chunk *)xmalloc(sizeof *c + cap);
+        c->next = g_arena; c->used = 0; c->cap = cap;
+        g_arena = c;
+    }
+    p = (char *)(g_arena + 1) + g_arena->used;
+    g_arena->used += n;
+    return p;
+}
+static char *arena_strdup(const char *s)
+{
+    size_t n;
+    if (!s) return NULL;
+    n = strlen(s) + 1;
+    return (char *)memcpy(arena_alloc(n), s, n);
+}
+static void arena_release(void)
+{
+    while (g_arena) { arena_chunk *c = g_arena; g_arena = c->next; free(c); }
+}
+
+static struct mafAli *clone_ali(const struct mafAli *a)      /* arena-owned: never passed to mafAliFree() */
+{
+    struct mafAli *b = (struct mafAli *)arena_alloc(sizeof *b);
     struct mafComp *c, *tail = NULL;
     *b = *a;
     b->next = NULL; b->components = NULL;
     for (c = a->components; c; c = c->next) {
-        struct mafComp *d = mafCpyComp(c);
-        d->text = xstrdup(c->text);
-        d->nameID = c->nameID;
+        struct mafComp *d = (struct mafComp *)arena_alloc(sizeof *d);
+        *d = *c;
+        d->next = NULL; d->mafPosMap = NULL;
+        d->src = arena_strdup(c->src); d->name = arena_strdup(c->name); d->contig = arena_strdup(c->contig);
+        d->text = arena_strdup(c->text);
         if (tail) tail->next = d; else b->components = d;
         tail = d;
     }
@@ -262,6 +296,8 @@ typedef struct {
     int sink;                 /* where the text goes */
     char *text; size_t len;   /* recorded output (unused parts, pre_yama's side write) or NULL */
     int job;                  /* index into the merge list, or -1 */
+    struct mafAli *src;       /* text still to be rendered (render_events): this block (arena copy) ... */
+    int cbeg, cend;           /* ... columns cbeg..cend of it, or the whole block when cbeg < 0 */
 } event;
 typedef struct {
     mz_py py;
@@ -288,20 +324,34 @@ static event *new_event(record *R, int sink)
     return &R->ev[R->nev++];
 }
 
-/* record what fn(arg...) writes: the two writers used by the walk */
+/* The two writers of the walk.  What they print depends on the block as it is NOW (the walk goes on cutting
+ * it), so the event keeps a copy; the text itself -- slicing, dash-column removal, scoring, formatting -- is
+ * produced later by render_events(), one event per thread. */
 static void rec_block(record *R, int sink, struct mafAli *a)
 {
     event *e = new_event(R, sink);
-    FILE *m = open_memstream(&e->text, &e->len);
-    mafWrite(m, a);
-    fclose(m);
+    e->src = clone_ali(a); e->cbeg = -1; e->cend = -1;
 }
 static void rec_part(record *R, int sink, struct mafAli *a, int cbeg, int cend)
 {
     event *e = new_event(R, sink);
-    FILE *m = open_memstream(&e->text, &e->len);
-    print_part_ali_col(a, cbeg, cend, m);
-    fclose(m);
+    e->src = clone_ali(a); e->cbeg = cbeg; e->cend = cend;
+}
+static void render_events(record *R)
+{
+    const int nev = R->nev;
+    int i;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nev > 64)
+    for (i = 0; i < nev; ++i) {
+        event *e = &R->ev[i];
+        FILE *m;
+        if (!e->src) continue;
+        m = open_memstream(&e->text, &e->len);
+        if (e->cbeg < 0) mafWrite(m, e->src);
+        else print_part_ali_col(e->src, e->cbeg, e->cend, m);
+        fclose(m);
+        e->src = NULL;
+    }
 }
 
 static void rec_merge(record *R, struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int v)
@@ -404,6 +454,7 @@ static void run_merges(record *R, int minw)
     double t0 = now_s(), t1;
     int i;
     mz_score_profile_sync();
+    render_events(R);
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)
     for (i = 0; i < nmg; ++i) {
         merge *g = &R->mg[i];
@@ -459,7 +510,7 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
             }
             if (g->text) { if (g->len) fwrite(g->text, 1, g->len, out); free(g->text); }
             mafAliFree(&g->result);
-            mafAliFree(&g->a1); mafAliFree(&g->a2);
+            g->a1 = g->a2 = NULL;                           /* (arena) */
         } else if (e->text) {
             if (f && e->len) fwrite(e->text, 1, e->len, f);
             free(e->text);
@@ -467,6 +518,7 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
     }
     free(R->ev); free(R->mg);
     memset(R, 0, sizeof *R);
+    arena_release();
 }
 
 int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
