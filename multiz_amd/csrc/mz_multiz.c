@@ -16,9 +16,11 @@
  * (multi_util.c:468-509), retrieve_first / seperate_cp_wk (multi_util.c:805-843) and the command line of
  * multiz (multiz.c:180-294).
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
 #include "../../include/maf.h"
 #include "../../include/mz_scores.h"
 #include "../../include/mz_multiz.h"
@@ -49,16 +51,13 @@ typedef struct { FILE *fp; const char *name; int line_nbr, verbose; char *line; 
 /* one line, newline kept; -1 at end of file */
 static long in_line(maf_in *in)
 {
-    size_t n = 0;
-    int ch;
-    while ((ch = fgetc(in->fp)) != EOF) {
-        if (n + 2 > in->cap) { in->cap += (in->cap >> 5) + 16; in->line = (char *)realloc(in->line, in->cap); if (!in->line) mz_fatalf("out of memory reading %s", in->name); }
-        in->line[n++] = (char)ch;
-        if (ch == '\n') break;
+    const ssize_t n = getline(&in->line, &in->cap, in->fp);
+    if (n < 0) {
+        if (!in->line) { in->line = (char *)xmalloc(16); in->cap = 16; }
+        in->line[0] = 0;
+        return -1;
     }
-    if (n + 1 > in->cap) { in->cap += 16; in->line = (char *)realloc(in->line, in->cap); }
-    in->line[n] = 0;
-    return (n == 0 && ch == EOF) ? -1 : (long)n;
+    return (long)n;
 }
 
 /* next line that is not a comment; comment lines are echoed to stdout when verbose, except the
