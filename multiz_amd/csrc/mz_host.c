@@ -63,6 +63,8 @@ typedef struct gbuf { void *p; size_t cap; } gbuf;
 
 #define MZ_SLICES 4                        /* (number of helper events) */
 
+#define MZ_SETS 4                          /* buffer sets of the chunk pipeline: uploading, computing, copying back, being unpacked */
+
 static struct {
     int ready;
     int device;
@@ -74,9 +76,9 @@ static struct {
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
-    gbuf h_in[2], d_in[2], d_plan[2], d_tb[2], d_script[2], d_out[2], d_prep[2], h_res[2];   /* two sets: chunk pipeline */
-    hipStream_t bstream[2];                /* one stream per set (mz_yama_batch) */
-    hipEvent_t bdone[2];
+    gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS];
+    hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
+    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
 } G;
 
 static int dev_reserve(gbuf *b, size_t need)
@@ -114,8 +116,12 @@ int mz_init(int device)
     /* the helper streams (mz_dev_run_async) and the second chunk stream are created on first use: a stream costs
      * ~9 ms of start-up and a short run -- one yama() call, one chunk -- needs none of them */
     G.stream2 = G.stream3 = NULL;
-    G.bstream[0] = G.stream; G.bstream[1] = NULL;
-    for (i = 0; i < 2; ++i) HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
+    G.bstream[0] = G.stream;
+    for (i = 1; i < MZ_SETS; ++i) G.bstream[i] = NULL;
+    for (i = 0; i < MZ_SETS; ++i) {
+        HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&G.bplan[i], hipEventDisableTiming));
+    }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
     G.device = device;
@@ -144,14 +150,16 @@ void mz_finalize(void)
     int s;
     if (!G.ready) return;
     hipStreamSynchronize(G.stream);
-    for (s = 0; s < 2; ++s) {
+    for (s = 0; s < MZ_SETS; ++s) {
         gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s] };
         if (G.bstream[s]) hipStreamSynchronize(G.bstream[s]);
         for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
         if (G.h_in[s].p)  { hipHostFree(G.h_in[s].p);  G.h_in[s].p = NULL;  G.h_in[s].cap = 0; }
         if (G.h_res[s].p) { hipHostFree(G.h_res[s].p); G.h_res[s].p = NULL; G.h_res[s].cap = 0; }
-        if (s == 1 && G.bstream[s]) hipStreamDestroy(G.bstream[s]);
+        if (G.h_tot[s].p) { hipHostFree(G.h_tot[s].p); G.h_tot[s].p = NULL; G.h_tot[s].cap = 0; }
+        if (s >= 1 && G.bstream[s]) hipStreamDestroy(G.bstream[s]);
         hipEventDestroy(G.bdone[s]);
+        hipEventDestroy(G.bplan[s]);
     }
     for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
@@ -412,8 +420,11 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
  * for a 2 ms loop costs more than it saves (and was seen to stall for 70-100 ms now and then) */
 #define MZ_COPY_THREADS 24
 
-/* one chunk of a host batch in flight: everything up to the asynchronous copy of its results is issued by
- * chunk_submit() on the stream of buffer set `set`; chunk_collect() waits for it and fills the caller's outs */
+/* One chunk of a host batch in flight, on the stream and buffers of set `set`, in three steps:
+ *   chunk_upload()  packs the jobs into pinned memory and issues the copy to the device, the plan and the copy of
+ *                   the plan's totals back (asynchronous: the host goes on to pack the next chunk);
+ *   chunk_launch()  waits for those totals, sizes the workspaces and issues the kernels and the copy of the results;
+ *   chunk_collect() waits for the results and fills the caller's outs. */
 typedef struct chunk {
     int set, n;
     const mz_job *jobs;
@@ -423,15 +434,15 @@ typedef struct chunk {
     double t_pack, t_plan;
 } chunk;
 
-static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
+static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
 {
-    double t0 = now_s(), t1, t2;
+    double t0 = now_s();
     hipStream_t st;
     mz_dev_batch b;
-    size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes, res_bytes;
+    size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes;
     char *h, *d;
     int32_t *hK, *hL, *hM, *hN, *hLB, *hRB;
-    int64_t *hoA, *hoB, *hoBand, totals[8];
+    int64_t *hoA, *hoB, *hoBand;
     uint8_t *hA, *hB;
     int p;
 
@@ -488,16 +499,30 @@ static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
             }
         }
     }
-    t1 = now_s();
+    c->t_pack = now_s() - t0;
     HIPCK(hipMemcpyAsync(G.d_in[set].p, G.h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
 
-    if (dev_reserve(&G.d_plan[set], mz_dev_plan_bytes(n))) return -1;
+    if (dev_reserve(&G.d_plan[set], mz_dev_plan_bytes(n)) || host_reserve(&G.h_tot[set], 8 * sizeof(int64_t))) return -1;
     mz_dev_carve(&b, G.d_plan[set].p);
     b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
     if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    t2 = now_s();
+    HIPCK(hipMemcpyAsync(G.h_tot[set].p, b.totals, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCK(hipEventRecord(G.bplan[set], st));
+    c->b = b;
+    return 0;
+}
+
+static int chunk_launch(chunk *c)
+{
+    const int set = c->set, n = c->n;
+    const double t0 = now_s();
+    hipStream_t st = G.bstream[set];
+    mz_dev_batch b = c->b;
+    const int64_t *totals = (const int64_t *)G.h_tot[set].p;
+    size_t res_bytes;
+
+    HIPCK(hipEventSynchronize(G.bplan[set]));
+    c->t_plan = now_s() - t0;
 
     if (dev_reserve(&G.d_tb[set], 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script[set], (size_t)totals[1] + 256) ||
         dev_reserve(&G.d_out[set], (size_t)totals[2] + 256) || dev_reserve(&G.d_prep[set], 4 * (size_t)totals[4] + 256))
@@ -523,7 +548,6 @@ static int chunk_submit(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     }
     HIPCK(hipEventRecord(G.bdone[set], st));
     c->b = b; c->out_bytes = totals[2];
-    c->t_pack = t1 - t0; c->t_plan = t2 - t1;
     return 0;
 }
 
@@ -563,19 +587,19 @@ static int chunk_collect(chunk *c)
     }
     if (oom) return set_err("out of memory for the output columns");
     if (getenv("MZ_TIMING"))
-        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms\n",
+        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, wait for H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms\n",
                 n, 1e3 * c->t_pack, 1e3 * c->t_plan, 1e3 * (t1 - t0), 1e3 * (now_s() - t1));
     return failed;
 }
 
-/* A batch of any size: chunks of at most 64 Ki pairs / ~1 GB of input columns run one after the other through
- * the same staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
+/* A batch of any size: chunks of at most 16 Ki pairs / ~1 GB of input columns go through four rotating sets of
+ * staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
  * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit. */
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
     static int max_pairs;
     int done = 0, failed = 0;
-    if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 65536; }
+    if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 16384; }
     if (n <= 0) return 0;
     {
         const int first = !G.ready && getenv("MZ_TIMING") != NULL;
@@ -589,35 +613,49 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
                            1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), 1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
     }
     {
-        /* two chunks in flight on two buffer sets and streams: while chunk i is being packed, uploaded and
-         * planned (the host waits for its sizes), the kernels and the result copy of chunk i-1 run; while the
-         * kernels of chunk i run, chunk i-1 is unpacked */
-        chunk ck[2];
-        int have_prev = 0, cur = 0;
-        while (done < n) {
-            size_t bytes = 0;
-            int m = 0, rc;
-            while (done + m < n && m < max_pairs && bytes < ((size_t)1 << 30)) {
-                const mz_job *j = &jobs[done + m];
-                if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1)
-                    bytes += (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1);
-                ++m;
+        /* Up to four chunks in flight on four buffer sets and streams: while chunk k is uploaded and planned the
+         * host packs chunk k+1; when the plan's totals of chunk k are in, its kernels and the copy of its results
+         * are issued; chunk k-1 is computing or copying back; chunk k-2 is unpacked.  The host does not wait for a
+         * copy or a kernel it could work beside. */
+        chunk ck[MZ_SETS];
+        int k = 0, up = 0, rc;
+#define NEXT_CHUNK(first, count) do { size_t bytes_ = 0; int m_ = 0; \
+            while ((first) + m_ < n && m_ < max_pairs && bytes_ < ((size_t)1 << 30)) { \
+                const mz_job *j_ = &jobs[(first) + m_]; \
+                if (j_->K >= 1 && j_->L >= 1 && j_->M >= 1 && j_->N >= 1) \
+                    bytes_ += (size_t)j_->K * j_->M + (size_t)j_->L * j_->N + 8 * ((size_t)j_->M + 1); \
+                ++m_; } (count) = m_; } while (0)
+        {
+            int m0;
+            NEXT_CHUNK(0, m0);
+            if (chunk_upload(&ck[0], 0, m0, jobs, outs)) return -1;
+            up = m0;
+        }
+        for (k = 0; done < n; ++k) {
+            chunk *cur = &ck[k % MZ_SETS];
+            if (up < n) {                                    /* pack + upload the next chunk beside this one's copy */
+                int m1;
+                NEXT_CHUNK(up, m1);
+                if (chunk_upload(&ck[(k + 1) % MZ_SETS], (k + 1) % MZ_SETS, m1, jobs + up, outs + up)) return -1;
+                up += m1;
             }
-            if (chunk_submit(&ck[cur], cur, m, jobs + done, outs + done)) return -1;
-            if (have_prev) {
-                rc = chunk_collect(&ck[cur ^ 1]);
+            if (chunk_launch(cur)) return -1;
+            if (k > 1) {
+                rc = chunk_collect(&ck[(k - 2) % MZ_SETS]);
                 if (rc < 0) return rc;
                 failed += rc;
             }
-            have_prev = 1;
-            cur ^= 1;
-            done += m;
+            done += cur->n;
         }
-        if (have_prev) {
-            const int rc = chunk_collect(&ck[cur ^ 1]);
+        if (k > 1) {
+            rc = chunk_collect(&ck[(k - 2) % MZ_SETS]);
             if (rc < 0) return rc;
             failed += rc;
         }
+        rc = chunk_collect(&ck[(k - 1) % MZ_SETS]);
+        if (rc < 0) return rc;
+        failed += rc;
+#undef NEXT_CHUNK
     }
     return failed;
 }
