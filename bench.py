@@ -69,11 +69,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in the product)")
+    # MZ_BENCH_SHARE_GPU=1 (development only): every rank on GPU 0 with a gloo group, to exercise the N > 1 control
+    # flow on a one-GPU box; the number it prints is not a scaling measurement
+    share = world > 1 and os.environ.get("MZ_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red = torch.device("cpu") if share else dev                 # where the closing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL
 
     import multiz_amd as mz
     from multiz_amd import api, synth
@@ -115,7 +124,7 @@ def main():
     elapsed = time.perf_counter() - t0
     workspaces = ring[:min(3, args.warmup + args.steps)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -123,7 +132,7 @@ def main():
     failed = int((res["status"] != 0).sum())
     total_bytes, cells = algorithmic_bytes(batch, res["om"])
     assert cells == int(res["cells"].sum()), "device cell count differs from the host count"
-    stats = torch.tensor([cells, pairs, failed], dtype=torch.float64, device=dev)
+    stats = torch.tensor([cells, pairs, failed], dtype=torch.float64, device=red)
     if world > 1:
         dist.all_reduce(stats)                                   # the batch-closing reduction
     all_cells, all_pairs, all_failed = (int(x) for x in stats.tolist())
