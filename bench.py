@@ -23,8 +23,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# CPU-baseline threads: spread over the cores at once (must be set before any libgomp is loaded)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
+# CPU-baseline threads (rank 0, N = 1 only): spread over the cores at once (must be set before any libgomp is loaded).
+# Not with N > 1: binding pins each process's initial thread to the first place -- the SAME core for every rank.
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # HBM bytes of one launch of the dominant kernel on the default c2 batch, from the PMC passes in profiles/
