@@ -8,6 +8,9 @@ extern "C" {
 /* all asynchronous on `stream` (a hipStream_t) */
 int mzk_upload_scores(const mz_score_model *m, void *stream);
 int mzk_plan(const mz_dev_batch *b, void *stream);
+/* expand the host path's delta-coded band bounds into the int32 pools (see k_unband) */
+int mzk_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
+               const uint8_t *packed, int32_t *poolLB, int32_t *poolRB, void *stream);
 int mzk_prep(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
 int mzk_walk(const mz_dev_batch *b, void *stream, int beside_dp);   /* beside_dp: another batch's DP runs at the same time */

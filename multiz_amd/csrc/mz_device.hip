@@ -2188,6 +2188,52 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Band bounds as the host path ships them (mz_yama_batch): LB and RB are monotone and move by a column or two per
+// row, so instead of 8 bytes per row (two thirds of a C2 pair's input) the staging block carries, per pair,
+//   format 1:  LB[0], RB[0] (int32), then M bytes LB[i]-LB[i-1], then M bytes RB[i]-RB[i-1]   (all steps 0..255)
+//   format 0:  LB[0..M], RB[0..M] as int32                                                    (anything else)
+// at byte offset offC[p] (4-byte aligned).  One wave per pair turns that back into the int32 pools every kernel reads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC,
+                                                 const uint8_t *fmt, const uint8_t *packed, int32_t *poolLB, int32_t *poolRB)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n) return;
+    const int M = bandLen[p] - 1;                       // entries 0..M (an invalid job carries one dummy entry)
+    int32_t *LB = poolLB + offBand[p], *RB = poolRB + offBand[p];
+    const uint8_t *src = packed + offC[p];
+    if (fmt[p] == 0) {
+        const int32_t *s = (const int32_t *)src;
+        for (int i = lane; i <= M; i += WAVE) { LB[i] = s[i]; RB[i] = s[M + 1 + i]; }
+        return;
+    }
+    int baseL = ((const int32_t *)src)[0], baseR = ((const int32_t *)src)[1];
+    const uint8_t *dL = src + 8, *dR = src + 8 + M;
+    if (lane == 0) { LB[0] = baseL; RB[0] = baseR; }
+    for (int i0 = 1; i0 <= M; i0 += WAVE) {
+        const int i = i0 + lane;
+        int x = i <= M ? dL[i - 1] : 0, y = i <= M ? dR[i - 1] : 0;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int a = __shfl_up(x, o), c = __shfl_up(y, o);
+            if (lane >= o) { x += a; y += c; }
+        }
+        if (i <= M) { LB[i] = baseL + x; RB[i] = baseR + y; }
+        baseL += __builtin_amdgcn_readlane(x, WAVE - 1);
+        baseR += __builtin_amdgcn_readlane(y, WAVE - 1);
+    }
+}
+
+extern "C" int mzk_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
+                          const uint8_t *packed, int32_t *poolLB, int32_t *poolRB, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_unband, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, bandLen, offBand, offC, fmt, packed, poolLB, poolRB);
+    CK(hipGetLastError(), "unband launch");
+    return 0;
+}
+
 extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
 {
     if (b->n <= 0) return 0;

@@ -76,7 +76,7 @@ static struct {
     /* last score tables handed to the device */
     int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
     /* grow-only buffers of the host-buffer path */
-    gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS];
+    gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS], d_band[MZ_SETS];
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
 } G;
@@ -151,9 +151,9 @@ void mz_finalize(void)
     if (!G.ready) return;
     hipStreamSynchronize(G.stream);
     for (s = 0; s < MZ_SETS; ++s) {
-        gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s] };
+        gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s], &G.d_band[s] };
         if (G.bstream[s]) hipStreamSynchronize(G.bstream[s]);
-        for (i = 0; i < 6; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+        for (i = 0; i < 7; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
         if (G.h_in[s].p)  { hipHostFree(G.h_in[s].p);  G.h_in[s].p = NULL;  G.h_in[s].cap = 0; }
         if (G.h_res[s].p) { hipHostFree(G.h_res[s].p); G.h_res[s].p = NULL; G.h_res[s].cap = 0; }
         if (G.h_tot[s].p) { hipHostFree(G.h_tot[s].p); G.h_tot[s].p = NULL; G.h_tot[s].cap = 0; }
@@ -441,9 +441,14 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     mz_dev_batch b;
     size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes;
     char *h, *d;
-    int32_t *hK, *hL, *hM, *hN, *hLB, *hRB;
-    int64_t *hoA, *hoB, *hoBand;
-    uint8_t *hA, *hB;
+    int32_t *hK, *hL, *hM, *hN, *hLen;
+    const int32_t *dLen;
+    int64_t *hoA, *hoB, *hoBand, *hoC;
+    const int64_t *doC;
+    uint8_t *hA, *hB, *hFmt, *hC;
+    const uint8_t *dFmt, *dC;
+    size_t bytesC = 0;
+    uint32_t *csz;
     int p;
 
     if (lazy_stream(&G.bstream[set])) return -1;
@@ -457,10 +462,30 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
         bytesB += ok ? (size_t)j->L * j->N : 0;
         nband += ok ? (size_t)j->M + 1 : 1;
     }
-    /* one pinned staging block: [K L M N](int32 x n) [offA offB offBand](int64 x n) LB RB A B */
-    hdr = al256(4 * (size_t)n) * 4 + al256(8 * (size_t)n) * 3;
-    in_bytes = hdr + 2 * al256(4 * nband) + al256(bytesA) + al256(bytesB);
-    if (host_reserve(&G.h_in[set], in_bytes) || dev_reserve(&G.d_in[set], in_bytes)) return -1;
+    /* how each pair's band bounds will travel (see below): decided first, in parallel, so that the staging block has
+     * their real size and the copy to the device moves no slack */
+    csz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *csz);
+    if (!csz) return set_err("out of memory");
+#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
+    for (p = 0; p < n; ++p) {
+        const mz_job *j = &jobs[p];
+        if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
+            const int M = j->M;
+            int i, small = 1;
+            for (i = 1; i <= M && small; ++i)
+                small = (unsigned)(j->LB[i] - j->LB[i - 1]) < 256u && (unsigned)(j->RB[i] - j->RB[i - 1]) < 256u;
+            /* bit 31: byte steps; low bits: bytes in the staging block, a multiple of 4 */
+            csz[p] = small ? (0x80000000u | (uint32_t)((8 + 2 * (size_t)M + 3) & ~(size_t)3)) : (uint32_t)(8 * ((size_t)M + 1));
+        } else csz[p] = 8;
+    }
+    for (p = 0; p < n; ++p) bytesC += csz[p] & 0x7fffffffu;
+    /* one pinned staging block: [K L M N bandLen](int32 x n) [offA offB offBand offC](int64 x n) fmt(n) bands A B.
+     * The band bounds travel delta-coded where they can (k_unband, mz_device.hip) and are expanded on the device
+     * into poolLB / poolRB, which live in a device-only buffer: they were two thirds of the input of a C2 pair. */
+    hdr = al256(4 * (size_t)n) * 5 + al256(8 * (size_t)n) * 4 + al256((size_t)n);
+    in_bytes = hdr + al256(bytesC) + al256(bytesA) + al256(bytesB);
+    if (host_reserve(&G.h_in[set], in_bytes) || dev_reserve(&G.d_in[set], in_bytes) ||
+        dev_reserve(&G.d_band[set], 2 * al256(4 * nband))) { free(csz); return -1; }
     h = (char *)G.h_in[set].p; d = (char *)G.d_in[set].p;
 
     memset(&b, 0, sizeof b);
@@ -471,18 +496,25 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     SLICE(hM, int32_t, M, 4 * (size_t)n); SLICE(hN, int32_t, N, 4 * (size_t)n);
     SLICE(hoA, int64_t, offA, 8 * (size_t)n); SLICE(hoB, int64_t, offB, 8 * (size_t)n);
     SLICE(hoBand, int64_t, offBand, 8 * (size_t)n);
-    SLICE(hLB, int32_t, poolLB, 4 * nband); SLICE(hRB, int32_t, poolRB, 4 * nband);
+    hLen = (int32_t *)h; dLen = (const int32_t *)d; h += al256(4 * (size_t)n); d += al256(4 * (size_t)n);
+    hoC = (int64_t *)h; doC = (const int64_t *)d; h += al256(8 * (size_t)n); d += al256(8 * (size_t)n);
+    hFmt = (uint8_t *)h; dFmt = (const uint8_t *)d; h += al256((size_t)n); d += al256((size_t)n);
+    hC = (uint8_t *)h; dC = (const uint8_t *)d; h += al256(bytesC); d += al256(bytesC);
     SLICE(hA, uint8_t, poolA, bytesA); SLICE(hB, uint8_t, poolB, bytesB);
 #undef SLICE
+    b.poolLB = (const int32_t *)G.d_band[set].p;
+    b.poolRB = (const int32_t *)((char *)G.d_band[set].p + al256(4 * nband));
     {
-        size_t oa = 0, ob = 0, oband = 0;
+        size_t oa = 0, ob = 0, oband = 0, oc = 0;
         for (p = 0; p < n; ++p) {                            /* offsets first ... */
             const mz_job *j = &jobs[p];
             int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
             hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
-            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband;
+            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
+            hLen[p] = ok ? j->M + 1 : 1;
             if (ok) { oa += (size_t)j->K * j->M; ob += (size_t)j->L * j->N; oband += (size_t)j->M + 1; }
             else oband += 1;
+            oc += csz[p] & 0x7fffffffu;
         }
         /* ... then the copies into the pinned staging block, on all host threads (a single thread moves
          * ~14 GB/s: 18 ms for the 240 MB of a 20 000-pair C2 batch, three times the GPU work) */
@@ -492,15 +524,29 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
             if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
                 memcpy(hA + hoA[p], j->A, (size_t)j->K * j->M);
                 memcpy(hB + hoB[p], j->B, (size_t)j->L * j->N);
-                memcpy(hLB + hoBand[p], j->LB, 4 * ((size_t)j->M + 1));
-                memcpy(hRB + hoBand[p], j->RB, 4 * ((size_t)j->M + 1));
+                {   /* band bounds: byte steps when every step of LB and RB is 0..255, raw otherwise */
+                    const int M = j->M, small = (csz[p] >> 31) != 0;
+                    uint8_t *c8 = hC + hoC[p];
+                    int i;
+                    hFmt[p] = (uint8_t)small;
+                    if (small) {
+                        ((int32_t *)c8)[0] = j->LB[0]; ((int32_t *)c8)[1] = j->RB[0];
+                        for (i = 1; i <= M; ++i) { c8[8 + i - 1] = (uint8_t)(j->LB[i] - j->LB[i - 1]); c8[8 + M + i - 1] = (uint8_t)(j->RB[i] - j->RB[i - 1]); }
+                    } else {
+                        memcpy(c8, j->LB, 4 * ((size_t)M + 1));
+                        memcpy(c8 + 4 * ((size_t)M + 1), j->RB, 4 * ((size_t)M + 1));
+                    }
+                }
             } else {
-                hLB[hoBand[p]] = hRB[hoBand[p]] = 0;
+                hFmt[p] = 0;
+                memset(hC + hoC[p], 0, 8);
             }
         }
     }
+    free(csz);
     c->t_pack = now_s() - t0;
     HIPCK(hipMemcpyAsync(G.d_in[set].p, G.h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
+    if (mzk_unband(n, dLen, b.offBand, doC, dFmt, dC, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st)) return set_err("%s", mzk_last_error());
 
     if (dev_reserve(&G.d_plan[set], mz_dev_plan_bytes(n)) || host_reserve(&G.h_tot[set], 8 * sizeof(int64_t))) return -1;
     mz_dev_carve(&b, G.d_plan[set].p);

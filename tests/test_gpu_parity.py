@@ -327,6 +327,33 @@ def _check(res, pairs, tags=None, exact_scores=True):
             assert np.array_equal(r.score[live], want.final[live]), tag
 
 
+def test_band_steps_that_do_not_fit_a_byte(mz):
+    # mz_yama_batch() ships LB / RB as byte steps where every step is 0..255 and raw otherwise: a band that jumps by
+    # hundreds of columns per row (legal: monotone, connected, wide enough) must take the raw route, next to ordinary
+    # pairs in the same call, and give the reference's result
+    rng = np.random.default_rng(77)
+    pairs = []
+    for M, N, step in ((6, 2000, 300), (9, 3000, 320), (40, 1200, 0)):
+        A = inputs.random_block(rng, M, 2, dash=0.05, odd=0.02)
+        B = inputs.noisy_copy(rng, A, N, 3, dash=0.05)
+        if step:
+            LB = np.array([0, 0] + [min(step * i, N - 500) for i in range(1, M)], dtype=np.int32)
+            RB = np.array([min(step * (i + 1) + 100, N) for i in range(M)] + [N], dtype=np.int32)
+            RB = np.maximum.accumulate(RB)
+        else:
+            LB, RB = mo.smooth(*inputs.diag_band(M, N), M, N, 30)
+        assert mo.check(M, N, LB, RB)[0] == 0
+        pairs.append((A, B, LB, RB))
+    assert max(int(np.diff(p[2]).max()) for p in pairs[:2]) > 255
+    for kset in (2, 1, 0):
+        _kernels(mz, kset)
+        res = mz.yama_batch(pairs)
+        for i, (p, r) in enumerate(zip(pairs, res)):
+            w = mo.yama(*p)
+            assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), (kset, i)
+    _kernels(mz, 2)
+
+
 def test_host_batches_are_chunked(tmp_path):
     # mz_yama_batch() runs big batches in chunks through the same staging buffers (MZ_CHUNK_PAIRS=7 here, read
     # once per process, hence the subprocess): results must not depend on the chunking
