@@ -638,15 +638,18 @@ static int chunk_collect(chunk *c)
     return failed;
 }
 
-/* A batch of any size: chunks of at most 16 Ki pairs / ~1 GB of input columns go through four rotating sets of
- * staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
+/* A batch of any size: chunks of 1 Ki - 16 Ki pairs / at most ~1 GB of input columns go through four rotating sets
+ * of staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
  * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit. */
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
-    static int max_pairs;
-    int done = 0, failed = 0;
-    if (!max_pairs) { const char *e = getenv("MZ_CHUNK_PAIRS"); max_pairs = e && atoi(e) > 0 ? atoi(e) : 16384; }
+    static int env_pairs = -1;
+    int done = 0, failed = 0, max_pairs;
+    if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (n <= 0) return 0;
+    /* chunk size: about a quarter of the call, so that even a few thousand pairs overlap their copies with their
+     * kernels, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU) and at most 16 Ki */
+    max_pairs = env_pairs ? env_pairs : (n + 3) / 4 < 1024 ? 1024 : (n + 3) / 4 > 16384 ? 16384 : (n + 3) / 4;
     {
         const int first = !G.ready && getenv("MZ_TIMING") != NULL;
         struct timespec t0, t1, t2;

@@ -4,7 +4,8 @@ import multiz_amd as mz
 from multiz_amd import synth, api
 mz.api.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-c = synth.CONFIGS["c2"]
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+c = synth.CONFIGS[cfg]
 batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=0)
 jobs = (api.Job * n)(); outs = (api.Out * n)()
 for i in range(n):
@@ -20,4 +21,4 @@ for rep in range(3):
     dt = time.perf_counter() - t
     assert rc == 0
     for i in range(n): mz.lib().free_cols(outs[i].cols)
-    print(f"mz_yama_batch({n} c2 pairs, host buffers in, malloc'ed columns out): {dt*1e3:.1f} ms -> {cells/dt/1e9:.1f} GCUPS")
+    print(f"mz_yama_batch({n} {cfg} pairs, host buffers in, malloc'ed columns out): {dt*1e3:.1f} ms -> {cells/dt/1e9:.1f} GCUPS")
