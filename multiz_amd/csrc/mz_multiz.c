@@ -633,7 +633,7 @@ int mz_multiz_main(int argc, char **argv)
  * (:228-254).  A condition the stock program dies of in the middle of the enumeration (multic.c:139,161,176) is
  * raised at the same point of the output. */
 
-typedef struct { struct mafAli *ali; char *unused; } cnode;
+typedef struct { struct mafAli *ali; char *unused; char *text; size_t len; } cnode;
 typedef struct {
     mz_py py;
     cnode *a, *b;
@@ -660,6 +660,7 @@ static cnode *cnode_list(struct mafAli *list, int *count)      /* create_aliNode
     v = (cnode *)xmalloc((size_t)n * sizeof *v);
     for (i = 0; i < n; ++i) {
         v[i].ali = pop_first(&list);
+        v[i].text = NULL; v[i].len = 0;
         v[i].unused = (char *)xmalloc((size_t)v[i].ali->textSize + 1);
         memset(v[i].unused, 'u', (size_t)v[i].ali->textSize);
     }
@@ -821,6 +822,7 @@ int mz_multic_main(int argc, char **argv)
     FILE *fpw[2];
     crecord R;
     int radius = 30, minw = 1, nohead = 0, v, i, k, x, stop = 0;
+    double tm[4];
     size_t na = 64;
     const char *usage =
         "args: [R=?] [M=?] [C=?] file1 file2 v? [out1 out2] [nohead] [all]\n"
@@ -859,9 +861,11 @@ int mz_multic_main(int argc, char **argv)
     mallopt(M_TOP_PAD, 256 << 20);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    tm[0] = now_s();
     init_scores70();
     l1 = mz_maf_read_all(argv[1], 1);
     l2 = mz_maf_read_all(argv[2], 1);
+    tm[1] = now_s();
 
     memset(&R, 0, sizeof R);
     while (l1 && l2) {                                      /* one reference contig at a time, in file-1 order */
@@ -882,7 +886,9 @@ int mz_multic_main(int argc, char **argv)
         if (C->fatal) stop = 1;                             /* the stock program ends there: nothing later is aligned */
     }
     /* (the merges point into the cnode arrays, which do not move; R.mg may have: pointers into it are taken below) */
+    tm[2] = now_s();
     run_multic(&R, radius, v, minw);
+    tm[3] = now_s();
 
     for (k = 0; k < R.nct; ++k) {
         ccontig *C = &R.ct[k];
@@ -898,17 +904,32 @@ int mz_multic_main(int argc, char **argv)
             mark_used(g->b, g->rbeg, g->rend);
         }
         if (C->fatal) mz_fatalf("%s", C->fatal);
-        for (x = 0; x < 2; ++x) {
+        for (x = 0; x < 2; ++x) {                           /* the unused stretches: rendered one block per thread ... */
+            cnode *list = x ? C->B : C->A;
+            const int n = x ? C->nb : C->na;
+            if (!fpw[x]) continue;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
+            for (i = 0; i < n; ++i)
+                if (list[i].ali->textSize >= minw) {
+                    FILE *m = open_memstream(&list[i].text, &list[i].len);
+                    print_unused_multic(&list[i], m);
+                    fclose(m);
+                }
+        }
+        for (x = 0; x < 2; ++x) {                           /* ... and written in order */
             cnode *list = x ? C->B : C->A;
             const int n = x ? C->nb : C->na;
             for (i = 0; i < n; ++i) {
-                if (fpw[x] && list[i].ali->textSize >= minw) print_unused_multic(&list[i], fpw[x]);
+                if (list[i].text) { if (list[i].len) fwrite(list[i].text, 1, list[i].len, fpw[x]); free(list[i].text); }
                 mafAliFree(&list[i].ali);
                 free(list[i].unused);
             }
             free(list);
         }
     }
+    if (getenv("MZ_TIMING"))
+        fprintf(stderr, "mz_multic: read %.3f s, enumerate %.3f s (%d merges), stages + yama batches %.3f s, replay + unused parts %.3f s\n",
+                tm[1] - tm[0], tm[2] - tm[1], R.nmg, tm[3] - tm[2], now_s() - tm[3]);
     free(R.mg); free(R.ct);
 
     for (a = l1; a; a = a->next)                            /* contigs that only one file has */
