@@ -1,0 +1,36 @@
+/* mz_drivers.h -- internal: what the batched command-line drivers (mz_multiz.c, mz_multic.c) share:
+ * the MAF reader and list helpers of mz_mafio.c, the staged pre_yama() of mz_py.h, small utilities. */
+#ifndef MZAMD_MZ_DRIVERS_H
+#define MZAMD_MZ_DRIVERS_H
+
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/types.h>
+#include <time.h>
+#include <malloc.h>
+#include "../../include/maf.h"
+#include "../../include/mz_scores.h"
+#include "../../include/mz_multiz.h"
+#include "mz_py.h"
+
+__attribute__((noreturn)) void mz_fatalf(const char *fmt, ...);
+__attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o);
+extern int row2;
+extern char *argv0;
+
+#define MZ_STAGE_THREADS 32     /* host threads of the per-merge stages (allocation-heavy: more does not help) */
+#define MERGE_FAILED 99         /* merge state: yama() refused the job (beside the MZ_PY_* states) */
+
+/* MZ_TIMING=1: phase times of a run on stderr */
+static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+/* mz_mafio.c */
+void *mz_xmalloc(size_t n);
+char *mz_xstrdup(const char *s);
+struct mafAli *mz_pop_first(struct mafAli **head);
+void mz_take_chr(struct mafAli **from, struct mafAli **to, const char *chr);   /* blocks on contig chr, order kept */
+void mz_tune_malloc(void);                                                     /* heap growth in big steps */
+
+#endif
