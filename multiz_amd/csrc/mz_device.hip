@@ -251,7 +251,7 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
 {
     if (count <= 0) return 0;
     hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_emit_wide, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "emit launch");
     return 0;
 }
