@@ -13,9 +13,14 @@
 #include "maf.h"
 #include "mz_yama.h"
 
-struct pwuAliFiles;       /* reference align_util.h; only pre_yama2 (no caller in the tree) uses it */
+struct pwuAliFiles;       /* reference align_util.h:51-54; opaque here */
 
 struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, int radius, int reference, FILE *fpw2);
+/* reference mz_preyama.h:27 / mz_preyama.c:386-521 (no caller in the reference tree): merge the slice of a2 over
+ * X[beg1..end1] with the slice of a3 over Y[begN..endN], the band taken from the pairwise alignment a1 of X and Y.
+ * Calls the caller's connectionAgreement2() (reference align_util.c; a weak reference in the library). */
+struct mafAli *pre_yama2(struct mafAli *a1, struct mafAli *a2, struct mafAli *a3, int beg1, int end1,
+                         int begN, int endN, int radius, struct pwuAliFiles *pws);
 
 void smooth(int *LB, int *RB, int M, int N, int radius);                                   /* :17-35  */
 struct mafAli *mafBuild(uchar **A_new, int nrow, int ncol, struct mafAli *a2, int cbeg2,

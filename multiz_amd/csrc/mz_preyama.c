@@ -2,6 +2,7 @@
  * pre_yama() itself, with the reference's names so that stock drivers link unchanged
  * (reference mz_preyama.c:17-35 here).
  */
+#define _GNU_SOURCE            /* RTLD_DEFAULT (pre_yama2) */
 #include <stdlib.h>
 #include "../../include/mz_preyama.h"
 
@@ -361,4 +362,120 @@ struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, 
         st = mz_py_step(&p, flat, om, &result);
     }
     return result;
+}
+
+/* ------------------------------------------------------------------------------------------------ pre_yama2
+ * The three-block form (reference mz_preyama.c:360-521; declared in mz_preyama.h:27, no caller in the reference
+ * tree): a1 is a PAIRWISE alignment of sequence X (top row) and sequence Y; a2 is a block topped by X, a3 a block
+ * topped by Y; the slices of a2 over X[beg1..end1] and of a3 over Y[begN..endN] are merged, with the band taken from
+ * how a1 pairs the positions of X and Y.  connectionAgreement2() (reference align_util.c:520-) decides from the
+ * pairwise files in `pws` whether the merge is wanted at all; it lives in the caller's align_util.o (a weak
+ * reference here: an executable that calls pre_yama2 links it, nothing else needs it). */
+#include <ctype.h>
+#include <stdio.h>
+#include <dlfcn.h>
+
+extern int connectionAgreement2(struct mafAli *a2, struct mafAli *a3, int cbeg2, int cend2, int cbeg3, int cend3,
+                                struct pwuAliFiles *pws) __attribute__((weak));
+
+/* the reference's must_equal(), mz_preyama.c:361-383: same text on stderr (no program-name prefix), exit(1) */
+static void rows_must_agree(char x, char y, int pos, struct mafComp *c1, int cbeg1, int cend1,
+                            struct mafComp *c2, int cbeg2, int cend2, int file2)
+{
+    int i;
+    char z;
+    if (toupper((unsigned char)x) == toupper((unsigned char)y)) return;
+    fprintf(stderr, "%c != %c\n", x, y);
+    fprintf(stderr, "in file 1, positions %d... of %s are:\n  ", pos, c1->src);
+    for (i = cbeg1; i <= cend1; ++i)
+        if ((z = c1->text[i]) != '-') fputc(z, stderr);
+    fputc('\n', stderr);
+    fprintf(stderr, "while in file %d they are:\n  ", file2);
+    for (i = cbeg2; i <= cend2; ++i)
+        if ((z = c2->text[i]) != '-') fputc(z, stderr);
+    fputc('\n', stderr);
+    exit(1);
+}
+
+struct mafAli *pre_yama2(struct mafAli *a1, struct mafAli *a2, struct mafAli *a3, int beg1, int end1,
+                         int begN, int endN, int radius, struct pwuAliFiles *pws)
+{
+    struct mafAli *val;
+    struct mafComp *c, *c1, *c2, *c3, *d;
+    int cbeg1, cend1, cbeg2, cend2, cbeg3, cend3, i, j, k, M, N, K, L, M_new, *LB, *RB;
+    uchar **A, **B, **AL_new;
+
+    if ((c = a1->components) == NULL || (c1 = c->next) == NULL) mz_fatalf("pre_yama: cannot find c and c1");
+    if (c1->next != NULL) mz_fatalf("pre_yama: a1 is not a pairwise alignment");
+    for (d = c2 = a2->components, K = 0; d != NULL; ++K, d = d->next)
+        ;
+    for (d = c3 = a3->components, L = 0; d != NULL; ++L, d = d->next)
+        ;
+    if (K == 0 || L == 0) mz_fatalf("pre_yama: an alignment has 0 rows");
+    if (strcmp(c->src, c2->src) != 0) mz_fatalf("pre_yama: first rows for sequences %s != %s", c->src, c2->src);
+    if (c->srcSize != c2->srcSize)          /* (the reference prints c1's size as the second number) */
+        mz_fatalf("pre_yama: first row srcSizes %d != %d", c->srcSize, c1->srcSize);
+    if (c->strand != c2->strand) mz_fatalf("pre_yama: first rows on opposite strands");
+    if (strcmp(c1->src, c3->src) != 0) mz_fatalf("pre_yama: first rows (2) for sequences %s != %s", c1->src, c3->src);
+    if (c1->srcSize != c3->srcSize) mz_fatalf("pre_yama: first row (2) srcSizes %d != %d", c1->srcSize, c3->srcSize);
+    if (c1->strand != c3->strand) mz_fatalf("pre_yama: first rows (2) on opposite strands");
+
+    cbeg1 = mafPos2Col(c, beg1, a1->textSize);
+    cend1 = mafPos2Col(c, end1, a1->textSize);
+    if (cbeg1 != mafPos2Col(c1, begN, a1->textSize)) mz_fatalf("pre_yama: mismatch of beg1 and begN");
+    if (cend1 != mafPos2Col(c1, endN, a1->textSize)) mz_fatalf("pre_yama: mismatch of end1 and endN");
+    cbeg2 = mafPos2Col(c2, beg1, a2->textSize);
+    cend2 = mafPos2Col(c2, end1, a2->textSize);
+    cbeg3 = mafPos2Col(c3, begN, a3->textSize);
+    cend3 = mafPos2Col(c3, endN, a3->textSize);
+
+    {   /* the executable's (weak reference, bound when the library is loaded) or one loaded later (tests) */
+        typedef int (*agree_fn)(struct mafAli *, struct mafAli *, int, int, int, int, struct pwuAliFiles *);
+        agree_fn agree = connectionAgreement2 ? connectionAgreement2 : (agree_fn)dlsym(RTLD_DEFAULT, "connectionAgreement2");
+        if (!agree) mz_fatalf("pre_yama2: connectionAgreement2() (align_util.c) is not linked in");
+        if (agree(a2, a3, cbeg2, cend2, cbeg3, cend3, pws) == 0) return NULL;
+    }
+
+    M = cend2 - cbeg2 + 1;
+    N = cend3 - cbeg3 + 1;
+    if ((M > N ? M : N) < 2) return NULL;
+
+    A = cols_new(M, K);
+    for (i = 1; i <= M; ++i)
+        for (j = 0, d = c2; j < K; ++j, d = d->next) A[i][j] = (uchar)d->text[cbeg2 + i - 1];
+    B = cols_new(N, L);
+    for (i = 1; i <= N; ++i)
+        for (j = 0, d = c3; j < L; ++j, d = d->next) B[i][j] = (uchar)d->text[cbeg3 + i - 1];
+
+    /* the band: column k of a1 pairs column i of A with column j of B; for a given i, LB[i] / RB[i] are the least
+     * and greatest such j (mz_preyama.c:461-497) */
+    LB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    RB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
+    for (i = 0; i <= M; ++i) { LB[i] = 0; RB[i] = N; }
+    for (i = j = 0, k = cbeg1; k <= cend1; ++k) {
+        uchar x, y, z;
+        if ((x = (uchar)c->text[k]) != '-') {
+            do {
+                if (++i > M) mz_fatalf("pre_yama: bad scene");
+            } while ((z = A[i][0]) == '-');
+            rows_must_agree((char)x, (char)z, beg1, c, cbeg1, cend1, c2, cbeg2, cend2, 2);
+        }
+        if ((y = (uchar)c1->text[k]) != '-') {
+            do {
+                if (++j > N) mz_fatalf("pre_yama: ouch");
+            } while ((z = B[j][0]) == '-');
+            rows_must_agree((char)y, (char)z, begN, c1, cbeg1, cend1, c3, cbeg3, cend3, 3);
+        }
+        if (LB[i] == 0) LB[i] = j;
+        RB[i] = j;
+    }
+    if (i != M || j != N) mz_fatalf("pre_yama: i = %d, M = %d, j = %d, N = %d", i, M, j, N);
+
+    smooth(LB, RB, M, N, radius);
+    yama(A, K, M, B, L, N, LB, RB, &AL_new, &M_new);
+    val = mafBuild(AL_new, K + L, M_new, a2, cbeg2, a3, cbeg3, 1);
+
+    cols_free(AL_new); cols_free(A); cols_free(B);
+    free(LB); free(RB);
+    return val;
 }

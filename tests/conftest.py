@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: it carries its own copy of the HIP runtime, and libmzamd.so (linked against /opt/rocm's) must find that
+# one already loaded -- two HIP runtimes in one process do not share a device.  (multiz_amd.api does the same; a test
+# that loads the library with ctypes before anything imported torch would otherwise decide the order.)
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -31,7 +31,7 @@ def _declared_functions():
 
 def test_every_declared_entry_point_is_exported(lib):
     names = _declared_functions()
-    assert {"yama", "pre_yama", "smooth", "mafBuild", "rmColDash", "mapping", "init_scores70", "init_scores85",
+    assert {"yama", "pre_yama", "pre_yama2", "smooth", "mafBuild", "rmColDash", "mapping", "init_scores70", "init_scores85",
             "mafScoreRange", "mz_yama_batch", "mz_dev_run", "mz_init"} <= names
     missing = [n for n in sorted(names) if not hasattr(lib, n)]
     assert not missing, missing

@@ -174,3 +174,70 @@ def test_product_score_range_profile_and_literal():
     finally:
         C.c_void_p.in_dll(lib, "ss").value = saved
         lib.init_scores70()
+
+
+# ------------------------------------------------------------------ pre_yama2 (three blocks; no caller in the reference)
+
+def _three_blocks(rng, nrows2, nrows3, length):
+    """X and a diverged copy Y; a1 = their pairwise alignment, a2 = a block topped by X, a3 = a block topped by Y;
+    returns (a1, a2, a3, beg1, end1, begN, endN) with both ends on columns of a1 that pair a base with a base"""
+    X = inputs.ACGT[rng.integers(0, 4, size=length)]
+    xs, ys, Y = [], [], []
+    for p in range(length):
+        u = rng.random()
+        if u < 0.05:                                   # a base only X has
+            xs.append(int(X[p])); ys.append(inputs.DASHB)
+            continue
+        if u < 0.10:                                   # bases only Y has, then the pair
+            for _ in range(int(rng.integers(1, 4))):
+                b = int(inputs.ACGT[rng.integers(0, 4)])
+                xs.append(inputs.DASHB); ys.append(b); Y.append(b)
+        b = int(X[p]) if rng.random() < 0.85 else int(inputs.ACGT[rng.integers(0, 4)])
+        xs.append(int(X[p])); ys.append(b); Y.append(b)
+    Y = np.array(Y, dtype=np.uint8)
+    txt = lambda v: bytes(v).decode("ascii")          # noqa: E731
+    a1 = mo.Block(rows=[mo.Row(src="xs.chr1", start=0, size=length, strand="+", srcSize=length + 1000, text=txt(xs)),
+                        mo.Row(src="ys.chr1", start=0, size=len(Y), strand="+", srcSize=len(Y) + 1000, text=txt(ys))])
+    a2 = inputs.random_maf_block(rng, X, 0, length, nrows2, "p")
+    a2.rows[0].src = "xs.chr1"
+    a3 = inputs.random_maf_block(rng, Y, 0, len(Y), nrows3, "q")
+    a3.rows[0].src = "ys.chr1"
+    both = [k for k in range(len(xs)) if xs[k] != inputs.DASHB and ys[k] != inputs.DASHB]
+    cb, ce = both[int(rng.integers(0, len(both) // 3))], both[int(rng.integers(2 * len(both) // 3, len(both)))]
+    pos = lambda row, col: sum(1 for ch in row[:col] if ch != inputs.DASHB)   # noqa: E731
+    return a1, a2, a3, pos(xs, cb), pos(xs, ce), pos(ys, cb), pos(ys, ce)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not mo.have_reference(), reason="oracle/_ref/libref.so not built")
+def test_product_preyama2_matches_reference(product, tmp_path):
+    # connectionAgreement2() is the caller's (align_util.c); a stand-in that always agrees is loaded globally, so this
+    # compares pre_yama2 itself: checks, slicing, the band from the pairwise alignment, yama() -- on the GPU for the
+    # product -- and mafBuild(..., top = 1).  The reference is loaded from a private copy of libref.so AFTER the
+    # stand-in: an instance loaded earlier in the session keeps calling its own connectionAgreement2(), with pws = NULL.
+    import shutil
+    stub = os.path.join(ROOT, "oracle", "libca2stub.so")
+    if not os.path.exists(stub):
+        pytest.skip("oracle/libca2stub.so not built")
+    C.CDLL(stub, mode=C.RTLD_GLOBAL)
+    private = str(tmp_path / "libref_private.so")
+    shutil.copy(mo.REF_PATH, private)
+    ref = mo.Reference(private)
+    sig = [C.POINTER(mo.MafAli)] * 3 + [C.c_int] * 5 + [C.c_void_p]
+    for lib in (ref.lib, product):
+        lib.pre_yama2.restype = C.POINTER(mo.MafAli)
+        lib.pre_yama2.argtypes = sig
+    rng = np.random.default_rng(1234)
+    done = 0
+    for _ in range(40):
+        a1, a2, a3, beg1, end1, begN, endN = _three_blocks(rng, int(rng.integers(1, 5)), int(rng.integers(1, 5)), int(rng.integers(80, 400)))
+        R = int(rng.choice([15, 30, 50]))
+        outs = []
+        for lib in (ref.lib, product):
+            keep = mo._Keep()
+            c1, c2, c3 = (mo.block_to_c(x, keep) for x in (a1, a2, a3))
+            p = lib.pre_yama2(C.byref(c1), C.byref(c2), C.byref(c3), beg1, end1, begN, endN, R, None)
+            outs.append(mo.block_from_c(p))
+        assert same_block(outs[1], outs[0])
+        done += outs[0] is not None
+    assert done >= 30
