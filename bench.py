@@ -55,7 +55,7 @@ def fnv_rows(cols, om):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)    # (a step is ~6 ms; the pipeline's fill and drain cost ~2.5 ms per run)
+    ap.add_argument("--steps", type=int, default=100)   # (a step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=["c2", "c3"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
