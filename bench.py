@@ -1,45 +1,129 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS (DP cell updates / s) of the yama block-pair merge on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scatter]
 
-A "step" is one pass of the whole hot path -- validity/plan, banded DP with traceback bytes,
-traceback walk, merged-column emit (reference mz_yama.c:58-313) -- over one batch of synthetic
-block pairs that is already resident in HBM.  Workload at N=1: BASELINE.json configs[1]
-("50k synthetic block pairs, 2+2 rows, ~1k x 1k cols, banded yama DP on 1 MI355X"); with N > 1
-every rank runs its own 50k-pair shard of the same generator (weak scaling, no data-path
-collective: block pairs are independent; one all-reduce of three scalars closes the batch).
+A "step" is one pass of the whole hot path -- validity/plan, banded DP with traceback, traceback walk,
+merged-column emit (reference mz_yama.c:58-313) -- over one batch of synthetic block pairs that is already
+resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("50k synthetic block pairs, 2+2 rows, ~1k x 1k
+cols, banded yama DP on 1 MI355X"); --config picks another BASELINE configuration (c3 deep sum-of-pairs, c4 one
+GPU's share of the 30-leaf guide-tree workload, c5 long blocks).  With N > 1 every rank runs its own shard of the
+same generator (weak scaling, no data-path collective: block pairs are independent; one all-reduce of three
+scalars closes the batch).  --scatter instead builds the WHOLE list on rank 0 and deals it out through
+multiz_amd.shard (RCCL point-to-point scatter, device compute on the received tensors, gather) before the timed
+steps -- BASELINE configs[3]'s "sharded over 8 x MI355X via RCCL" as one command; the exchange times are reported
+beside the value.  `--gpus N` without a torch.distributed environment starts the N ranks itself.
 
-Cells are band cells, counted exactly as the reference counts tback_size (mz_yama.c:60-66).
-One JSON line on stdout (rank 0).
+One JSON line on stdout (rank 0).  `value` is the whole-job rate of the pipelined, device-resident form.  Beside it
+(SURVEY.md section 8d asks for both columns): `value_host` = the same batch through mz_yama_batch() from host
+buffers to malloc()ed merged columns, PCIe both ways included (N=1), and `kernel_gcups` = the phases one after the
+other from HIP events.  Cells are band cells, counted exactly as the reference counts tback_size (mz_yama.c:60-66).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# CPU-baseline threads (rank 0, N = 1 only): spread over the cores at once (must be set before any libgomp is loaded).
-# Not with N > 1: binding pins each process's initial thread to the first place -- the SAME core for every rank.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# HBM bytes of one launch of the dominant kernel on the default c2 batch, from the PMC passes in profiles/
-# (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs).  Measured, never estimated; valid for the default
-# c2 batch only.
-# k_dp_row on the c2 batch, profiles/r1h_pmc_summary.txt: FETCH_SIZE 355 553 KB (narrow coalesced reads are
-# counted at one half on gfx950: x2) + WRITE_SIZE 2 438 496 KB
-TRAFFIC_BYTES_PER_LAUNCH = (2 * 355553 + 2438496) * 1024
+# PMC figures of one launch of the dominant kernel on the DEFAULT c2 batch (50 000 pairs), from the separate rocprofv3
+# --pmc passes summarised in profiles/r2_pmc_summary.txt.  Measured, never estimated; reported only for that batch.
+#   FETCH_SIZE 355 553 KB (narrow coalesced reads: x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2 438 496 KB
+PMC_C2 = {"traffic": (2 * 355553 + 2438496) * 1024, "valu_insts": 2835120086}
+# VALU issue: integer max / dot2 / cndmask / DPP wave-instructions occupy a SIMD for 4 shader cycles on gfx950
+# (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt; v_add/v_sub/v_and: 2-3); 1024 SIMDs.
+VALU_CYCLES = 4.0
+SIMDS = 1024
+CLOCK_GHZ = 2.4
 
+
+def spawn_ranks(args):
+    """--gpus N given, no torch.distributed environment: start the N ranks as child processes (before this process
+    touches the GPU) and exit with their status"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+# ------------------------------------------------------------------------------------------ CPU leg (child process)
+
+def one_socket_cores():
+    """one logical CPU per physical core of the socket CPU 0 sits on (sysfs topology); model name"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        pkg0 = open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % allowed[0]).read().strip()
+        seen, cpus = set(), []
+        for c in allowed:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            if open(base + "physical_package_id").read().strip() != pkg0:
+                continue
+            core = open(base + "core_id").read().strip()
+            if core not in seen:
+                seen.add(core)
+                cpus.append(c)
+        return cpus, model
+    except OSError:
+        return sorted(os.sched_getaffinity(0)), model
+
+
+def cpu_leg(spec_path):
+    """Child process, never touches the GPU: the reference's yama() (oracle/_ref/libref.so; the oracle's faithful
+    restatement when that is absent) on a seeded sample of the same batch, one pair per OpenMP thread on the
+    physical cores of ONE socket.  Writes om / hash per sampled pair for the parent's parity gate."""
+    spec = json.load(open(spec_path))
+    cpus, model = one_socket_cores()
+    os.sched_setaffinity(0, cpus)                      # before any OpenMP runtime starts: its threads inherit the mask
+    os.environ["OMP_PROC_BIND"] = "spread"
+    os.environ["OMP_PLACES"] = "cores"
+    import numpy as np
+    from multiz_amd import synth
+    from oracle import mzoracle as mo
+    cfg, pairs, cores = synth.CONFIGS[spec["config"]], spec["pairs"], len(cpus)
+    batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=spec["first_pair"])
+    use_ref = mo.have_reference()
+    run_cpu = (lambda bt: mo.ref_batch(bt, threads=cores)) if use_ref else (lambda bt: mo.yama_batch(bt, variant=0, threads=cores))
+    rng = np.random.default_rng(12345)
+    probe = synth.subset(batch, np.sort(rng.choice(pairs, size=min(pairs, 2 * cores), replace=False)))
+    run_cpu(probe)                                     # warm-up: thread pool, page faults
+    t = time.perf_counter()
+    run_cpu(probe)
+    per_pair = (time.perf_counter() - t) / len(probe["K"])
+    nsample = int(max(min(cores, pairs), min(pairs, spec["seconds"] / max(per_pair, 1e-7))))
+    idx = np.sort(rng.choice(pairs, size=nsample, replace=False))
+    sample = synth.subset(batch, idx)
+    t = time.perf_counter()
+    om, hs, ccells, bad = run_cpu(sample)
+    cpu_s = time.perf_counter() - t
+    np.savez(spec["out"], idx=idx, om=om, hs=hs)
+    what = ("reference yama() (oracle/_ref/libref.so, gcc -O2 -fcommon)" if use_ref
+            else "oracle faithful O(K*L)/cell restatement (gcc -O2)")
+    print(json.dumps({"value": round(ccells / cpu_s / 1e9, 5), "unit": "GCUPS", "cores": cores, "model": model,
+                      "kind": "reference" if use_ref else "port", "bad": int(bad),
+                      "sample": f"{nsample} of the {pairs} pairs (seeded), {ccells} band cells in {cpu_s:.1f} s; {what}, "
+                                f"OpenMP one pair per thread on the {cores} physical cores of one socket"}))
+
+
+# ------------------------------------------------------------------------------------------ main
 
 def algorithmic_bytes(batch, om):
     """K*M + L*N (columns in) + 8*(M+1) (LB,RB) + cells (1 B traceback per
     cell) + (M+N) (traceback read, upper bound) + (K+L)*OM (merged block out), summed over pairs."""
+    import numpy as np
     K, L, M, N = (batch[k].astype(np.int64) for k in ("K", "L", "M", "N"))
     n_band = int(batch["offBand"][-1]) + int(M[-1]) + 1
     cells = int((batch["poolRB"][:n_band].astype(np.int64) - batch["poolLB"][:n_band] + 1).sum())
@@ -47,28 +131,59 @@ def algorithmic_bytes(batch, om):
     return total, cells
 
 
-def fnv_rows(cols, om):
-    from oracle import mzoracle as mo
-    return mo.fnv1a_np(cols, mo.fnv1a_np(np.array([om], dtype=np.int32).view(np.uint8)))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)   # (a step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
+    ap.add_argument("--steps", type=int, default=100)   # (a c2 step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) column")
+    ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 builds the whole list and deals it out (multiz_amd.shard)")
+    ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_leg:
+        return cpu_leg(args.cpu_leg)
 
-    import torch
-    import torch.distributed as dist
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)
+    world = int(env_world or "1")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (or without a distributed environment, and bench.py starts the ranks)")
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- CPU baseline first (rank 0, N=1 only), in a child process that never touches the GPU, pinned to one
+    # socket's physical cores, before this process initialises the device.  Preferred: the REAL reference's yama()
+    # (oracle/_ref/libref.so, built from /root/reference by oracle/Makefile, -O2) driven one pair per thread; otherwise
+    # the oracle's faithful O(K*L)/cell restatement.  Checker/baseline only; its per-pair hashes feed the parity gate.
+    cpu = cpu_arrays = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import numpy as np
+        cfg0 = args.config
+        with tempfile.TemporaryDirectory() as td:
+            from multiz_amd import synth as _synth
+            spec = {"config": cfg0, "pairs": args.pairs or _synth.CONFIGS[cfg0]["pairs"], "first_pair": 0,
+                    "seconds": args.cpu_seconds, "out": os.path.join(td, "cpu.npz")}
+            json.dump(spec, open(os.path.join(td, "spec.json"), "w"))
+            env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+            env["MZ_NO_TORCH"] = "1"
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", os.path.join(td, "spec.json")],
+                               capture_output=True, text=True, env=env, cwd=ROOT)
+            if p.returncode != 0:
+                raise SystemExit("CPU-baseline leg failed:\n" + p.stderr[-2000:])
+            cpu = json.loads(p.stdout.strip().splitlines()[-1])
+            z = np.load(spec["out"])
+            cpu_arrays = (z["idx"], z["om"], z["hs"])
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in the product)")
     # MZ_BENCH_SHARE_GPU=1 (development only): every rank on GPU 0 with a gloo group, to exercise the N > 1 control
@@ -78,7 +193,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    red = torch.device("cpu") if share else dev                 # where the closing reductions live
+    red = torch.device("cpu") if share else dev                 # where the exchange and the closing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -87,14 +202,42 @@ def main():
             dist.init_process_group("nccl", device_id=dev)      # RCCL
 
     import multiz_amd as mz
-    from multiz_amd import api, synth
+    from multiz_amd import api, shard, synth
 
     api.init(local)
     cfg = dict(synth.CONFIGS[args.config])
     pairs = args.pairs or cfg["pairs"]
-    batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"],
-                             first_pair=rank * pairs)
-    db = mz.DevBatch(batch, device=dev)                          # inputs now resident in HBM
+    exchange = None
+    if args.scatter and world > 1:
+        # the list exists on rank 0 only: partition by band cells, one grouped RCCL send per peer, the shard's
+        # tensors become the device batch where they land; the aligned shard goes back the same way (checked below)
+        whole = synth.make_batch(pairs * world, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"]) if rank == 0 else None
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        tens, my_idx = shard.scatter_batch(whole, 0, red)
+        torch.cuda.synchronize(dev)
+        t_scatter = time.perf_counter() - t0
+        batch = {k: v.cpu().numpy() for k, v in tens.items()}                 # host copy for the byte accounting below
+        db = mz.DevBatch.from_tensors(tens, device=dev)
+        db.run()
+        r = db.results_device()
+        res_t = dict(om=r["om"], status=r["status"], off=r["offOut"], out=db.out[: int(r["totals"][2].item())])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        sh = shard.gather_results(res_t, my_idx, pairs * world,
+                                  (whole["K"].astype(np.int64) + whole["L"]) if rank == 0 else None, 0, red)
+        torch.cuda.synchronize(dev)
+        t_gather = time.perf_counter() - t0
+        exchange = {"scatter_s": round(t_scatter, 4), "gather_s": round(t_gather, 4), "pairs_this_rank": int(len(my_idx))}
+        if rank == 0:
+            assert (sh.status == 0).all() and (sh.owner >= 0).all(), "a pair came back without a result"
+            exchange["ranks_used"] = int(len(set(sh.owner.tolist())))
+        del whole
+        pairs_here = int(len(my_idx))
+    else:
+        batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=rank * pairs)
+        db = mz.DevBatch(batch, device=dev)                      # inputs now resident in HBM
+        pairs_here = pairs
     ring = [db, db.alternate(), db.alternate()]                  # three rotating workspaces for the pipelined form
 
     def sync_all():
@@ -106,8 +249,10 @@ def main():
     # per-kernel durations for the roofline: the batch with the phases serialised and a HIP event pair around
     # each, on the stream the kernels are launched on (outside the timed region; doubles as extra warm-up)
     kern_ms = np.zeros(4)
-    for _ in range(args.steps):
+    kreps = max(3, min(args.steps, 20))
+    for _ in range(kreps):
         kern_ms += np.array(db.run(timed=True))
+    kern_ms /= kreps
     sync_all()
     # production form for a stream of batches (mz_dev_run_async): the DPs run back to back; plan + prep of step
     # k+1 and the latency-bound traceback walk + emit of step k-1 run on two helper streams beside the DP of
@@ -134,7 +279,7 @@ def main():
     failed = int((res["status"] != 0).sum())
     total_bytes, cells = algorithmic_bytes(batch, res["om"])
     assert cells == int(res["cells"].sum()), "device cell count differs from the host count"
-    stats = torch.tensor([cells, pairs, failed], dtype=torch.float64, device=red)
+    stats = torch.tensor([cells, pairs_here, failed], dtype=torch.float64, device=red)
     if world > 1:
         dist.all_reduce(stats)                                   # the batch-closing reduction
     all_cells, all_pairs, all_failed = (int(x) for x in stats.tolist())
@@ -143,68 +288,79 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     gcups = all_cells * args.steps / elapsed / 1e9
-    dp_ms = kern_ms[1] / args.steps
+    dp_ms = float(kern_ms[1])
     roof_achieved = total_bytes / (dp_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes over the DP kernel's time
+    default_batch = args.config == "c2" and pairs == 50000 and not args.scatter
+    modes = np.bincount(res["mode"], minlength=13)
 
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",
         "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {pairs} block pairs/GPU, {cfg['K']}+{cfg['L']} rows, "
-                               f"M,N~U[{cfg['mlo']},{cfg['mhi']}], diag band R={cfg['radius']}",
-                   "pairs_total": all_pairs, "band_cells_total": all_cells, "parallelism": f"pairs sharded x{world}"},
-        "kernel_ms": {"plan": round(kern_ms[0] / args.steps, 3), "dp": round(dp_ms, 3),
-                      "walk": round(kern_ms[2] / args.steps, 3), "emit": round(kern_ms[3] / args.steps, 3)},
+        "config": {"workload": synth.describe(args.config, pairs),
+                   "pairs_total": all_pairs, "band_cells_total": all_cells,
+                   "parallelism": f"pairs sharded x{world}" + (" (list built on rank 0, RCCL scatter/gather)" if exchange else "")},
+        # the second column of SURVEY 8(d): the phases one after the other (HIP events, serial form)
+        "kernel_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
+        "kernel_ms": {"plan": round(float(kern_ms[0]), 3), "dp": round(dp_ms, 3),
+                      "walk": round(float(kern_ms[2]), 3), "emit": round(float(kern_ms[3]), 3)},
+        "dp_modes": {str(m): int(c) for m, c in enumerate(modes) if c},
         # dominant kernel: k_dp_row (the DP; one launch per step).  achieved = algorithmic bytes of the
         # batch / its HIP-event time.  The kernel is VALU-issue bound, not HBM bound:
-        # measured traffic (profiles/, separate --pmc passes) stays under 1 TB/s.
+        # measured traffic (profiles/, separate --pmc passes) stays under 1 TB/s; `valu` prices the same launch
+        # against the integer VALU issue roof (instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)).
         "roofline": {"bound": "hbm", "kernel": "k_dp_row", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(roof_achieved / HBM_PEAK_GBS, 5), "traffic": TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and pairs == 50000) else None,
+                     "unit": "GB/s", "frac": round(roof_achieved / HBM_PEAK_GBS, 5),
+                     "traffic": PMC_C2["traffic"] if default_batch else None,
                      "bytes_per_cell": round(total_bytes / cells, 4), "algorithmic_bytes": total_bytes,
-                     "dp_kernel_gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1)},
+                     "dp_kernel_gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1),
+                     "valu": ({"insts_per_launch": PMC_C2["valu_insts"], "cycles_per_inst": VALU_CYCLES, "simds": SIMDS,
+                               "clock_ghz": CLOCK_GHZ,
+                               "frac": round(PMC_C2["valu_insts"] * VALU_CYCLES / (SIMDS * CLOCK_GHZ * 1e9 * dp_ms * 1e-3), 4)}
+                              if default_batch else None)},
     }
+    if exchange:
+        out["exchange"] = exchange
 
-    # ---- CPU baseline + parity gate (rank 0, N=1 only).  Preferred: the REAL reference's yama()
-    # (oracle/_ref/libref.so, built from /root/reference by oracle/Makefile, -O2) driven one pair per
-    # thread; otherwise the oracle's faithful O(K*L)/cell restatement.  Both are checkers/baselines only.
-    if rank == 0 and world == 1 and not args.no_cpu:
+    # ---- the first column of SURVEY 8(d): host buffers in, malloc()ed merged columns out, through mz_yama_batch()
+    # (pack, H2D, kernels, D2H, unpack; chunks pipelined four deep).  N = 1 only: it measures one GPU's PCIe link.
+    if rank == 0 and world == 1 and not args.no_host:
+        jobs, outs = api.host_jobs(batch)
+        api.yama_batch_records(jobs, outs)                       # warm-up: staging buffers grow to size
+        host_om = outs["OM"].copy()
+        api.free_outs(outs)
+        reps, t_host = 3, 0.0
+        for _ in range(reps):
+            t = time.perf_counter()
+            api.yama_batch_records(jobs, outs)
+            t_host += time.perf_counter() - t
+            api.free_outs(outs)
+        assert np.array_equal(host_om, res["om"]), "host path and device-resident path disagree"
+        out["value_host"] = round(cells * reps / t_host / 1e9, 2)
+        out["host_ms_per_batch"] = round(1e3 * t_host / reps, 2)
+
+    # ---- parity gate against the CPU leg's hashes (rank 0, N=1 only)
+    if cpu is not None:
         from oracle import mzoracle as mo
-        cores = os.cpu_count() or 1          # (libgomp has pinned this thread by now; affinity would read 1)
-        use_ref = mo.have_reference()
-        run_cpu = (lambda bt: mo.ref_batch(bt, threads=cores)) if use_ref else (lambda bt: mo.yama_batch(bt, variant=0, threads=cores))
-        rng = np.random.default_rng(12345)
-        probe = synth.subset(batch, rng.choice(pairs, size=min(pairs, 4 * cores), replace=False))
-        run_cpu(probe)                                            # warm-up: thread pool, page faults
-        t = time.perf_counter()
-        run_cpu(probe)
-        per_pair = (time.perf_counter() - t) / len(probe["K"])
-        nsample = int(max(cores, min(pairs, args.cpu_seconds / max(per_pair, 1e-7))))
-        idx = np.sort(rng.choice(pairs, size=nsample, replace=False))
-        sample = synth.subset(batch, idx)
-        t = time.perf_counter()
-        om, hs, ccells, bad = run_cpu(sample)
-        cpu_s = time.perf_counter() - t
+        idx, om, hs = cpu_arrays
         # parity gate: per-pair hash of (OM, merged column bytes), GPU vs CPU
         mism = 0
+        W = batch["K"].astype(np.int64) + batch["L"]
         for w in workspaces:
             wres = w.results()
             host_out = w.out.cpu().numpy()
             for j, i in enumerate(idx):
-                K, L = int(batch["K"][i]), int(batch["L"][i])
                 o0, m_ = int(wres["offOut"][i]), int(wres["om"][i])
-                if m_ != int(om[j]) or fnv_rows(host_out[o0: o0 + m_ * (K + L)], m_) != int(hs[j]):
+                if m_ != int(om[j]) or mo.fnv1a_np(host_out[o0: o0 + m_ * int(W[i])],
+                                                   mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8))) != int(hs[j]):
                     mism += 1
             del host_out
-        if mism or bad:
-            raise SystemExit(f"PARITY FAILURE: {mism} of {nsample} sampled pairs differ from the CPU reference -- number void")
-        what = ("reference yama() (oracle/_ref/libref.so, gcc -O2 -fcommon)" if use_ref
-                else "oracle faithful O(K*L)/cell restatement (gcc -O2)")
-        out["cpu_baseline"] = {"value": round(ccells / cpu_s / 1e9, 5), "unit": "GCUPS", "cores": cores,
-                               "kind": "reference" if use_ref else "port",
-                               "sample": f"{nsample} of the {pairs} pairs (seeded), {ccells} band cells in {cpu_s:.1f} s; "
-                                         f"{what}, OpenMP one pair per thread on {cores} threads"}
-        out["parity"] = f"ok: {nsample} sampled pairs x {len(workspaces)} workspaces bit-identical (OM + merged columns) to the CPU {out['cpu_baseline']['kind']}"
+        if mism or cpu.pop("bad"):
+            raise SystemExit(f"PARITY FAILURE: {mism} of {len(idx)} sampled pairs differ from the CPU reference -- number void")
+        out["cpu_baseline"] = cpu
+        out["parity"] = (f"ok: {len(idx)} sampled pairs x {len(workspaces)} workspaces bit-identical (OM + merged columns) "
+                         f"to the CPU {cpu['kind']}")
 
     if rank == 0:
         print(json.dumps(out))

@@ -53,10 +53,15 @@ enum {
     MZ_E_RB_MONO = 4,
     MZ_E_TRACEBACK = 5,
     MZ_E_EMIT = 6,
-    MZ_E_ROWS = 16,        /* K or L outside 1..127 (profile counters are int8 dot-product operands) */
+    MZ_E_ROWS = 16,        /* K or L outside 1..255 (per-column class counters are bytes, the substitution row
+                              vector is int16) */
     MZ_E_SHAPE = 17,       /* M < 1 or N < 1 */
-    MZ_E_RANGE = 18,       /* K*L*(open+extend)*(M+N) >= 2^30: the reference's own int32 would overflow */
-    MZ_E_WORKSPACE = 19    /* workspace too small for this batch (caller must re-plan) */
+    MZ_E_RANGE = 18,       /* M + N >= 2^30 (step counters are int32).  There is no bound on K*L*(M+N): like the
+                              reference (mz_yama.c:50-71) the exact kernels compute in plain int32, the row-parallel
+                              kernels re-base their scores, and the guard-dropping kernels are only chosen where the
+                              plan proves every reachable score stays above -2^29 */
+    MZ_E_WORKSPACE = 19,   /* workspace too small for this batch (caller must re-plan) */
+    MZ_E_DEVICE = 20       /* not computed: a device error (or malloc failure) ended the call before this pair's result */
 };
 
 /* which DP kernel the plan picked for a pair:
@@ -71,7 +76,8 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
        MZ_MODE_ROW = 5 /* FASTT arithmetic, lane = column, one band row per iteration (bands <= 63 wide) */,
        MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */,
        MZ_MODE_ROWR = 7, MZ_MODE_COLR = 8 /* ROW / COL for scores too large for the 2^30 ring lift: the prefix
-                                             maximum runs on lanes rotated to the band start (two ds_bpermute) */ };
+                                             maximum runs on lanes rotated to the band start (two ds_bpermute) */,
+       MZ_MODE_WIDE = 9, MZ_MODE_WIDESTRIP = 10 /* blocks of 128..255 rows: WF64 / STRIP with int16 gap vectors */ };
 
 typedef struct mz_dev_batch {
     int32_t n;
@@ -90,7 +96,8 @@ typedef struct mz_dev_batch {
     int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
-    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare */
+    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare,
+                              [8] pairs of more than 127 rows, [9] their work counter; 32 entries in all */
     int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */
@@ -119,6 +126,14 @@ typedef struct mz_score_model {
  * mz_last_error() set.  There is NO CPU fallback: without a usable HIP device every entry
  * point fails. */
 int  mz_init(int device);
+/* The same on several GPUs of the node (devices == NULL: GPUs 0..ngpu-1); the first is the primary device, where
+ * the device-resident API (mz_dev_*) runs.  mz_yama_batch() then deals a large batch out over all of them -- one host
+ * thread, one set of streams and staging buffers per GPU, contiguous ranges of the job list balanced by band size;
+ * block pairs are independent, so there is no exchange between GPUs.  Without an explicit call the first use of the
+ * library reads MZ_DEVICE (first GPU, default 0) and MZ_NGPU (count, default 1) from the environment, which is how
+ * the drivers mz_multiz / mz_multic use a whole node. */
+int  mz_init_multi(int ngpu, const int *devices);
+int  mz_device_count(void);               /* GPUs the library is running on (0 before initialisation) */
 void mz_finalize(void);
 const char *mz_last_error(void);
 /* the hipStream_t the library launches on (for callers that time with HIP events) */
@@ -153,9 +168,12 @@ typedef struct mz_out {
     unsigned char *cols;      /* malloc()ed, OM*(K+L) bytes, caller frees; NULL on error   */
 } mz_out;
 
-/* Align n independent block pairs on the GPU.  Returns the number of failed pairs, or -1 on
- * a device error. */
+/* Align n independent block pairs on the GPU(s).  Returns the number of failed pairs, or -1 on a device error;
+ * in either case every outs[i] is defined: status MZ_E_DEVICE and cols == NULL for pairs without a result.
+ * Calls are serialised (the library state is process-wide). */
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
+/* free() every outs[i].cols of a finished call and reset them to NULL */
+void mz_free_outs(int n, mz_out *outs);
 
 /* ---------------------------------------------------------------- device-resident API */
 

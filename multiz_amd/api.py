@@ -53,12 +53,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (there is no fallback path)")
-        try:
-            # torch ships its own libamdhip64; load it first so that this library binds to the same
-            # HIP runtime instead of bringing /opt/rocm's copy into the process as a second one
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        if os.environ.get("MZ_NO_TORCH") != "1":       # (host-only helpers in a process that never touches the GPU)
+            try:
+                # torch ships its own libamdhip64; load it first so that this library binds to the same
+                # HIP runtime instead of bringing /opt/rocm's copy into the process as a second one
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.mz_last_error.restype = C.c_char_p
         _lib.mz_init.argtypes = [C.c_int]
@@ -132,6 +133,40 @@ def yama_batch(pairs: Sequence[tuple]) -> List[Result]:
     return res
 
 
+JOB_DT = np.dtype([("K", "<i4"), ("L", "<i4"), ("M", "<i4"), ("N", "<i4"), ("A", "<u8"), ("B", "<u8"), ("LB", "<u8"), ("RB", "<u8")])
+OUT_DT = np.dtype([("status", "<i4"), ("badrow", "<i4"), ("OM", "<i4"), ("score", "<i4", (3,)), ("cols", "<u8")])
+
+
+def host_jobs(batch: dict):
+    """mz_job[n] / mz_out[n] (include/mz_amd.h) as numpy record arrays over a packed host batch, without a per-pair
+    loop: what a C caller of mz_yama_batch() would hold.  The batch's arrays must stay alive while the jobs are used."""
+    assert JOB_DT.itemsize == C.sizeof(Job) and OUT_DT.itemsize == C.sizeof(Out)
+    n = len(batch["K"])
+    for k, dt in (("poolA", np.uint8), ("poolB", np.uint8), ("poolLB", np.int32), ("poolRB", np.int32)):
+        assert batch[k].dtype == dt and batch[k].flags["C_CONTIGUOUS"], k
+    jobs = np.zeros(n, dtype=JOB_DT)
+    for k in ("K", "L", "M", "N"):
+        jobs[k] = batch[k]
+    jobs["A"] = batch["poolA"].ctypes.data + batch["offA"].astype(np.uint64)
+    jobs["B"] = batch["poolB"].ctypes.data + batch["offB"].astype(np.uint64)
+    jobs["LB"] = batch["poolLB"].ctypes.data + 4 * batch["offBand"].astype(np.uint64)
+    jobs["RB"] = batch["poolRB"].ctypes.data + 4 * batch["offBand"].astype(np.uint64)
+    return jobs, np.zeros(n, dtype=OUT_DT)
+
+
+def yama_batch_records(jobs: np.ndarray, outs: np.ndarray) -> int:
+    """mz_yama_batch() on record arrays from host_jobs(); the caller reads outs and then calls free_outs()"""
+    rc = lib().mz_yama_batch(len(jobs), jobs.ctypes.data_as(C.POINTER(Job)), outs.ctypes.data_as(C.POINTER(Out)))
+    _check(rc, "mz_yama_batch")
+    return rc
+
+
+def free_outs(outs: np.ndarray):
+    f = lib().mz_free_outs
+    f.argtypes = [C.c_int, C.c_void_p]
+    f(len(outs), outs.ctypes.data)
+
+
 def yama_one(A, B, LB, RB) -> Result:
     return yama_batch([(A, B, LB, RB)])[0]
 
@@ -140,16 +175,22 @@ class DevBatch:
     """A device-resident batch built from torch tensors (torch is plumbing: HBM allocations and the
     current HIP stream).  Inputs are packed pools (see include/mz_amd.h)."""
 
-    def __init__(self, host: dict, device="cuda:0", cap_tb: Optional[int] = None):
+    def __init__(self, host: dict, device="cuda:0", cap_tb: Optional[int] = None, _tensors: Optional[dict] = None):
         import torch
         self.torch = torch
         self.dev = torch.device(device)
-        n = len(host["K"])
+        if self.dev.index is not None:
+            torch.cuda.set_device(self.dev)              # the library launches on the current device's streams
+        if _tensors is not None:                         # already on the device (from_tensors)
+            self.t = _tensors
+            n = int(self.t["K"].numel())
+        else:
+            n = len(host["K"])
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
+            self.t = {k: t(host[k], np.int32) for k in ("K", "L", "M", "N", "poolLB", "poolRB")}
+            self.t.update({k: t(host[k], np.int64) for k in ("offA", "offB", "offBand")})
+            self.t.update({k: t(host[k], np.uint8) for k in ("poolA", "poolB")})
         self.n = n
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)  # noqa: E731
-        self.t = {k: t(host[k], np.int32) for k in ("K", "L", "M", "N", "poolLB", "poolRB")}
-        self.t.update({k: t(host[k], np.int64) for k in ("offA", "offB", "offBand")})
-        self.t.update({k: t(host[k], np.uint8) for k in ("poolA", "poolB")})
         self.plan_mem = torch.empty(lib().mz_dev_plan_bytes(n), dtype=torch.uint8, device=self.dev)
         self.c = DevBatchC()
         self.c.n = n
@@ -172,6 +213,33 @@ class DevBatch:
         self.c.tbw, self.c.script, self.c.out, self.c.prep = self.tbw.data_ptr(), self.script.data_ptr(), self.out.data_ptr(), self.prep.data_ptr()
         self.c.capTb, self.c.capScript, self.c.capOut, self.c.capPrep = tb + 64, sc + 64, ou + 64, pr + 64
         torch.cuda.synchronize(self.dev)                     # inputs complete (run_async's plan runs on a library stream)
+
+    @classmethod
+    def from_tensors(cls, tensors: dict, device=None) -> "DevBatch":
+        """a batch whose packed pools are ALREADY device tensors (e.g. received over RCCL by multiz_amd.shard):
+        K, L, M, N, poolLB, poolRB int32; offA, offB, offBand int64; poolA, poolB uint8 -- used in place"""
+        import torch
+        want = dict(K=torch.int32, L=torch.int32, M=torch.int32, N=torch.int32, poolLB=torch.int32, poolRB=torch.int32,
+                    offA=torch.int64, offB=torch.int64, offBand=torch.int64, poolA=torch.uint8, poolB=torch.uint8)
+        dev = torch.device(device) if device is not None else tensors["K"].device
+        if dev.type != "cuda":
+            raise RuntimeError("DevBatch needs HIP device tensors (there is no CPU path in the product)")
+        t = {k: tensors[k].to(device=dev, dtype=dt).contiguous() for k, dt in want.items()}
+        for k in ("poolA", "poolB", "poolLB", "poolRB"):       # (an empty pool still needs an address)
+            if t[k].numel() == 0:
+                t[k] = torch.zeros(1, dtype=want[k], device=dev)
+        return cls(None, device=dev, _tensors=t)
+
+    def results_device(self) -> dict:
+        """the plan/result arrays as device tensors (views into plan_mem): nothing crosses PCIe"""
+        self.torch.cuda.synchronize(self.dev)
+        n, torch = self.n, self.torch
+
+        def v(ptr, count, dt):
+            off = ptr - self.plan_mem.data_ptr()
+            return self.plan_mem[off: off + count * dt.itemsize].view(dt)
+        return dict(status=v(self.c.status, n, torch.int32), mode=v(self.c.mode, n, torch.int32), cells=v(self.c.cells, n, torch.int64),
+                    om=v(self.c.om, n, torch.int32), offOut=v(self.c.offOut, n, torch.int64), totals=v(self.c.totals, 8, torch.int64))
 
     def alternate(self) -> "DevBatch":
         """a second workspace (traceback, script, output, plan arrays) over the SAME resident inputs, for the

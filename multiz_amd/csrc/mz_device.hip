@@ -9,12 +9,15 @@
 //    forms of per-column class/gap counts (oracle/yama_profile_oracle.c is the executable
 //    specification; integer-exact).  The counts are packed as int8/int16 vectors so that a
 //    cell costs a handful of v_dot4_i32_i8 / v_dot2_i32_i16 instead of 4*K*L table look-ups.
-//  * one 64-lane wave owns one block pair and sweeps anti-diagonals: lane = DP row mod 64,
-//    step t handles cells (r, t-r).  (r-1,c) and (r-1,c-1) come from the neighbouring lane
-//    through DPP wave rotates (no LDS traffic for the recurrence); (r,c-1) is the lane's own
-//    previous value.  Column profiles of B sit in an LDS ring, row records of A in LDS.
-//  * traceback bytes are stored "diagonal-major", four steps per dword, so that every store
-//    is one fully coalesced 256-byte row per wave.
+//  * one 64-lane wave owns one block pair.  The main kernels (kernels/row.inc) are ROW-parallel:
+//    a lane owns a band column (a ring over the columns), the wave computes one whole band row
+//    per iteration, C and D come from the previous row (one DPP rotate for the diagonal) and the
+//    along-the-row I recurrence is a DPP prefix maximum.  Bands that fit neither that form nor
+//    its transposed twin fall back to anti-diagonal wavefronts (kernels/wavefront_*.inc: lane =
+//    DP row mod 64, step t handles cells (r, t-r)) or to 64-row strips (kernels/strip.inc).
+//    Column records sit in an LDS ring, row records in an LDS block, both built in-kernel.
+//  * traceback entries are 2-bit pick tags in three streams (reference bytes in the exact
+//    kernels), laid out so that every store is one fully coalesced 256-byte row per wave.
 //
 // No MFMA anywhere: this is an integer max-plus recurrence, not a contraction.
 
@@ -35,6 +38,9 @@
 #define ROW_NROWS(M) ((M) + 2)
 #define ROW_NCOLS(N) ((((N) + WAVE + WAVE - 1) / WAVE) * WAVE + WAVE)
 #define COL_PREP_DWORDS(N) (2LL * ((N) + 1))           // transposed band bounds of a COL pair
+// row-parallel family (lane = column / transposed: lane = row) and its transposed members
+#define MODE_IS_ROWFAM(m) ((m) >= MZ_MODE_ROW && (m) <= MZ_MODE_COLR)
+#define MODE_IS_COLFAM(m) ((m) == MZ_MODE_COL || (m) == MZ_MODE_COLR)
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; };
 __constant__ ScoreConst c_sc;
@@ -121,7 +127,7 @@ __device__ __forceinline__ int t_hi(const int *LB, int M, int c)        // last 
 // ------------------------------------------------------------------------------------------
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
-static char g_err[256];
+static thread_local char g_err[256];   // (one host thread per GPU in multi-GPU batches)
 static int fail(hipError_t e, const char *what)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -226,6 +232,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
     hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }

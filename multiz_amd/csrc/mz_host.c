@@ -9,6 +9,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <limits.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,7 +23,7 @@
 
 /* ------------------------------------------------------------------ error plumbing */
 
-static char g_err[512];
+static __thread char g_err[512];             /* per thread: the GPUs of a multi-GPU batch are driven by one host thread each */
 char *argv0;                               /* reference util.c:4; drivers set it in main() */
 
 const char *mz_last_error(void) { return g_err; }
@@ -65,7 +66,13 @@ typedef struct gbuf { void *p; size_t cap; } gbuf;
 
 #define MZ_SETS 4                          /* buffer sets of the chunk pipeline: uploading, computing, copying back, being unpacked */
 
-static struct {
+#define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
+
+/* Everything the library holds on ONE GPU.  g_dev[0] is the primary context: the device-resident API (mz_dev_*)
+ * and single-GPU runs live there.  mz_init_multi() / MZ_NGPU add contexts on further GPUs, each driven by its own
+ * host thread when mz_yama_batch() deals a large batch out over them (block pairs are
+ * independent, so the shards never talk to each other). */
+typedef struct mz_ctx {
     int ready;
     int device;
     hipStream_t stream;
@@ -73,13 +80,22 @@ static struct {
     hipStream_t stream3;                   /* pipelined form: plan of batch k+1 beside the DP of batch k */
     hipEvent_t ev[5];
     hipEvent_t evs[MZ_SLICES + 1];
-    /* last score tables handed to the device */
-    int **ss_seen; int *gop_seen; int ge_seen; int scores_ok;
+    int scores_ok;                         /* the device's copy of the score model is current */
     /* grow-only buffers of the host-buffer path */
     gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS], d_band[MZ_SETS];
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
-} G;
+    struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
+    int ws_victim;
+} mz_ctx;
+
+#define MZ_MAX_DEV 16
+static mz_ctx g_dev[MZ_MAX_DEV];
+static int g_ndev;                         /* contexts in use (0 before mz_init) */
+#define G (g_dev[0])
+static unsigned long long g_score_sum;     /* checksum of the score tables last handed to the devices */
+static int g_score_have;
+static pthread_mutex_t g_big = PTHREAD_MUTEX_INITIALIZER;   /* one host-path call at a time (the library state is process-wide) */
 
 static int dev_reserve(gbuf *b, size_t need)
 {
@@ -102,34 +118,93 @@ static int host_reserve(gbuf *b, size_t need)
 
 void *mz_stream(void) { return G.ready ? (void *)G.stream : NULL; }
 
-int mz_init(int device)
+static int ctx_open(mz_ctx *X, int device)
 {
-    int count = 0, i;
-    if (G.ready && G.device == device) return 0;
-    if (G.ready) mz_finalize();
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        return set_err("no HIP device available (this library has no CPU path)");
-    if (device < 0 || device >= count)
-        return set_err("HIP device %d out of range (%d present)", device, count);
+    int i;
+    memset(X, 0, sizeof *X);
     HIPCK(hipSetDevice(device));
-    HIPCK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
-    /* the helper streams (mz_dev_run_async) and the second chunk stream are created on first use: a stream costs
+    HIPCK(hipStreamCreateWithFlags(&X->stream, hipStreamNonBlocking));
+    /* the helper streams (mz_dev_run_async) and the further chunk streams are created on first use: a stream costs
      * ~9 ms of start-up and a short run -- one yama() call, one chunk -- needs none of them */
-    G.stream2 = G.stream3 = NULL;
-    G.bstream[0] = G.stream;
-    for (i = 1; i < MZ_SETS; ++i) G.bstream[i] = NULL;
+    X->bstream[0] = X->stream;
     for (i = 0; i < MZ_SETS; ++i) {
-        HIPCK(hipEventCreateWithFlags(&G.bdone[i], hipEventDisableTiming));
-        HIPCK(hipEventCreateWithFlags(&G.bplan[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&X->bdone[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&X->bplan[i], hipEventDisableTiming));
     }
-    for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&G.ev[i]));
-    for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&G.evs[i], hipEventDisableTiming));
-    G.device = device;
-    G.ready = 1;
-    G.scores_ok = 0;
-    G.ss_seen = NULL;
+    for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
+    for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&X->evs[i], hipEventDisableTiming));
+    X->device = device;
+    X->ready = 1;
     return 0;
 }
+
+static void ctx_close(mz_ctx *X)
+{
+    int i, s;
+    if (!X->ready) return;
+    hipSetDevice(X->device);
+    hipStreamSynchronize(X->stream);
+    for (s = 0; s < MZ_SETS; ++s) {
+        gbuf *d[] = { &X->d_in[s], &X->d_plan[s], &X->d_tb[s], &X->d_script[s], &X->d_out[s], &X->d_prep[s], &X->d_band[s] };
+        if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
+        for (i = 0; i < 7; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+        if (X->h_in[s].p)  { hipHostFree(X->h_in[s].p);  X->h_in[s].p = NULL;  X->h_in[s].cap = 0; }
+        if (X->h_res[s].p) { hipHostFree(X->h_res[s].p); X->h_res[s].p = NULL; X->h_res[s].cap = 0; }
+        if (X->h_tot[s].p) { hipHostFree(X->h_tot[s].p); X->h_tot[s].p = NULL; X->h_tot[s].cap = 0; }
+        if (s >= 1 && X->bstream[s]) hipStreamDestroy(X->bstream[s]);
+        hipEventDestroy(X->bdone[s]);
+        hipEventDestroy(X->bplan[s]);
+    }
+    for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
+    for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);
+    for (i = 0; i < MZ_WS_MAX; ++i) if (X->ws[i].used) { hipEventDestroy(X->ws[i].done); X->ws[i].used = 0; }
+    if (X->stream2) { hipStreamSynchronize(X->stream2); hipStreamDestroy(X->stream2); }
+    if (X->stream3) { hipStreamSynchronize(X->stream3); hipStreamDestroy(X->stream3); }
+    hipStreamDestroy(X->stream);
+    X->ready = 0;
+}
+
+/* ngpu contexts on the given devices (devices == NULL: first, first+1, ...).  The first one is the primary
+ * context.  Returns 0, or -1 with mz_last_error() set (nothing is left open then). */
+static int init_devices(int ngpu, const int *devices, int first)
+{
+    int count = 0, i, j;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return set_err("no HIP device available (this library has no CPU path)");
+    if (ngpu < 1 || ngpu > MZ_MAX_DEV) return set_err("mz_init_multi: %d GPUs requested (1..%d supported)", ngpu, MZ_MAX_DEV);
+    for (i = 0; i < ngpu; ++i) {
+        const int d = devices ? devices[i] : first + i;
+        if (d < 0 || d >= count) return set_err("HIP device %d out of range (%d present)", d, count);
+        for (j = 0; j < i; ++j)
+            if ((devices ? devices[j] : first + j) == d) return set_err("mz_init_multi: device %d listed twice", d);
+    }
+    if (g_ndev) mz_finalize();
+    for (i = 0; i < ngpu; ++i)
+        if (ctx_open(&g_dev[i], devices ? devices[i] : first + i)) {
+            for (j = 0; j <= i; ++j) ctx_close(&g_dev[j]);
+            return -1;
+        }
+    g_ndev = ngpu;
+    g_score_have = 0;
+    HIPCK(hipSetDevice(g_dev[0].device));
+    return 0;
+}
+
+int mz_init(int device)
+{
+    if (g_ndev == 1 && G.ready && G.device == device) return 0;
+    return init_devices(1, NULL, device);
+}
+
+int mz_init_multi(int ngpu, const int *devices)
+{
+    int i, same = g_ndev == ngpu;
+    for (i = 0; same && i < ngpu; ++i) same = g_dev[i].ready && g_dev[i].device == (devices ? devices[i] : i);
+    if (same) return 0;
+    return init_devices(ngpu, devices, 0);
+}
+
+int mz_device_count(void) { return g_ndev; }
 
 /* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs 4 % of the
  * pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
@@ -140,42 +215,25 @@ static int lazy_stream(hipStream_t *s)
     return 0;
 }
 
-#define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
-static struct { const void *key; hipEvent_t done; int used; } g_ws[MZ_WS_MAX];
-static int g_ws_victim;
-
 void mz_finalize(void)
 {
     int i;
-    int s;
-    if (!G.ready) return;
-    hipStreamSynchronize(G.stream);
-    for (s = 0; s < MZ_SETS; ++s) {
-        gbuf *d[] = { &G.d_in[s], &G.d_plan[s], &G.d_tb[s], &G.d_script[s], &G.d_out[s], &G.d_prep[s], &G.d_band[s] };
-        if (G.bstream[s]) hipStreamSynchronize(G.bstream[s]);
-        for (i = 0; i < 7; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
-        if (G.h_in[s].p)  { hipHostFree(G.h_in[s].p);  G.h_in[s].p = NULL;  G.h_in[s].cap = 0; }
-        if (G.h_res[s].p) { hipHostFree(G.h_res[s].p); G.h_res[s].p = NULL; G.h_res[s].cap = 0; }
-        if (G.h_tot[s].p) { hipHostFree(G.h_tot[s].p); G.h_tot[s].p = NULL; G.h_tot[s].cap = 0; }
-        if (s >= 1 && G.bstream[s]) hipStreamDestroy(G.bstream[s]);
-        hipEventDestroy(G.bdone[s]);
-        hipEventDestroy(G.bplan[s]);
-    }
-    for (i = 0; i < 5; ++i) hipEventDestroy(G.ev[i]);
-    for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(G.evs[i]);
-    for (i = 0; i < MZ_WS_MAX; ++i) if (g_ws[i].used) { hipEventDestroy(g_ws[i].done); g_ws[i].used = 0; }
-    if (G.stream2) { hipStreamSynchronize(G.stream2); hipStreamDestroy(G.stream2); }
-    if (G.stream3) { hipStreamSynchronize(G.stream3); hipStreamDestroy(G.stream3); }
-    hipStreamDestroy(G.stream);
-    G.ready = 0;
+    for (i = 0; i < g_ndev; ++i) ctx_close(&g_dev[i]);
+    g_ndev = 0;
+    g_score_have = 0;
 }
 
+/* first use without mz_init(): MZ_DEVICE = first GPU (default 0), MZ_NGPU = how many (default 1) */
 static int ensure_init(void)
 {
-    const char *e;
-    if (G.ready) return 0;
+    const char *e, *n;
+    int ngpu;
+    if (g_ndev) return 0;
     e = getenv("MZ_DEVICE");
-    return mz_init(e ? atoi(e) : 0);
+    n = getenv("MZ_NGPU");
+    ngpu = n ? atoi(n) : 1;
+    if (ngpu <= 1) return mz_init(e ? atoi(e) : 0);
+    return init_devices(ngpu, NULL, e ? atoi(e) : 0);
 }
 
 /* ------------------------------------------------------------------ scores */
@@ -236,16 +294,37 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     return 0;
 }
 
+/* the model goes to every context's __constant__ copy.  Kernels of earlier calls may still be reading it
+ * (mz_dev_run_async, another caller's stream), so each device is drained first; score changes are rare. */
+static int upload_everywhere(const mz_score_model *m)
+{
+    int i;
+    for (i = 0; i < g_ndev; ++i) {
+        HIPCK(hipSetDevice(g_dev[i].device));
+        HIPCK(hipDeviceSynchronize());
+        if (mzk_upload_scores(m, g_dev[i].stream)) return set_err("%s", mzk_last_error());
+        g_dev[i].scores_ok = 1;
+    }
+    HIPCK(hipSetDevice(G.device));
+    return 0;
+}
+
 int mz_set_scores(const int *ss_flat, const int *gop16, int ext)
 {
     mz_score_model m;
     if (ensure_init()) return -1;
     if (model_from_tables(NULL, ss_flat, gop16, ext, &m)) return -1;
-    if (mzk_upload_scores(&m, G.stream)) return set_err("%s", mzk_last_error());
-    G.scores_ok = 1;
-    G.ss_seen = NULL;
+    if (upload_everywhere(&m)) return -1;
+    g_score_have = 0;
     mz_scores_explicit = 1;                /* keep them until init_scores70/85() is called again */
     return 0;
+}
+
+static void scores_stale(void)
+{
+    int i;
+    for (i = 0; i < MZ_MAX_DEV; ++i) g_dev[i].scores_ok = 0;
+    g_score_have = 0;
 }
 
 /* Switch the fast DP kernel off (exact kernels only) or back on; used by the parity tests to
@@ -253,28 +332,50 @@ int mz_set_scores(const int *ss_flat, const int *gop16, int ext)
 void mz_enable_fast(int on)
 {
     g_no_fast = !on;
-    G.scores_ok = 0;                       /* force the score model (which carries g1,g2) to be re-sent */
+    scores_stale();                        /* force the score model (which carries g1,g2) to be re-sent */
     mz_scores_explicit = 0;
 }
 
 void mz_enable_row(int on)
 {
     g_no_row = !on;
-    G.scores_ok = 0;
+    scores_stale();
     mz_scores_explicit = 0;
 }
 
-/* hand the reference-style globals (ss, gop, gap_extend) to the device if they changed */
+/* Checksum of what the kernels take from the caller's tables: the scores of the ten bytes that stand for the six
+ * classes in both cases, gop[16], gap_extend.  A caller that edits its tables IN PLACE (same pointers) is
+ * noticed too; a changed sum triggers the full structure check of model_from_tables() and a new upload. */
+static unsigned long long score_checksum(void)
+{
+    static const unsigned char rep[10] = { 'A', 'C', 'G', 'T', 'a', 'c', 'g', 't', '-', 'N' };
+    unsigned long long h = 1469598103934665603ULL;
+    int a, b;
+#define MIX(v) do { h ^= (unsigned long long)(unsigned)(v); h *= 1099511628211ULL; } while (0)
+    for (a = 0; a < 10; ++a)
+        for (b = 0; b < 10; ++b) MIX(ss[rep[a]][rep[b]]);
+    for (a = 0; a < 16; ++a) MIX(gop[a]);
+    MIX(gap_extend);
+    MIX((g_no_fast << 1) | g_no_row);
+#undef MIX
+    return h;
+}
+
+/* hand the reference-style globals (ss, gop, gap_extend) to the devices if they changed */
 static int sync_global_scores(void)
 {
     mz_score_model m;
-    if (mz_scores_explicit && G.scores_ok) return 0;   /* tables given through mz_set_scores() */
+    unsigned long long sum;
+    int i, all = 1;
+    for (i = 0; i < g_ndev; ++i) all &= g_dev[i].scores_ok;
+    if (mz_scores_explicit && all) return 0;   /* tables given through mz_set_scores() */
     if (ss == NULL || gop == NULL)
         init_scores70();                   /* batch API default: HOXD70, as multiz.c:257 */
-    if (G.scores_ok && G.ss_seen == ss && G.gop_seen == gop && G.ge_seen == gap_extend) return 0;
+    sum = score_checksum();
+    if (all && g_score_have && sum == g_score_sum) return 0;
     if (model_from_tables(ss, NULL, gop, gap_extend, &m)) return -1;
-    if (mzk_upload_scores(&m, G.stream)) return set_err("%s", mzk_last_error());
-    G.ss_seen = ss; G.gop_seen = gop; G.ge_seen = gap_extend; G.scores_ok = 1;
+    if (upload_everywhere(&m)) return -1;
+    g_score_sum = sum; g_score_have = 1;
     return 0;
 }
 
@@ -287,8 +388,8 @@ size_t mz_dev_plan_bytes(int n)
     size_t s = 0, N = (size_t)(n > 0 ? n : 1);
     s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
     s += 9 * al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
-    s += al256(8 * 8);                     /* totals */
-    s += al256(4 * N) + al256(8 * 6 * (N / 256 + 2));   /* packList, scanAux */
+    s += al256(8 * 32);                    /* totals */
+    s += al256(4 * N) + al256(8 * 8 * (N / 256 + 2));   /* packList, scanAux */
     s += al256(4 * N) + al256(12 * N);     /* om, final3 */
     return s;
 }
@@ -303,8 +404,8 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     TAKE(cells, int64_t *, 8 * N);
     TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N); TAKE(szPrep, int64_t *, 8 * N);
     TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N); TAKE(offPrep, int64_t *, 8 * N);
-    TAKE(totals, int64_t *, 64);
-    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 6 * (N / 256 + 2));
+    TAKE(totals, int64_t *, 8 * 32);
+    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 8 * (N / 256 + 2));
     TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
 #undef TAKE
 }
@@ -337,7 +438,7 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
 {
     hipStream_t s;
     int i;
-    if (ensure_init() || sync_global_scores() || lazy_stream(&G.stream2) || lazy_stream(&G.stream3)) return -1;
+    if (ensure_init() || sync_global_scores()) return -1;
     s = (hipStream_t)pick_stream(stream);
     if (ms) {                              /* serial, one HIP event pair per phase */
         HIPCK(hipEventRecord(G.ev[0], s));
@@ -371,22 +472,22 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
 {
     hipStream_t s;
     int w, slot = -1;
-    if (ensure_init() || sync_global_scores()) return -1;
+    if (ensure_init() || sync_global_scores() || lazy_stream(&G.stream2) || lazy_stream(&G.stream3)) return -1;
     s = (hipStream_t)pick_stream(stream);
-    for (w = 0; w < MZ_WS_MAX; ++w) if (g_ws[w].used && g_ws[w].key == (const void *)b->tbw) slot = w;
+    for (w = 0; w < MZ_WS_MAX; ++w) if (G.ws[w].used && G.ws[w].key == (const void *)b->tbw) slot = w;
     if (slot < 0) {
-        for (w = 0; w < MZ_WS_MAX; ++w) if (!g_ws[w].used) { slot = w; break; }
+        for (w = 0; w < MZ_WS_MAX; ++w) if (!G.ws[w].used) { slot = w; break; }
         if (slot < 0) {                                   /* table full: forget the oldest entry once it is idle */
-            slot = g_ws_victim;
-            g_ws_victim = (g_ws_victim + 1) % MZ_WS_MAX;
-            HIPCK(hipEventSynchronize(g_ws[slot].done));
+            slot = G.ws_victim;
+            G.ws_victim = (G.ws_victim + 1) % MZ_WS_MAX;
+            HIPCK(hipEventSynchronize(G.ws[slot].done));
         } else {
-            HIPCK(hipEventCreateWithFlags(&g_ws[slot].done, hipEventDisableTiming));
+            HIPCK(hipEventCreateWithFlags(&G.ws[slot].done, hipEventDisableTiming));
         }
-        g_ws[slot].key = (const void *)b->tbw;
-        g_ws[slot].used = 1;
+        G.ws[slot].key = (const void *)b->tbw;
+        G.ws[slot].used = 1;
     } else {
-        HIPCK(hipStreamWaitEvent(G.stream3, g_ws[slot].done, 0));      /* its previous batch has been walked and emitted */
+        HIPCK(hipStreamWaitEvent(G.stream3, G.ws[slot].done, 0));      /* its previous batch has been walked and emitted */
     }
     if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
     if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return set_err("%s", mzk_last_error());
@@ -396,7 +497,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     HIPCK(hipEventRecord(G.evs[2], s));
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
     if (mzk_walk(b, G.stream2, 1) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
-    HIPCK(hipEventRecord(g_ws[slot].done, G.stream2));
+    HIPCK(hipEventRecord(G.ws[slot].done, G.stream2));
     return 0;
 }
 
@@ -407,7 +508,7 @@ int mz_dev_wait(void *stream)
     if (ensure_init()) return -1;
     s = (hipStream_t)pick_stream(stream);
     for (w = 0; w < MZ_WS_MAX; ++w)
-        if (g_ws[w].used) HIPCK(hipStreamWaitEvent(s, g_ws[w].done, 0));
+        if (G.ws[w].used) HIPCK(hipStreamWaitEvent(s, G.ws[w].done, 0));
     return 0;
 }
 
@@ -419,6 +520,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 /* host threads of the pack / unpack loops: enough to saturate memory bandwidth; waking a whole 256-thread pool
  * for a 2 ms loop costs more than it saves (and was seen to stall for 70-100 ms now and then) */
 #define MZ_COPY_THREADS 24
+static int g_copy_threads = MZ_COPY_THREADS;   /* per device worker; fewer each when several GPUs work side by side */
 
 /* One chunk of a host batch in flight, on the stream and buffers of set `set`, in three steps:
  *   chunk_upload()  packs the jobs into pinned memory and issues the copy to the device, the plan and the copy of
@@ -426,6 +528,7 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
  *   chunk_launch()  waits for those totals, sizes the workspaces and issues the kernels and the copy of the results;
  *   chunk_collect() waits for the results and fills the caller's outs. */
 typedef struct chunk {
+    mz_ctx *X;
     int set, n;
     const mz_job *jobs;
     mz_out *outs;
@@ -434,7 +537,7 @@ typedef struct chunk {
     double t_pack, t_plan;
 } chunk;
 
-static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
+static int chunk_upload(mz_ctx *X, chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
 {
     double t0 = now_s();
     hipStream_t st;
@@ -451,9 +554,9 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     uint32_t *csz;
     int p;
 
-    if (lazy_stream(&G.bstream[set])) return -1;
-    st = G.bstream[set];
-    c->set = set; c->n = n; c->jobs = jobs; c->outs = outs;
+    if (lazy_stream(&X->bstream[set])) return -1;
+    st = X->bstream[set];
+    c->X = X; c->set = set; c->n = n; c->jobs = jobs; c->outs = outs;
 
     for (p = 0; p < n; ++p) {
         const mz_job *j = &jobs[p];
@@ -466,7 +569,7 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
      * their real size and the copy to the device moves no slack */
     csz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *csz);
     if (!csz) return set_err("out of memory");
-#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
     for (p = 0; p < n; ++p) {
         const mz_job *j = &jobs[p];
         if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
@@ -484,9 +587,9 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
      * into poolLB / poolRB, which live in a device-only buffer: they were two thirds of the input of a C2 pair. */
     hdr = al256(4 * (size_t)n) * 5 + al256(8 * (size_t)n) * 4 + al256((size_t)n);
     in_bytes = hdr + al256(bytesC) + al256(bytesA) + al256(bytesB);
-    if (host_reserve(&G.h_in[set], in_bytes) || dev_reserve(&G.d_in[set], in_bytes) ||
-        dev_reserve(&G.d_band[set], 2 * al256(4 * nband))) { free(csz); return -1; }
-    h = (char *)G.h_in[set].p; d = (char *)G.d_in[set].p;
+    if (host_reserve(&X->h_in[set], in_bytes) || dev_reserve(&X->d_in[set], in_bytes) ||
+        dev_reserve(&X->d_band[set], 2 * al256(4 * nband))) { free(csz); return -1; }
+    h = (char *)X->h_in[set].p; d = (char *)X->d_in[set].p;
 
     memset(&b, 0, sizeof b);
     b.n = n;
@@ -502,8 +605,8 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     hC = (uint8_t *)h; dC = (const uint8_t *)d; h += al256(bytesC); d += al256(bytesC);
     SLICE(hA, uint8_t, poolA, bytesA); SLICE(hB, uint8_t, poolB, bytesB);
 #undef SLICE
-    b.poolLB = (const int32_t *)G.d_band[set].p;
-    b.poolRB = (const int32_t *)((char *)G.d_band[set].p + al256(4 * nband));
+    b.poolLB = (const int32_t *)X->d_band[set].p;
+    b.poolRB = (const int32_t *)((char *)X->d_band[set].p + al256(4 * nband));
     {
         size_t oa = 0, ob = 0, oband = 0, oc = 0;
         for (p = 0; p < n; ++p) {                            /* offsets first ... */
@@ -518,7 +621,7 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
         }
         /* ... then the copies into the pinned staging block, on all host threads (a single thread moves
          * ~14 GB/s: 18 ms for the 240 MB of a 20 000-pair C2 batch, three times the GPU work) */
-#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
         for (p = 0; p < n; ++p) {
             const mz_job *j = &jobs[p];
             if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
@@ -545,46 +648,47 @@ static int chunk_upload(chunk *c, int set, int n, const mz_job *jobs, mz_out *ou
     }
     free(csz);
     c->t_pack = now_s() - t0;
-    HIPCK(hipMemcpyAsync(G.d_in[set].p, G.h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
+    HIPCK(hipMemcpyAsync(X->d_in[set].p, X->h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
     if (mzk_unband(n, dLen, b.offBand, doC, dFmt, dC, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st)) return set_err("%s", mzk_last_error());
 
-    if (dev_reserve(&G.d_plan[set], mz_dev_plan_bytes(n)) || host_reserve(&G.h_tot[set], 8 * sizeof(int64_t))) return -1;
-    mz_dev_carve(&b, G.d_plan[set].p);
+    if (dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
+    mz_dev_carve(&b, X->d_plan[set].p);
     b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
     if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(G.h_tot[set].p, b.totals, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCK(hipEventRecord(G.bplan[set], st));
+    HIPCK(hipMemcpyAsync(X->h_tot[set].p, b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCK(hipEventRecord(X->bplan[set], st));
     c->b = b;
     return 0;
 }
 
 static int chunk_launch(chunk *c)
 {
+    mz_ctx *X = c->X;
     const int set = c->set, n = c->n;
     const double t0 = now_s();
-    hipStream_t st = G.bstream[set];
+    hipStream_t st = X->bstream[set];
     mz_dev_batch b = c->b;
-    const int64_t *totals = (const int64_t *)G.h_tot[set].p;
+    const int64_t *totals = (const int64_t *)X->h_tot[set].p;
     size_t res_bytes;
 
-    HIPCK(hipEventSynchronize(G.bplan[set]));
+    HIPCK(hipEventSynchronize(X->bplan[set]));
     c->t_plan = now_s() - t0;
 
-    if (dev_reserve(&G.d_tb[set], 4 * (size_t)totals[0] + 256) || dev_reserve(&G.d_script[set], (size_t)totals[1] + 256) ||
-        dev_reserve(&G.d_out[set], (size_t)totals[2] + 256) || dev_reserve(&G.d_prep[set], 4 * (size_t)totals[4] + 256))
+    if (dev_reserve(&X->d_tb[set], 4 * (size_t)totals[0] + 256) || dev_reserve(&X->d_script[set], (size_t)totals[1] + 256) ||
+        dev_reserve(&X->d_out[set], (size_t)totals[2] + 256) || dev_reserve(&X->d_prep[set], 4 * (size_t)totals[4] + 256))
         return -1;
-    b.tbw = (uint32_t *)G.d_tb[set].p; b.script = (uint8_t *)G.d_script[set].p; b.out = (uint8_t *)G.d_out[set].p;
-    b.prep = (uint32_t *)G.d_prep[set].p; b.capPrep = (int64_t)(G.d_prep[set].cap / 4);
-    b.capTb = (int64_t)(G.d_tb[set].cap / 4); b.capScript = (int64_t)G.d_script[set].cap; b.capOut = (int64_t)G.d_out[set].cap;
+    b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = (uint8_t *)X->d_out[set].p;
+    b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
+    b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
 
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit(&b, st))
         return set_err("%s", mzk_last_error());
 
     /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */
     res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256((size_t)totals[2]);
-    if (host_reserve(&G.h_res[set], res_bytes)) return -1;
+    if (host_reserve(&X->h_res[set], res_bytes)) return -1;
     {
-        char *r = (char *)G.h_res[set].p;
+        char *r = (char *)X->h_res[set].p;
         HIPCK(hipMemcpyAsync(r, b.status, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
         HIPCK(hipMemcpyAsync(r, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
         HIPCK(hipMemcpyAsync(r, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, st));       r += al256(4 * (size_t)n);
@@ -592,17 +696,18 @@ static int chunk_launch(chunk *c)
         HIPCK(hipMemcpyAsync(r, b.offOut, 8 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(8 * (size_t)n);
         if (totals[2] > 0) HIPCK(hipMemcpyAsync(r, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, st));
     }
-    HIPCK(hipEventRecord(G.bdone[set], st));
+    HIPCK(hipEventRecord(X->bdone[set], st));
     c->b = b; c->out_bytes = totals[2];
     return 0;
 }
 
 static int chunk_collect(chunk *c)
 {
+    mz_ctx *X = c->X;
     const int n = c->n, set = c->set;
     const mz_job *jobs = c->jobs;
     mz_out *outs = c->outs;
-    char *r = (char *)G.h_res[set].p;
+    char *r = (char *)X->h_res[set].p;
     int32_t *rs = (int32_t *)r, *rb, *ro, *rf;
     int64_t *roff;
     uint8_t *rout;
@@ -614,20 +719,21 @@ static int chunk_collect(chunk *c)
     r += al256(4 * (size_t)n); rf = (int32_t *)r;
     r += al256(12 * (size_t)n); roff = (int64_t *)r;
     r += al256(8 * (size_t)n); rout = (uint8_t *)r;
-    HIPCK(hipEventSynchronize(G.bdone[set]));
+    HIPCK(hipEventSynchronize(X->bdone[set]));
     t1 = now_s();
-#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) reduction(+:failed) reduction(|:oom) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(g_copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
     for (p = 0; p < n; ++p) {
         mz_out *o = &outs[p];
         o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
         o->score[0] = o->score[1] = o->score[2] = 0;
+        if (rs[p] == MZ_E_EMIT) { o->OM = ro[p]; o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; }   /* i, j of the reference's message */
         if (rs[p] != MZ_OK) { failed++; continue; }
         o->OM = ro[p];
         o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
         {
             size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
             o->cols = (unsigned char *)malloc(nb ? nb : 1);
-            if (!o->cols) { oom = 1; continue; }
+            if (!o->cols) { oom = 1; o->status = MZ_E_DEVICE; o->OM = 0; continue; }
             memcpy(o->cols, rout + roff[p], nb);
         }
     }
@@ -638,75 +744,158 @@ static int chunk_collect(chunk *c)
     return failed;
 }
 
-/* A batch of any size: chunks of 1 Ki - 16 Ki pairs / at most ~1 GB of input columns go through four rotating sets
- * of staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
- * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit. */
+/* A batch of any size on ONE context: chunks of 1 Ki - 16 Ki pairs / at most ~1 GB of input columns go through four
+ * rotating sets of staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
+ * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit.
+ * Up to four chunks are in flight on four buffer sets and streams: while chunk k is uploaded and planned the host
+ * packs chunk k+1; when the plan's totals of chunk k are in, its kernels and the copy of its results are issued;
+ * chunk k-1 is computing or copying back; chunk k-2 is unpacked.  The host does not wait for a copy or a kernel it
+ * could work beside.  On a device error everything in flight is drained and every pair not yet collected is left
+ * marked MZ_E_DEVICE with cols == NULL (mz_yama_batch() pre-marks all of them), so a caller may clean up outs. */
+static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int max_pairs)
+{
+    chunk ck[MZ_SETS];
+    int k = 0, up = 0, done = 0, failed = 0, rc = 0, s;
+#define NEXT_CHUNK(first, count) do { size_t bytes_ = 0; int m_ = 0; \
+        while ((first) + m_ < n && m_ < max_pairs && bytes_ < ((size_t)1 << 30)) { \
+            const mz_job *j_ = &jobs[(first) + m_]; \
+            if (j_->K >= 1 && j_->L >= 1 && j_->M >= 1 && j_->N >= 1) \
+                bytes_ += (size_t)j_->K * j_->M + (size_t)j_->L * j_->N + 8 * ((size_t)j_->M + 1); \
+            ++m_; } (count) = m_; } while (0)
+#define STEP(call) do { rc = (call); if (rc < 0) goto fail; } while (0)
+    if (hipSetDevice(X->device) != hipSuccess) return set_err("hipSetDevice(%d) failed", X->device);
+    {
+        int m0;
+        NEXT_CHUNK(0, m0);
+        STEP(chunk_upload(X, &ck[0], 0, m0, jobs, outs));
+        up = m0;
+    }
+    for (k = 0; done < n; ++k) {
+        chunk *cur = &ck[k % MZ_SETS];
+        if (up < n) {                                    /* pack + upload the next chunk beside this one's copy */
+            int m1;
+            NEXT_CHUNK(up, m1);
+            STEP(chunk_upload(X, &ck[(k + 1) % MZ_SETS], (k + 1) % MZ_SETS, m1, jobs + up, outs + up));
+            up += m1;
+        }
+        STEP(chunk_launch(cur));
+        if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
+        done += cur->n;
+    }
+    if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
+    STEP(chunk_collect(&ck[(k - 1) % MZ_SETS])); failed += rc;
+    return failed;
+fail:
+    for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
+    return -1;
+#undef NEXT_CHUNK
+#undef STEP
+}
+
+/* host thread of one further GPU (mz_yama_batch with several contexts) */
+typedef struct dev_task { mz_ctx *X; int n, max_pairs, rc; const mz_job *jobs; mz_out *outs; char err[600]; } dev_task;
+static void *dev_worker(void *arg)
+{
+    dev_task *t = (dev_task *)arg;
+    t->rc = batch_on_ctx(t->X, t->n, t->jobs, t->outs, t->max_pairs);
+    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, g_err);
+    return NULL;
+}
+
+/* what a pair costs the GPU, roughly: band rows x the band's width in the middle (no pass over the bounds) */
+static double job_weight(const mz_job *j)
+{
+    if (j->K < 1 || j->L < 1 || j->M < 1 || j->N < 1 || !j->LB || !j->RB) return 1.0;
+    return ((double)j->M + 1.0) * (double)(j->RB[j->M / 2] - j->LB[j->M / 2] + 1) + 64.0 * (j->K + j->L);
+}
+
+#define MZ_MULTI_MIN 2048                  /* pairs per GPU below which dealing a batch out is not worth a thread */
+
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
     static int env_pairs = -1;
-    int done = 0, failed = 0, max_pairs;
+    int failed = 0, max_pairs, use, p, rc;
     if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (n <= 0) return 0;
-    /* chunk size: about a quarter of the call, so that even a few thousand pairs overlap their copies with their
-     * kernels, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU) and at most 16 Ki */
-    max_pairs = env_pairs ? env_pairs : (n + 3) / 4 < 1024 ? 1024 : (n + 3) / 4 > 16384 ? 16384 : (n + 3) / 4;
+    for (p = 0; outs && p < n; ++p) {                    /* "not computed" until a chunk says otherwise */
+        outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL;
+        outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
+    }
+    pthread_mutex_lock(&g_big);
     {
-        const int first = !G.ready && getenv("MZ_TIMING") != NULL;
+        const int first = !g_ndev && getenv("MZ_TIMING") != NULL;
         struct timespec t0, t1, t2;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        if (ensure_init()) return -1;
+        if (ensure_init()) { pthread_mutex_unlock(&g_big); return -1; }
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        if (sync_global_scores()) return -1;
+        if (sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+        if (!jobs || !outs) { pthread_mutex_unlock(&g_big); return set_err("mz_yama_batch: NULL jobs or outs"); }
         clock_gettime(CLOCK_MONOTONIC, &t2);
-        if (first) fprintf(stderr, "mz_yama_batch: GPU start-up %.1f ms (HIP runtime, streams), score upload incl. code object load %.1f ms\n",
-                           1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), 1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
+        if (first) fprintf(stderr, "mz_yama_batch: GPU start-up %.1f ms (HIP runtime, streams; %d GPU%s), score upload incl. code object load %.1f ms\n",
+                           1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), g_ndev, g_ndev > 1 ? "s" : "",
+                           1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
+    }
+    /* GPUs to use: all of them once every one gets a worthwhile share */
+    use = g_ndev;
+    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
+    {
+        /* chunk size: about a quarter of a GPU's share, so that even a few thousand pairs overlap their copies with
+         * their kernels, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU) and at most 16 Ki */
+        const int share = (n + use - 1) / use;
+        max_pairs = env_pairs ? env_pairs : (share + 3) / 4 < 1024 ? 1024 : (share + 3) / 4 > 16384 ? 16384 : (share + 3) / 4;
+    }
+    if (use == 1) {
+        g_copy_threads = MZ_COPY_THREADS;
+        rc = batch_on_ctx(&G, n, jobs, outs, max_pairs);
+        pthread_mutex_unlock(&g_big);
+        return rc;
     }
     {
-        /* Up to four chunks in flight on four buffer sets and streams: while chunk k is uploaded and planned the
-         * host packs chunk k+1; when the plan's totals of chunk k are in, its kernels and the copy of its results
-         * are issued; chunk k-1 is computing or copying back; chunk k-2 is unpacked.  The host does not wait for a
-         * copy or a kernel it could work beside. */
-        chunk ck[MZ_SETS];
-        int k = 0, up = 0, rc;
-#define NEXT_CHUNK(first, count) do { size_t bytes_ = 0; int m_ = 0; \
-            while ((first) + m_ < n && m_ < max_pairs && bytes_ < ((size_t)1 << 30)) { \
-                const mz_job *j_ = &jobs[(first) + m_]; \
-                if (j_->K >= 1 && j_->L >= 1 && j_->M >= 1 && j_->N >= 1) \
-                    bytes_ += (size_t)j_->K * j_->M + (size_t)j_->L * j_->N + 8 * ((size_t)j_->M + 1); \
-                ++m_; } (count) = m_; } while (0)
-        {
-            int m0;
-            NEXT_CHUNK(0, m0);
-            if (chunk_upload(&ck[0], 0, m0, jobs, outs)) return -1;
-            up = m0;
-        }
-        for (k = 0; done < n; ++k) {
-            chunk *cur = &ck[k % MZ_SETS];
-            if (up < n) {                                    /* pack + upload the next chunk beside this one's copy */
-                int m1;
-                NEXT_CHUNK(up, m1);
-                if (chunk_upload(&ck[(k + 1) % MZ_SETS], (k + 1) % MZ_SETS, m1, jobs + up, outs + up)) return -1;
-                up += m1;
+        /* Contiguous ranges of about equal weight, one per GPU, each driven by its own host thread through its own
+         * context (streams, staging buffers); results land in outs[] at the jobs' own positions, so there is nothing
+         * to gather.  No data-path collective: the work list lives in host memory and every GPU pulls its share over
+         * its own PCIe link. */
+        dev_task task[MZ_MAX_DEV];
+        pthread_t th[MZ_MAX_DEV];
+        double total = 0.0, acc = 0.0;
+        int d = 0, start = 0, started[MZ_MAX_DEV];
+        for (p = 0; p < n; ++p) total += job_weight(&jobs[p]);
+        g_copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
+        for (p = 0; p < n && d < use; ++p) {
+            acc += job_weight(&jobs[p]);
+            if (d == use - 1) { p = n - 1; acc = total; }
+            if (acc >= total * (d + 1) / use || p == n - 1) {
+                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
+                task[d].n = p + 1 - start; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0;
+                start = p + 1;
+                ++d;
             }
-            if (chunk_launch(cur)) return -1;
-            if (k > 1) {
-                rc = chunk_collect(&ck[(k - 2) % MZ_SETS]);
-                if (rc < 0) return rc;
-                failed += rc;
-            }
-            done += cur->n;
         }
-        if (k > 1) {
-            rc = chunk_collect(&ck[(k - 2) % MZ_SETS]);
-            if (rc < 0) return rc;
-            failed += rc;
+        use = d;
+        for (d = 1; d < use; ++d) {
+            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, dev_worker, &task[d]) == 0;
+            if (!started[d] && task[d].n > 0) dev_worker(&task[d]);         /* no thread: do it here, after the others started */
         }
-        rc = chunk_collect(&ck[(k - 1) % MZ_SETS]);
-        if (rc < 0) return rc;
-        failed += rc;
-#undef NEXT_CHUNK
+        if (task[0].n > 0) dev_worker(&task[0]);
+        rc = 0;
+        for (d = 0; d < use; ++d) {
+            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
+            if (task[d].n <= 0) continue;
+            if (task[d].rc < 0) { rc = -1; set_err("%s", task[d].err); }
+            else failed += task[d].rc;
+        }
+        hipSetDevice(G.device);
+        g_copy_threads = MZ_COPY_THREADS;
+        pthread_mutex_unlock(&g_big);
+        return rc < 0 ? -1 : failed;
     }
-    return failed;
+}
+
+/* free the merged columns of a finished mz_yama_batch() call (every cols pointer; NULLs are skipped) */
+void mz_free_outs(int n, mz_out *outs)
+{
+    int p;
+    for (p = 0; p < n; ++p) { free(outs[p].cols); outs[p].cols = NULL; }
 }
 
 /* ------------------------------------------------------------------ yama(): a batch of one */
@@ -723,10 +912,12 @@ __attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o)
     case MZ_E_LB_MONO:  mz_fatalf("LB not monotonic");
     case MZ_E_RB_MONO:  mz_fatalf("RB not monotonic");
     case MZ_E_TRACEBACK: mz_fatalf("Error generating edit script.");
-    case MZ_E_EMIT:     mz_fatalf("new_align: M=%d, N=%d, M_new=%d\n", j->M, j->N, o->OM);
-    case MZ_E_ROWS:     mz_fatalf("yama(gfx950): K=%d, L=%d outside the supported 1..127 rows per block", j->K, j->L);
+    case MZ_E_EMIT:     /* mz_yama.c:311-312 (the reference prints j twice) */
+        mz_fatalf("new_align: i=%d, j=%d, m=%d, M=%d, N=%d, M_new=%d\n", o->score[0], o->score[1], o->score[1], j->M, j->N, o->OM);
+    case MZ_E_ROWS:     mz_fatalf("yama(gfx950): K=%d, L=%d outside the supported 1..255 rows per block", j->K, j->L);
     case MZ_E_SHAPE:    mz_fatalf("yama(gfx950): empty block (M=%d, N=%d)", j->M, j->N);
-    case MZ_E_RANGE:    mz_fatalf("yama(gfx950): K*L*(M+N) = %d*%d*%d would overflow the 32-bit scores", j->K, j->L, j->M + j->N);
+    case MZ_E_RANGE:    mz_fatalf("yama(gfx950): M + N = %lld columns exceed the 2^30 steps of this build", (long long)j->M + j->N);
+    case MZ_E_DEVICE:   mz_fatalf("yama(gfx950): not computed (device error or out of memory)");
     default:            mz_fatalf("yama(gfx950): device status %d", o->status);
     }
 }

@@ -56,6 +56,45 @@ void mz_synth_shapes(int n, uint64_t seed, int64_t first_pair, int K, int L, int
     totals[0] = oa; totals[1] = ob; totals[2] = oband;
 }
 
+/* BASELINE config 4: the block pairs of a 30-leaf guide tree.  The tree is a balanced
+ * 16-leaf subtree with a 14-leaf caterpillar on top: 29 internal nodes, and the merge at a node with p and q leaves
+ * below its two children aligns a p-row block with a q-row block (K = p, L = q; tba.c:177-255 walks such a tree
+ * bottom-up, every node's merges are independent of its siblings').  Pair p of a batch belongs to a node drawn
+ * from its own random stream, so all 29 shapes are mixed through any shard. */
+static const unsigned char tree30[29][2] = {
+    { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 }, { 1, 1 },      /* balanced part: 8 cherries */
+    { 2, 2 }, { 2, 2 }, { 2, 2 }, { 2, 2 }, { 4, 4 }, { 4, 4 }, { 8, 8 },                /* ... up to its 16-leaf root */
+    { 16, 1 }, { 17, 1 }, { 18, 1 }, { 19, 1 }, { 20, 1 }, { 21, 1 }, { 22, 1 },         /* caterpillar: one more leaf per node */
+    { 23, 1 }, { 24, 1 }, { 25, 1 }, { 26, 1 }, { 27, 1 }, { 28, 1 }, { 29, 1 } };
+
+int mz_synth_tree_nodes(int32_t *K, int32_t *L)
+{
+    int i;
+    for (i = 0; i < 29; ++i) { if (K) K[i] = tree30[i][0]; if (L) L[i] = tree30[i][1]; }
+    return 29;
+}
+
+/* shapes of pair p for the tree workload: (K, L) of a random node, columns uniform in [lo, hi] */
+void mz_synth_shapes_tree(int n, uint64_t seed, int64_t first_pair, int mlo, int mhi,
+                          int32_t *aK, int32_t *aL, int32_t *aM, int32_t *aN,
+                          int64_t *offA, int64_t *offB, int64_t *offBand, int64_t totals[3])
+{
+    int64_t oa = 0, ob = 0, oband = 0;
+    int p;
+    for (p = 0; p < n; ++p) {
+        rng_t r;
+        unsigned node;
+        rng_seed(&r, seed, (uint64_t)(first_pair + p));
+        aM[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        aN[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        node = below(&r, 29);
+        aK[p] = tree30[node][0]; aL[p] = tree30[node][1];
+        offA[p] = oa; offB[p] = ob; offBand[p] = oband;
+        oa += (int64_t)aK[p] * aM[p]; ob += (int64_t)aL[p] * aN[p]; oband += aM[p] + 1;
+    }
+    totals[0] = oa; totals[1] = ob; totals[2] = oband;
+}
+
 static unsigned char base_byte(rng_t *r, int odd)
 {
     static const char acgt[4] = { 'A', 'C', 'G', 'T' };
@@ -70,6 +109,7 @@ void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius,
                    uint8_t *poolA, uint8_t *poolB, int32_t *poolLB, int32_t *poolRB)
 {
     int p;
+#pragma omp parallel for schedule(dynamic, 64) if (n > 256)       /* (every pair has its own stream: any order) */
     for (p = 0; p < n; ++p) {
         const int K = aK[p], L = aL[p], M = aM[p], N = aN[p];
         uint8_t *A = poolA + offA[p], *B = poolB + offB[p];
@@ -110,4 +150,17 @@ void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius,
         LB[0] = 0;
         smooth(LB, RB, M, N, radius);
     }
+}
+
+/* src[off[i] .. off[i]+len[i]) (elements of `elem` bytes) back to back into dst: the re-packing step of sharding a
+ * batch (multiz_amd/shard.py) and of sampling one (bench.py), one memcpy per segment on the host threads */
+void mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const void *src, void *dst)
+{
+    int64_t *pos = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof *pos), acc = 0, i;
+    if (!pos) return;
+    for (i = 0; i < n; ++i) { pos[i] = acc; acc += len[i]; }
+#pragma omp parallel for schedule(static) if (n > 1024)
+    for (i = 0; i < n; ++i)
+        memcpy((char *)dst + pos[i] * elem, (const char *)src + off[i] * elem, (size_t)(len[i] * elem));
+    free(pos);
 }

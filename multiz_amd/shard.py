@@ -2,13 +2,19 @@
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 Block pairs share nothing, so the data path has no collective: the root partitions the work list by
-cost (longest-processing-time greedy over band cells), hands every rank its packed sub-batch with one
-group of point-to-point sends (xGMI is point-to-point: one peer per link, all links busy at once),
-each rank aligns its shard, results come back the same way and are put back in the caller's order.
-A single all-reduce of three scalars (pairs, cells, failures) closes the batch.
+cost (band cells, heaviest first, dealt out in a snake so that every rank gets the same mix), hands every
+rank its packed sub-batch with one group of point-to-point sends (xGMI is point-to-point: one peer per
+link, all links busy at once), each rank aligns its shard ON ITS GPU straight from the received tensors
+(`device_compute`: a DevBatch over them, no host bounce), results come back the same way and are addressed
+in the caller's order.  A single all-reduce of three scalars (pairs, cells, failures) closes the batch.
+
+Nothing here loops over pairs in Python: partition is a sort, re-packing is a C gather of segments
+(mz_gather_segments in libmzamd.so), re-assembly is index arithmetic -- a guide-tree level of a million
+merges (BASELINE config 4) is dealt out in a fraction of the time its alignment takes.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
@@ -29,15 +35,35 @@ def pair_cost(batch: Dict[str, np.ndarray]) -> np.ndarray:
 
 
 def partition(cost: np.ndarray, world: int) -> List[np.ndarray]:
-    """LPT greedy: heaviest pair first onto the lightest rank; indices of each rank in ascending order"""
-    order = np.argsort(-cost, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    owner = np.empty(len(cost), dtype=np.int64)
-    for i in order:
-        r = int(np.argmin(load))
-        owner[i] = r
-        load[r] += int(cost[i])
+    """Heaviest pair first, dealt to the ranks in a snake (0..W-1, W-1..0, ...): one sort, no per-pair loop.
+    Within a round of 2W pairs rank i gets the i-th heaviest and the i-th lightest, so the loads differ by at
+    most the spread of the costs (max - min), like the longest-processing-time greedy this replaces.
+    Indices of each rank come back in ascending order."""
+    n = len(cost)
+    order = np.argsort(-np.asarray(cost, dtype=np.int64), kind="stable")
+    pos = np.arange(n, dtype=np.int64)
+    rnd, k = pos // world, pos % world
+    owner_sorted = np.where(rnd % 2 == 0, k, world - 1 - k)
+    owner = np.empty(n, dtype=np.int64)
+    owner[order] = owner_sorted
     return [np.flatnonzero(owner == r) for r in range(world)]
+
+
+def _gather(pool: np.ndarray, off: np.ndarray, ln: np.ndarray) -> np.ndarray:
+    """pool[off[i] : off[i]+ln[i]] back to back, copied by the library (memcpy per segment on the host threads)"""
+    from .api import lib
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    ln = np.ascontiguousarray(ln, dtype=np.int64)
+    out = np.empty(int(ln.sum()), dtype=pool.dtype)
+    if len(off):
+        f = lib().mz_gather_segments
+        f.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        f(len(off), pool.dtype.itemsize, off.ctypes.data, ln.ctypes.data, np.ascontiguousarray(pool).ctypes.data, out.ctypes.data)
+    return out
+
+
+def _excl(x: np.ndarray) -> np.ndarray:
+    return (np.cumsum(x) - x).astype(np.int64)
 
 
 def take(batch: Dict[str, np.ndarray], idx: np.ndarray) -> Dict[str, np.ndarray]:
@@ -45,17 +71,10 @@ def take(batch: Dict[str, np.ndarray], idx: np.ndarray) -> Dict[str, np.ndarray]
     idx = np.asarray(idx, dtype=np.int64)
     K, L, M, N = (batch[k][idx].astype(np.int64) for k in ("K", "L", "M", "N"))
     la, lb, ld = K * M, L * N, M + 1
-    oa, ob, od = (np.concatenate([[0], np.cumsum(x)[:-1]]).astype(np.int64) if len(x) else np.zeros(0, np.int64) for x in (la, lb, ld))
-
-    def gather(pool, off, ln):
-        if len(idx) == 0:
-            return pool[:0].copy()
-        return np.concatenate([pool[int(o): int(o) + int(n)] for o, n in zip(off, ln)])
-
     out = {k: batch[k][idx].astype(np.int32) for k in ("K", "L", "M", "N")}
-    out.update(offA=oa, offB=ob, offBand=od,
-               poolA=gather(batch["poolA"], batch["offA"][idx], la), poolB=gather(batch["poolB"], batch["offB"][idx], lb),
-               poolLB=gather(batch["poolLB"], batch["offBand"][idx], ld), poolRB=gather(batch["poolRB"], batch["offBand"][idx], ld))
+    out.update(offA=_excl(la), offB=_excl(lb), offBand=_excl(ld),
+               poolA=_gather(batch["poolA"], batch["offA"][idx], la), poolB=_gather(batch["poolB"], batch["offB"][idx], lb),
+               poolLB=_gather(batch["poolLB"], batch["offBand"][idx], ld), poolRB=_gather(batch["poolRB"], batch["offBand"][idx], ld))
     return out
 
 
@@ -63,9 +82,14 @@ def _dtype(name):
     return np.int32 if name in _I32 else np.int64 if name in _I64 else np.uint8
 
 
+def _tdtype(torch, name):
+    return getattr(torch, np.dtype(_dtype(name)).name)
+
+
 def scatter_batch(batch: Optional[Dict[str, np.ndarray]], src: int = 0, device="cpu", group=None):
-    """Root: partition + send each rank its shard.  Every rank: returns (shard, global indices of its pairs).
-    Sizes travel in one broadcast header; payloads in ONE batch of point-to-point ops."""
+    """Root: partition + send each rank its shard.  Every rank: returns (shard as torch tensors on `device`, global
+    indices of its pairs as a numpy array).  Sizes travel in one broadcast header; payloads in ONE batch of
+    point-to-point ops (RCCL: one grouped launch, all xGMI links at once)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -74,15 +98,13 @@ def scatter_batch(batch: Optional[Dict[str, np.ndarray]], src: int = 0, device="
     if rank == src:
         parts = partition(pair_cost(batch), world)
         shards = [take(batch, p) for p in parts]
-        for r, s in enumerate(shards):
-            header[r, :-1] = torch.tensor([len(s[f]) for f in FIELDS])
-            header[r, -1] = len(parts[r])
+        header[:, :-1] = torch.tensor([[len(s[f]) for f in FIELDS] for s in shards], dtype=torch.int64)
+        header[:, -1] = torch.tensor([len(p) for p in parts], dtype=torch.int64)
     dist.broadcast(header, src=src, group=group)
     sizes = header[rank].tolist()
-    mine = {f: torch.empty(sizes[i], dtype=getattr(torch, np.dtype(_dtype(f)).name), device=device) for i, f in enumerate(FIELDS)}
-    my_idx = torch.empty(sizes[-1], dtype=torch.int64, device=device)
     ops, keep = [], []
     if rank == src:
+        mine, my_idx = None, None
         for r in range(world):
             tens = {f: torch.from_numpy(np.ascontiguousarray(shards[r][f], dtype=_dtype(f))).to(device) for f in FIELDS}
             tidx = torch.from_numpy(parts[r].astype(np.int64)).to(device)
@@ -94,60 +116,76 @@ def scatter_batch(batch: Optional[Dict[str, np.ndarray]], src: int = 0, device="
                 if tidx.numel():
                     ops.append(dist.P2POp(dist.isend, tidx, r, group))
     else:
+        mine = {f: torch.empty(sizes[i], dtype=_tdtype(torch, f), device=device) for i, f in enumerate(FIELDS)}
+        my_idx = torch.empty(sizes[-1], dtype=torch.int64, device=device)
         ops += [dist.P2POp(dist.irecv, mine[f], src, group) for f in FIELDS if mine[f].numel()]
         if my_idx.numel():
             ops.append(dist.P2POp(dist.irecv, my_idx, src, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return {f: mine[f].cpu().numpy() for f in FIELDS}, my_idx.cpu().numpy()
+    return mine, my_idx.cpu().numpy()
 
 
-def gather_results(om: np.ndarray, cols: np.ndarray, my_idx: np.ndarray, n_total: int, dst: int = 0, device="cpu", group=None):
-    """cols: the rank's merged columns back to back (pair i contributes om[i]*(K+L) bytes).
-    Root returns (om_all int32[n_total], list of byte arrays in the caller's pair order); others None."""
+class Sharded:
+    """What the root holds after the gather: every rank's output buffer as it left the GPU, and for each pair of the
+    caller's list its owner, its offset in that buffer and its merged length -- the caller's order by indexing."""
+
+    def __init__(self, n_total: int, widths: np.ndarray):
+        self.om = np.zeros(n_total, dtype=np.int32)
+        self.status = np.full(n_total, -1, dtype=np.int32)
+        self.owner = np.full(n_total, -1, dtype=np.int32)
+        self.off = np.zeros(n_total, dtype=np.int64)
+        self.widths = np.asarray(widths, dtype=np.int64)
+        self.bufs: Dict[int, np.ndarray] = {}
+
+    def cols(self, i: int) -> np.ndarray:
+        o, nb = int(self.off[i]), int(self.om[i]) * int(self.widths[i])
+        return self.bufs[int(self.owner[i])][o: o + nb]
+
+    def __iter__(self):
+        return (self.cols(i) for i in range(len(self.om)))
+
+
+def gather_results(res: dict, my_idx: np.ndarray, n_total: int, widths: Optional[np.ndarray], dst: int = 0, device="cpu", group=None):
+    """res: what compute returned -- om int32[n], status int32[n], off int64[n] (offset of pair i's merged columns in
+    out), out uint8[...] as torch tensors (on `device`, or anywhere: they are moved).  One grouped exchange; the root
+    returns a Sharded, the others None."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    meta = torch.tensor([len(om), len(cols)], dtype=torch.int64, device=device)
+    t_om, t_st, t_off, t_out = (res[k].to(device) for k in ("om", "status", "off", "out"))
+    t_idx = torch.from_numpy(np.ascontiguousarray(my_idx, dtype=np.int64)).to(device)
+    meta = torch.tensor([t_om.numel(), t_out.numel()], dtype=torch.int64, device=device)
     metas = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
-    t_om = torch.from_numpy(np.ascontiguousarray(om, dtype=np.int32)).to(device)
-    t_idx = torch.from_numpy(np.ascontiguousarray(my_idx, dtype=np.int64)).to(device)
-    t_cols = torch.from_numpy(np.ascontiguousarray(cols, dtype=np.uint8)).to(device)
     if rank != dst:
-        ops = [dist.P2POp(dist.isend, t, dst, group) for t in (t_om, t_idx, t_cols) if t.numel()]
+        ops = [dist.P2POp(dist.isend, t, dst, group) for t in (t_om, t_st, t_off, t_idx, t_out) if t.numel()]
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         return None
     bufs, ops = {}, []
     for r in range(world):
         if r == dst:
-            bufs[r] = (t_om, t_idx, t_cols)
+            bufs[r] = (t_om, t_st, t_off, t_idx, t_out)
             continue
         n, nb = (int(x) for x in metas[r].tolist())
-        b = (torch.empty(n, dtype=torch.int32, device=device), torch.empty(n, dtype=torch.int64, device=device),
+        b = (torch.empty(n, dtype=torch.int32, device=device), torch.empty(n, dtype=torch.int32, device=device),
+             torch.empty(n, dtype=torch.int64, device=device), torch.empty(n, dtype=torch.int64, device=device),
              torch.empty(nb, dtype=torch.uint8, device=device))
         bufs[r] = b
         ops += [dist.P2POp(dist.irecv, t, r, group) for t in b if t.numel()]
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
-    om_all = np.zeros(n_total, dtype=np.int32)
-    out: List[Optional[np.ndarray]] = [None] * n_total
-    return om_all, out, {r: tuple(t.cpu().numpy() for t in b) for r, b in bufs.items()}
-
-
-def reassemble(gathered, widths: np.ndarray):
-    """put every rank's pairs back at their original positions; widths[i] = K+L of pair i"""
-    om_all, out, bufs = gathered
-    for r, (om, idx, cols) in bufs.items():
-        pos = 0
-        for m, i in zip(om, idx):
-            nb = int(m) * int(widths[i])
-            om_all[i] = m
-            out[int(i)] = cols[pos: pos + nb]
-            pos += nb
-    return om_all, out
+    sh = Sharded(n_total, widths)
+    for r, (om, st, off, idx, out) in bufs.items():
+        i = idx.cpu().numpy()
+        sh.om[i] = om.cpu().numpy()
+        sh.status[i] = st.cpu().numpy()
+        sh.off[i] = off.cpu().numpy()
+        sh.owner[i] = r
+        sh.bufs[r] = out.cpu().numpy()
+    return sh
 
 
 def close_batch(pairs: int, cells: int, failed: int, device="cpu", group=None):
@@ -159,20 +197,37 @@ def close_batch(pairs: int, cells: int, failed: int, device="cpu", group=None):
     return tuple(int(x) for x in t.tolist())
 
 
-def run_sharded(batch: Optional[Dict[str, np.ndarray]], compute: Callable, src: int = 0, device="cpu", group=None):
-    """scatter -> compute(shard) -> gather.  compute returns (om int32[n], cols uint8 back to back, cells, failed).
-    Root gets (om_all, list of merged-column byte arrays in the original order, totals); others (None, None, totals)."""
+def device_compute(shard: dict, device=None, keep: Optional[list] = None) -> dict:
+    """The product's compute for run_sharded(): the received tensors ARE the device batch (moved only if they arrived
+    on another device, as in the gloo tests); plan, DP, walk, emit through the C ABI (mz_dev_run)."""
+    import torch
+    from .api import DevBatch
+    dev = torch.device(device) if device is not None else shard["K"].device
+    n = int(shard["K"].numel())
+    if n == 0:
+        z = lambda dt: torch.zeros(0, dtype=dt, device=dev)  # noqa: E731
+        return dict(om=z(torch.int32), status=z(torch.int32), off=z(torch.int64), out=z(torch.uint8), cells=0, failed=0)
+    db = DevBatch.from_tensors({k: v.to(dev) for k, v in shard.items()}, device=dev)
+    db.run()
+    r = db.results_device()
+    if keep is not None:
+        keep.append(db)
+    total = int(r["totals"][2].item())
+    return dict(om=r["om"], status=r["status"], off=r["offOut"], out=db.out[:total],
+                cells=int(r["cells"].sum().item()), failed=int((r["status"] != 0).sum().item()))
+
+
+def run_sharded(batch: Optional[Dict[str, np.ndarray]], compute: Callable = device_compute, src: int = 0, device="cpu", group=None):
+    """scatter -> compute(shard) -> gather.  compute takes the shard (dict of torch tensors on `device`) and returns
+    dict(om, status, off, out: torch tensors; cells, failed: ints).  Root gets (Sharded, totals); others (None, totals)."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
     n_total = torch.tensor([len(batch["K"]) if rank == src else 0], dtype=torch.int64, device=device)
     dist.broadcast(n_total, src=src, group=group)
     shard, my_idx = scatter_batch(batch, src, device, group)
-    om, cols, cells, failed = compute(shard)
-    g = gather_results(om, cols, my_idx, int(n_total.item()), src, device, group)
-    totals = close_batch(len(my_idx), cells, failed, device, group)
-    if rank != src:
-        return None, None, totals
-    widths = batch["K"].astype(np.int64) + batch["L"].astype(np.int64)
-    om_all, out = reassemble(g, widths)
-    return om_all, out, totals
+    res = compute(shard)
+    widths = (batch["K"].astype(np.int64) + batch["L"].astype(np.int64)) if rank == src else None
+    sh = gather_results(res, my_idx, int(n_total.item()), widths, src, device, group)
+    totals = close_batch(len(my_idx), res["cells"], res["failed"], device, group)
+    return sh, totals

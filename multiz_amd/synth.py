@@ -15,8 +15,26 @@ CONFIGS = {
     "c1": dict(K=2, L=1, mlo=180, mhi=220, pairs=100, radius=30),
     "c2": dict(K=2, L=2, mlo=900, mhi=1100, pairs=50000, radius=30),
     "c3": dict(K=10, L=10, mlo=1800, mhi=2200, pairs=5000, radius=30),
+    # configs[3]: 1 M pairs over 8 GPUs from a 30-leaf caterpillar+balanced guide tree (mz_synth.c: tree30); K = L = 0
+    # stands for "K, L of a random tree node per pair"; `pairs` is one GPU's share
+    "c4": dict(K=0, L=0, mlo=200, mhi=1000, pairs=125000, radius=30),
     "c5": dict(K=2, L=2, mlo=95000, mhi=105000, pairs=1000, radius=30),
 }
+
+
+def describe(name: str, pairs: int) -> str:
+    c = CONFIGS[name]
+    rows = "K,L from a 30-leaf caterpillar+balanced guide tree (1..29 rows)" if c["K"] == 0 else f"{c['K']}+{c['L']} rows"
+    return f"{name}: {pairs} block pairs/GPU, {rows}, M,N~U[{c['mlo']},{c['mhi']}], diag band R={c['radius']}"
+
+
+def tree_nodes():
+    """(K, L) of the 29 internal nodes of the C4 guide tree"""
+    l = lib()
+    K, L = np.zeros(29, dtype=np.int32), np.zeros(29, dtype=np.int32)
+    l.mz_synth_tree_nodes.argtypes = [C.c_void_p, C.c_void_p]
+    assert l.mz_synth_tree_nodes(K.ctypes.data, L.ctypes.data) == 29
+    return K, L
 
 
 def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, seed: int = BASE_SEED,
@@ -25,9 +43,14 @@ def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, see
     aK, aL, aM, aN = (np.zeros(n, dtype=np.int32) for _ in range(4))
     oA, oB, oBand = (np.zeros(n, dtype=np.int64) for _ in range(3))
     tot = (C.c_int64 * 3)()
-    l.mz_synth_shapes.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
-    l.mz_synth_shapes(n, seed, first_pair, K, L, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
-                      oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
+    if K == 0 and L == 0:                # the tree workload (configs[3])
+        l.mz_synth_shapes_tree.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
+        l.mz_synth_shapes_tree(n, seed, first_pair, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
+                               oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
+    else:
+        l.mz_synth_shapes.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
+        l.mz_synth_shapes(n, seed, first_pair, K, L, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
+                          oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
     poolA = np.zeros(max(tot[0], 1), dtype=np.uint8)
     poolB = np.zeros(max(tot[1], 1), dtype=np.uint8)
     poolLB = np.zeros(max(tot[2], 1), dtype=np.int32)
@@ -50,18 +73,8 @@ def pair_of(batch: dict, i: int):
 
 def subset(batch: dict, idx) -> dict:
     """re-pack the chosen pairs into a new batch (used for the CPU-baseline sample)"""
-    idx = np.asarray(idx)
-    out = {k: batch[k][idx].copy() for k in ("K", "L", "M", "N")}
-    pa, pb, plb, prb, oa, ob, od = [], [], [], [], [], [], []
-    a = b = d = 0
-    for i in idx:
-        A, B, LB, RB = pair_of(batch, int(i))
-        oa.append(a); ob.append(b); od.append(d)
-        pa.append(A.ravel()); pb.append(B.ravel()); plb.append(LB); prb.append(RB)
-        a += A.size; b += B.size; d += LB.size
-    out.update(offA=np.array(oa, dtype=np.int64), offB=np.array(ob, dtype=np.int64), offBand=np.array(od, dtype=np.int64),
-               poolA=np.concatenate(pa), poolB=np.concatenate(pb), poolLB=np.concatenate(plb), poolRB=np.concatenate(prb))
-    return out
+    from .shard import take
+    return take(batch, np.asarray(idx, dtype=np.int64))
 
 
 def band_cells(batch: dict) -> int:

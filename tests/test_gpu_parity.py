@@ -109,7 +109,7 @@ def test_invalid_bands_are_reported(mz):
         if rc == 2:
             assert got.badrow == bad
     # row-count limits of this build are reported, not mis-computed
-    big = inputs.make_pair(rng, 130, 2, 20, 20, 30, "diag", mo.smooth)
+    big = inputs.make_pair(rng, 256, 2, 20, 20, 30, "diag", mo.smooth)
     assert mz.yama_batch([big])[0].status == 16
 
 
@@ -172,6 +172,41 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
         top, bot = g[:, :K], g[:, K:]
         assert np.array_equal(top[~(top == 45).all(axis=1)], A)
         assert np.array_equal(bot[~(bot == 45).all(axis=1)], B)
+
+
+def test_config4_tree_workload(mz):
+    # BASELINE.json configs[3]: block pairs of a 30-leaf caterpillar+balanced guide tree (K = p, L = q at a node with
+    # p, q leaves below its children; M,N~U[200,1000]) -- 20 000 pairs of one GPU's share, every pair against the
+    # oracle by hash of (OM, merged columns), through the device-resident API that bench.py --config c4 times
+    from multiz_amd import synth
+    n = 20000
+    c = synth.CONFIGS["c4"]
+    batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=3 * 125000)
+    tk, tl = synth.tree_nodes()
+    assert set(zip(batch["K"].tolist(), batch["L"].tolist())) == set(zip(tk.tolist(), tl.tolist()))   # all 29 node shapes
+    assert batch["K"].max() == 29 and (batch["K"] + batch["L"]).max() == 30
+    _kernels(mz, 2)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    assert set(res["mode"].tolist()) <= {5, 6, 7, 8}, np.bincount(res["mode"])        # all on the row-parallel kernels
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
+    assert bad == 0 and cells == int(res["cells"].sum())
+    host_out = db.out.cpu().numpy()
+    W = batch["K"].astype(np.int64) + batch["L"]
+    mism = 0
+    for i in range(n):
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        mism += m_ != om[i] or _hash(host_out[o0: o0 + m_ * int(W[i])], m_) != int(hs[i])
+    assert mism == 0, mism
+    # the literal O(K*L)-per-cell restatement on a few pairs of the deepest nodes
+    deep = np.flatnonzero(batch["K"] * batch["L"] >= 29)[:6]
+    for i in deep:
+        A, B, LB, RB = synth.pair_of(batch, int(i))
+        w = mo.yama(A, B, LB, RB)
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == w.OM and np.array_equal(host_out[o0: o0 + m_ * int(W[i])].reshape(m_, -1), w.cols)
 
 
 def test_every_kernel_family_is_exercised(mz):
@@ -300,6 +335,72 @@ def test_long_block_regime(mz):
         assert res["final3"][i].max() == want.final.max()
         live = want.final > -(1 << 29)
         assert np.array_equal(res["final3"][i][live], want.final[live])
+
+
+def test_no_global_score_range_limit(mz):
+    # The reference has no bound on K*L*(M+N) (mz_yama.c:50-71).  Round 1 refused every pair whose WORST-CASE path
+    # score could pass 2^30; now only the guard-dropping kernels are restricted (by the plan), the row-parallel
+    # kernels re-base and the exact ones compute in the reference's int32.  Shapes that used to die with MZ_E_RANGE:
+    # a 30-way merge of 13 000 columns, a 100-way block pair (K*L = 2 500) of 4 000 columns, a long 20-way pair on
+    # the exact kernels.  Real scores stay far inside int32 (checked against the oracle's finals).
+    from multiz_amd import synth
+    rng = np.random.default_rng(31)
+    pairs = [inputs.make_pair(rng, 15, 15, 6500, 6480, 30, "diag", mo.smooth),
+             inputs.make_pair(rng, 50, 50, 2000, 2000, 30, "diag", mo.smooth),
+             inputs.make_pair(rng, 29, 1, 9000, 9100, 30, "diag", mo.smooth),
+             inputs.make_pair(rng, 10, 10, 15000, 14900, 30, "diag", mo.smooth),
+             inputs.make_pair(rng, 60, 40, 700, 720, 12, "wander", mo.smooth)]
+    want = [mo.yama(*p, variant="profile") for p in pairs]
+    faithful = mo.yama(*pairs[1])                        # O(K*L) per cell: the literal restatement, once
+    assert faithful.OM == want[1].OM and np.array_equal(faithful.cols, want[1].cols)
+    batch = synth.pack_pairs(pairs)
+    seen = np.zeros(16, dtype=np.int64)
+    for which in (2, 1, 0):
+        _kernels(mz, which)
+        db = mz.DevBatch(batch)
+        db.run()
+        res = db.results()
+        assert (res["status"] == 0).all(), (which, res["status"])
+        seen += np.bincount(res["mode"], minlength=16)
+        out = db.out.cpu().numpy()
+        for i, (p, w) in enumerate(zip(pairs, want)):
+            m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+            assert m_ == w.OM, (which, i, int(res["mode"][i]))
+            assert np.array_equal(out[o0: o0 + m_ * (p[0].shape[1] + p[1].shape[1])].reshape(m_, -1), w.cols), (which, i, int(res["mode"][i]))
+            assert res["final3"][i].max() == w.final.max(), (which, i)
+    assert seen[7] + seen[8] > 0 and seen[0] > 0, seen
+    _kernels(mz, 2)
+
+
+def test_blocks_of_more_than_127_rows(mz):
+    # K, L up to 255: the exact kernels on int16 gap vectors (MZ_MODE_WIDE, and WIDESTRIP for bands the rolling
+    # wavefront cannot hold), against the oracle -- the literal O(K*L) restatement on the small ones
+    from multiz_amd import synth
+    rng = np.random.default_rng(150)
+    shapes = [(150, 3, 300, 310, 30, "diag"), (3, 200, 260, 250, 30, "diag"), (140, 130, 120, 124, 30, "diag"),
+              (255, 1, 90, 90, 30, "diag"), (1, 255, 80, 95, 12, "wander"), (128, 128, 70, 66, 30, "full"),
+              (160, 2, 400, 380, 100, "diag"), (2, 129, 150, 150, 60, "diag")]
+    pairs = [inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth, dash=float(rng.choice([0.05, 0.3])), odd=0.05)
+             for (K, L, M, N, R, band) in shapes]
+    pairs = [p for p in pairs if mo.check(p[0].shape[0], p[1].shape[0], p[2], p[3])[0] == 0]
+    batch = synth.pack_pairs(pairs)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all(), res["status"]
+    assert set(res["mode"].tolist()) <= {9, 10} and (res["mode"] == 9).any() and (res["mode"] == 10).any(), res["mode"]
+    out = db.out.cpu().numpy()
+    for i, p in enumerate(pairs):
+        w = mo.yama(*p, variant="faithful" if p[0].shape[0] * p[1].shape[0] < 30000 else "profile")
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == w.OM, i
+        assert np.array_equal(out[o0: o0 + m_ * (p[0].shape[1] + p[1].shape[1])].reshape(m_, -1), w.cols), i
+        assert np.array_equal(res["final3"][i], w.final), i          # exact kernels: the reference's own triple
+    # and through the host path, next to ordinary pairs
+    mixed = pairs[:3] + [inputs.make_pair(rng, 2, 2, 200, 210, 30, "diag", mo.smooth)]
+    for p, r in zip(mixed, mz.yama_batch(mixed)):
+        w = mo.yama(*p, variant="profile")
+        assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols)
 
 
 def test_empty_and_tiny_batches(mz):

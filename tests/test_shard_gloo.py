@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercising partition, grouped
 send/recv scatter, gather + reassembly and the closing all-reduce of multiz_amd/shard.py.  The per-rank
-compute is the CPU oracle standing in for the device (this test checks the exchange, not the kernel)."""
+compute is the CPU oracle standing in for the device (this test checks the exchange, not the kernel; the same
+exchange with the real device compute runs under -m gpu in test_shard_gpu.py)."""
 import os
 import socket
 
@@ -30,17 +31,25 @@ def _batch(seed, n):
 
 
 def _oracle_compute(shard):
+    """stands in for multiz_amd.shard.device_compute on a box without a GPU: same contract (om, status, off, out as
+    torch tensors; out padded between pairs like the device's output buffer)"""
+    import torch
+    shard = {k: v.cpu().numpy() for k, v in shard.items()}
     n = len(shard["K"])
-    om, chunks, cells = np.zeros(n, np.int32), [], 0
+    om, off, chunks, cells, pos = np.zeros(n, np.int32), np.zeros(n, np.int64), [], 0, 0
     for i in range(n):
         K, L, M, N = (int(shard[k][i]) for k in ("K", "L", "M", "N"))
         a0, b0, d0 = int(shard["offA"][i]), int(shard["offB"][i]), int(shard["offBand"][i])
         r = mo.yama(shard["poolA"][a0:a0 + K * M].reshape(M, K), shard["poolB"][b0:b0 + L * N].reshape(N, L),
                     shard["poolLB"][d0:d0 + M + 1], shard["poolRB"][d0:d0 + M + 1], variant="profile")
-        om[i] = r.OM
-        chunks.append(r.cols.ravel())
+        om[i], off[i] = r.OM, pos
+        pad = (-r.cols.size) % 16 + 16                       # the device pads its slices; the gather must not care
+        chunks += [r.cols.ravel(), np.full(pad, 0xEE, np.uint8)]
+        pos += r.cols.size + pad
         cells += mo.band_cells(shard["poolLB"][d0:d0 + M + 1], shard["poolRB"][d0:d0 + M + 1])
-    return om, (np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)), cells, 0
+    out = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    return dict(om=torch.from_numpy(om), status=torch.zeros(n, dtype=torch.int32), off=torch.from_numpy(off),
+                out=torch.from_numpy(out), cells=cells, failed=0)
 
 
 def _worker(rank, world, port, n, q):
@@ -50,12 +59,12 @@ def _worker(rank, world, port, n, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         batch, pairs = _batch(11, n) if rank == 0 else (None, None)
-        om, out, totals = shard.run_sharded(batch, _oracle_compute)
+        sh, totals = shard.run_sharded(batch, _oracle_compute)
         if rank == 0:
-            ok = True
-            for (A, B, LB, RB), m, o in zip(pairs, om, out):
+            ok = bool((sh.status == 0).all()) and sorted(set(sh.owner.tolist())) == list(range(min(world, n)))
+            for i, (A, B, LB, RB) in enumerate(pairs):
                 want = mo.yama(A, B, LB, RB)
-                ok &= int(m) == want.OM and np.array_equal(o, want.cols.ravel())
+                ok &= int(sh.om[i]) == want.OM and np.array_equal(sh.cols(i), want.cols.ravel())
             cells = sum(mo.band_cells(p[2], p[3]) for p in pairs)
             q.put((ok, totals, (n, cells, 0)))
     finally:
@@ -76,7 +85,15 @@ def test_scatter_compute_gather(world, n):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, totals, want = q.get(timeout=180)
+    import queue as _q
+    for _ in range(180):
+        try:
+            ok, totals, want = q.get(timeout=1)
+            break
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died"
+    else:
+        raise AssertionError("timed out")
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -91,8 +108,22 @@ def test_partition_is_balanced_and_complete():
     for world in (1, 2, 8):
         parts = shard.partition(cost, world)
         assert sorted(np.concatenate(parts).tolist()) == list(range(1000))
+        assert all((np.diff(p) > 0).all() for p in parts)       # ascending within a rank
         loads = np.array([cost[p].sum() for p in parts])
-        assert loads.max() - loads.min() <= cost.max()          # LPT bound
-    batch, _ = _batch(3, 12)
+        assert loads.max() - loads.min() <= cost.max()          # the snake deal's bound (as for LPT)
+    # a million pairs are dealt out without a per-pair loop: well under a second
+    import time
+    big = rng.integers(10**4, 10**5, size=1_000_000)
+    t = time.perf_counter()
+    parts = shard.partition(big, 8)
+    assert time.perf_counter() - t < 2.0
+    loads = np.array([big[p].sum() for p in parts])
+    assert (loads.max() - loads.min()) / loads.mean() < 1e-4
+    batch, pairs = _batch(3, 12)
     sub = shard.take(batch, np.array([7, 2, 9]))
     assert np.array_equal(shard.pair_cost(sub), shard.pair_cost(batch)[[7, 2, 9]])
+    from multiz_amd import synth
+    for j, i in enumerate((7, 2, 9)):                            # the re-packed pairs are the originals, byte for byte
+        for x, y in zip(synth.pair_of(sub, j), pairs[i]):
+            assert np.array_equal(x, y)
+    assert len(shard.take(batch, np.zeros(0, np.int64))["poolA"]) == 0

@@ -1,12 +1,18 @@
-// per-instruction VALU throughput on MI355X: 8 waves/SIMD, 8 independent chains, inline asm
+// per-instruction VALU throughput on MI355X: 1 / 2 / 8 waves per SIMD, 8 independent chains, inline asm.
+// Each line: wall time per wave-instruction per SIMD (HIP events), the in-kernel shader clock over the run
+// (s_memtime ticks / s_memrealtime ticks x 100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6) and hence
+// SHADER CYCLES per wave-instruction per SIMD -- the unit DESIGN.md's VALU-issue roofline is priced in.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP8(X) X(a,b,c) X(b,c,d) X(c,d,e) X(d,e,f) X(e,f,g) X(f,g,h) X(g,h,a) X(h,a,b)
 #define DEFK(NAME, ASM) \
-__global__ __launch_bounds__(64) void k_##NAME(int *out, int iters) { \
+__global__ __launch_bounds__(64) void k_##NAME(int *out, int iters, unsigned long long *clk) { \
     int a = threadIdx.x, b = a * 3 + 1, c = a ^ 5, d = a + 7, e = 1, f = 2, g = 3, h = 4; \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
     for (int i = 0; i < iters; ++i) { \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) { REP8(ASM) } } \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; } \
     out[blockIdx.x * 64 + threadIdx.x] = a + b + c + d + e + f + g + h; }
 #define A_ADD(x,y,z)  asm volatile("v_add_u32 %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
 #define A_SUB(x,y,z)  asm volatile("v_sub_u32 %0, %1, %2" : "+v"(x) : "v"(y), "v"(z));
@@ -46,20 +52,24 @@ LIST(MK)
 template <typename K> void run(const char *name, K kern, int blocks, int iters)
 {
     int *out; hipMalloc(&out, blocks * 64 * 4);
+    unsigned long long *clk, hclk[2]; hipMalloc(&clk, 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, 10); hipDeviceSynchronize();
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, 10, clk); hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, iters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, iters, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
     double instr = (double)iters * 64 * (blocks / 1024.0);     // wave-instructions per SIMD
-    printf("%-9s %5.1f w/SIMD: %7.3f ns per wave-instr per SIMD\n", name, blocks / 1024.0, ms * 1e6 / instr);
-    hipFree(out);
+    double ghz = hclk[1] ? (double)hclk[0] / (double)hclk[1] * 0.1 : 0.0;
+    printf("%-9s %5.1f w/SIMD: %7.3f ns per wave-instr per SIMD, shader clock %.2f GHz -> %.2f cycles per wave-instr\n",
+           name, blocks / 1024.0, ms * 1e6 / instr, ghz, ms * 1e6 / instr * ghz);
+    hipFree(out); hipFree(clk);
 }
 int main()
 {
     for (int blocks : {1024, 2048, 8192}) {
-#define RUN(N) run(#N, k_##N, blocks, 4000);
+#define RUN(N) run(#N, k_##N, blocks, 20000);
         LIST(RUN)
         printf("\n");
     }
