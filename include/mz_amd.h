@@ -97,7 +97,7 @@ typedef struct mz_dev_batch {
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare,
-                              [8] pairs of more than 127 rows, [9] their work counter; 32 entries in all */
+                              [8] pairs of more than 127 rows, [9] their work counter, [10] the batch chase's pair counter; 32 entries in all */
     int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */

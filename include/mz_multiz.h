@@ -19,6 +19,16 @@ struct mafAli *mz_maf_read_all(const char *path, int verbose);
 int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
                     FILE *out, FILE *out1, FILE *out2);
 
+/* The same run in three steps, so that several independent runs -- the merges at sibling nodes of a guide tree --
+ * share their GPU batches: prepare() walks the lists and records events and merges (has_out1/2: whether unused
+ * parts are wanted), align() runs the pending merges of ALL given runs as one batch per wave, finish() replays a
+ * run into its sinks and frees it. */
+struct mz_mzrun;
+struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
+                                   int has_out1, int has_out2);
+void mz_multiz_align(struct mz_mzrun **runs, int n);
+void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2);
+
 /* the multiz command line: [R=?] [M=?] file1 file2 v [out1 out2] [nohead] [all] */
 int mz_multiz_main(int argc, char **argv);
 
@@ -27,5 +37,12 @@ int mz_multiz_main(int argc, char **argv);
  * with no species in common is merged over its overlap (all of them enumerated first and aligned as GPU batches),
  * then the stretches no merge used are printed.  Output is byte-identical to the stock binary's. */
 int mz_multic_main(int argc, char **argv);
+
+/* The reference-guided tree driver in one process (reference auto_mz.c "roast", speciesTree.c, and the
+ * maf_project / multiz / multic chain it spawns), same command line:
+ *     [+-] [R=?] [M=?] [P=?] [T=?] [X=?] [C=?] E=reference-species species-guid-tree maf-source... destination
+ * No temporary files, no child processes, one GPU start-up; the merges of sibling subtrees share GPU batches.
+ * The destination holds, block for block, what the stock roast writes. */
+int mz_roast_main(int argc, char **argv);
 
 #endif

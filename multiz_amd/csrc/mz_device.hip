@@ -250,7 +250,11 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     if (force ? force == 1 : (!beside_dp || count <= 16384))
         hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     else
-        hipLaunchKernelGGL(k_walk, dim3((count + WALK_LANES - 1) / WALK_LANES), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    {
+        const int waves = (count + WALK_LANES - 1) / WALK_LANES;
+        CK(hipMemsetAsync(&b->totals[10], 0, sizeof(int64_t), (hipStream_t)stream), "walk counter");      // the chase's pair counter
+        hipLaunchKernelGGL(k_walk, dim3(waves < WALK_GRID ? waves : WALK_GRID), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    }
     CK(hipGetLastError(), "walk launch");
     return 0;
 }

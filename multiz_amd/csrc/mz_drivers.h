@@ -27,6 +27,13 @@ extern char *argv0;
 static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 /* mz_mafio.c */
+struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE *echo);
+struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name);
+/* mz_project.c */
+struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others);
+/* mz_multic.c */
+int mz_multic_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int minw, int cate,
+                    FILE *out, FILE *out1, FILE *out2);
 void *mz_xmalloc(size_t n);
 char *mz_xstrdup(const char *s);
 struct mafAli *mz_pop_first(struct mafAli **head);

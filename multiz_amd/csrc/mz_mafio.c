@@ -22,7 +22,7 @@ void mz_tune_malloc(void)
 
 /* ------------------------------------------------------------------------------------------------ MAF reader */
 
-typedef struct { FILE *fp; const char *name; int line_nbr, verbose; char *line; size_t cap; } maf_in;
+typedef struct { FILE *fp; const char *name; int line_nbr, verbose; char *line; size_t cap; FILE *echo; } maf_in;
 
 /* one line, newline kept; -1 at end of file */
 static long in_line(maf_in *in)
@@ -44,7 +44,7 @@ static long in_maf_line(maf_in *in)
     while ((n = in_line(in)) > 1) {
         in->line_nbr++;
         if (in->line[0] != '#') break;
-        if (in->verbose && strstr(in->line, "eof") == NULL) fputs(in->line, stdout);
+        if (in->verbose && strstr(in->line, "eof") == NULL) fputs(in->line, in->echo ? in->echo : stdout);
     }
     return n;
 }
@@ -137,7 +137,8 @@ static struct mafAli *maf_next(maf_in *in)
     return a;
 }
 
-struct mafAli *mz_maf_read_all(const char *path, int verbose)
+/* every block of an open MAF stream (header line first), in order; comment lines go to `echo` when verbose */
+struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE *echo)
 {
     maf_in in;
     struct mafAli *first = NULL, *last = NULL, *a;
@@ -145,18 +146,38 @@ struct mafAli *mz_maf_read_all(const char *path, int verbose)
     int version;
 
     memset(&in, 0, sizeof in);
-    in.name = path; in.verbose = verbose;
-    in.fp = fopen(path, "r");
-    if (!in.fp) mz_fatalf("Cannot open %s.", path);
-    if (!fgets(buf, sizeof buf, in.fp)) mz_fatalf("empty file %s", path);
+    in.name = name; in.verbose = verbose; in.fp = fp; in.echo = echo;
+    if (!fgets(buf, sizeof buf, in.fp)) mz_fatalf("empty file %s", name);
     if (sscanf(buf, "##maf version=%d", &version) != 1) mz_fatalf("improper maf header line: %s", buf);
     while ((a = maf_next(&in)) != NULL) {
         if (last) last->next = a; else first = a;
         last = a;
     }
-    fclose(in.fp);
     free(in.line);
     return first;
+}
+
+struct mafAli *mz_maf_read_all(const char *path, int verbose)
+{
+    struct mafAli *list;
+    FILE *fp = fopen(path, "r");
+    if (!fp) mz_fatalf("Cannot open %s.", path);
+    list = mz_maf_read_stream(fp, path, verbose, NULL);
+    fclose(fp);
+    return list;
+}
+
+/* the same over MAF text in memory (the in-process tree driver hands blocks from one program to the next this way) */
+struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name)
+{
+    struct mafAli *list;
+    FILE *fp;
+    if (len == 0) mz_fatalf("empty file %s", name);
+    fp = fmemopen((void *)text, len, "r");
+    if (!fp) mz_fatalf("Cannot open %s.", name);
+    list = mz_maf_read_stream(fp, name, 0, NULL);
+    fclose(fp);
+    return list;
 }
 
 /* ------------------------------------------------------------------------------------------------ list helpers */

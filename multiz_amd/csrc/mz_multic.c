@@ -194,15 +194,94 @@ static void print_unused_multic(cnode *x, FILE *f)             /* multic.c:228-2
     }
 }
 
+/* The multic run itself on two parsed lists (reference multic.c main loop + multih()): merged blocks to `out`,
+ * unused stretches to out1 / out2 (NULL: dropped); blocks of contigs present in one list only stay in *list1 /
+ * *list2.  `cate` is the s= option.  The command line below and the in-process tree driver (mz_roast.c) call it. */
+int mz_multic_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int minw, int cate,
+                    FILE *out, FILE *out1, FILE *out2)
+{
+    FILE *fpw[2] = { out1, out2 };
+    crecord R;
+    int i, k, x, stop = 0;
+    double tm[4];
+    align_cate = cate;
+    tm[1] = mz_now_s();
+    memset(&R, 0, sizeof R);
+    while (*list1 && *list2) {                                      /* one reference contig at a time, in file-1 order */
+        struct mafAli *wk1 = NULL, *wk2 = NULL;
+        char *chr = mz_xstrdup((*list1)->components->src);
+        ccontig *C;
+        mz_take_chr(list1, &wk1, chr);
+        mz_take_chr(list2, &wk2, chr);
+        free(chr);
+        if (R.nct == R.capct) { R.capct = R.capct ? 2 * R.capct : 16; R.ct = (ccontig *)realloc(R.ct, (size_t)R.capct * sizeof(ccontig)); if (!R.ct) mz_fatalf("out of memory"); }
+        C = &R.ct[R.nct++];
+        memset(C, 0, sizeof *C);
+        C->A = cnode_list(wk1, &C->na);
+        C->B = cnode_list(wk2, &C->nb);
+        C->m0 = R.nmg;
+        if (!stop && C->A && C->B) enumerate_multic(&R, C, v);
+        C->m1 = R.nmg;
+        if (C->fatal) stop = 1;                             /* the stock program ends there: nothing later is aligned */
+    }
+    /* (the merges point into the cnode arrays, which do not move; R.mg may have: pointers into it are taken below) */
+    tm[2] = mz_now_s();
+    run_multic(&R, radius, v, minw);
+    tm[3] = mz_now_s();
+
+    for (k = 0; k < R.nct; ++k) {
+        ccontig *C = &R.ct[k];
+        for (i = C->m0; i < C->m1; ++i) {
+            cmerge *g = &R.mg[i];
+            if (g->state == MERGE_FAILED) {
+                fflush(out); if (fpw[0]) fflush(fpw[0]); if (fpw[1]) fflush(fpw[1]);
+                mz_fatal_status(&g->bad_job, &g->bad_out);
+            }
+            if (!g->have) continue;
+            if (g->text) { if (g->len) fwrite(g->text, 1, g->len, out); free(g->text); }
+            mark_used(g->a, g->rbeg, g->rend);
+            mark_used(g->b, g->rbeg, g->rend);
+        }
+        if (C->fatal) mz_fatalf("%s", C->fatal);
+        for (x = 0; x < 2; ++x) {                           /* the unused stretches: rendered one block per thread ... */
+            cnode *list = x ? C->B : C->A;
+            const int n = x ? C->nb : C->na;
+            if (!fpw[x]) continue;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
+            for (i = 0; i < n; ++i)
+                if (list[i].ali->textSize >= minw) {
+                    FILE *m = open_memstream(&list[i].text, &list[i].len);
+                    print_unused_multic(&list[i], m);
+                    fclose(m);
+                }
+        }
+        for (x = 0; x < 2; ++x) {                           /* ... and written in order */
+            cnode *list = x ? C->B : C->A;
+            const int n = x ? C->nb : C->na;
+            for (i = 0; i < n; ++i) {
+                if (list[i].text) { if (list[i].len) fwrite(list[i].text, 1, list[i].len, fpw[x]); free(list[i].text); }
+                mafAliFree(&list[i].ali);
+                free(list[i].unused);
+            }
+            free(list);
+        }
+    }
+    if (getenv("MZ_TIMING"))
+        fprintf(stderr, "mz_multic: enumerate %.3f s (%d merges), stages + yama batches %.3f s, replay + unused parts %.3f s\n",
+                tm[2] - tm[1], R.nmg, tm[3] - tm[2], mz_now_s() - tm[3]);
+    free(R.mg); free(R.ct);
+
+    return 0;
+}
+
 int mz_multic_main(int argc, char **argv)
 {
     static char cmd[64];
     char *args;
     struct mafAli *l1, *l2, *a;
     FILE *fpw[2];
-    crecord R;
-    int radius = 30, minw = 1, nohead = 0, v, i, k, x, stop = 0;
-    double tm[4];
+    int radius = 30, minw = 1, nohead = 0, v, i, x;
+    double tm[2];
     size_t na = 64;
     const char *usage =
         "args: [R=?] [M=?] [C=?] file1 file2 v? [out1 out2] [nohead] [all]\n"
@@ -244,72 +323,9 @@ int mz_multic_main(int argc, char **argv)
     l1 = mz_maf_read_all(argv[1], 1);
     l2 = mz_maf_read_all(argv[2], 1);
     tm[1] = mz_now_s();
+    if (getenv("MZ_TIMING")) fprintf(stderr, "mz_multic: read %.3f s\n", tm[1] - tm[0]);
 
-    memset(&R, 0, sizeof R);
-    while (l1 && l2) {                                      /* one reference contig at a time, in file-1 order */
-        struct mafAli *wk1 = NULL, *wk2 = NULL;
-        char *chr = mz_xstrdup(l1->components->src);
-        ccontig *C;
-        mz_take_chr(&l1, &wk1, chr);
-        mz_take_chr(&l2, &wk2, chr);
-        free(chr);
-        if (R.nct == R.capct) { R.capct = R.capct ? 2 * R.capct : 16; R.ct = (ccontig *)realloc(R.ct, (size_t)R.capct * sizeof(ccontig)); if (!R.ct) mz_fatalf("out of memory"); }
-        C = &R.ct[R.nct++];
-        memset(C, 0, sizeof *C);
-        C->A = cnode_list(wk1, &C->na);
-        C->B = cnode_list(wk2, &C->nb);
-        C->m0 = R.nmg;
-        if (!stop && C->A && C->B) enumerate_multic(&R, C, v);
-        C->m1 = R.nmg;
-        if (C->fatal) stop = 1;                             /* the stock program ends there: nothing later is aligned */
-    }
-    /* (the merges point into the cnode arrays, which do not move; R.mg may have: pointers into it are taken below) */
-    tm[2] = mz_now_s();
-    run_multic(&R, radius, v, minw);
-    tm[3] = mz_now_s();
-
-    for (k = 0; k < R.nct; ++k) {
-        ccontig *C = &R.ct[k];
-        for (i = C->m0; i < C->m1; ++i) {
-            cmerge *g = &R.mg[i];
-            if (g->state == MERGE_FAILED) {
-                fflush(stdout); if (fpw[0]) fflush(fpw[0]); if (fpw[1]) fflush(fpw[1]);
-                mz_fatal_status(&g->bad_job, &g->bad_out);
-            }
-            if (!g->have) continue;
-            if (g->text) { if (g->len) fwrite(g->text, 1, g->len, stdout); free(g->text); }
-            mark_used(g->a, g->rbeg, g->rend);
-            mark_used(g->b, g->rbeg, g->rend);
-        }
-        if (C->fatal) mz_fatalf("%s", C->fatal);
-        for (x = 0; x < 2; ++x) {                           /* the unused stretches: rendered one block per thread ... */
-            cnode *list = x ? C->B : C->A;
-            const int n = x ? C->nb : C->na;
-            if (!fpw[x]) continue;
-#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
-            for (i = 0; i < n; ++i)
-                if (list[i].ali->textSize >= minw) {
-                    FILE *m = open_memstream(&list[i].text, &list[i].len);
-                    print_unused_multic(&list[i], m);
-                    fclose(m);
-                }
-        }
-        for (x = 0; x < 2; ++x) {                           /* ... and written in order */
-            cnode *list = x ? C->B : C->A;
-            const int n = x ? C->nb : C->na;
-            for (i = 0; i < n; ++i) {
-                if (list[i].text) { if (list[i].len) fwrite(list[i].text, 1, list[i].len, fpw[x]); free(list[i].text); }
-                mafAliFree(&list[i].ali);
-                free(list[i].unused);
-            }
-            free(list);
-        }
-    }
-    if (getenv("MZ_TIMING"))
-        fprintf(stderr, "mz_multic: read %.3f s, enumerate %.3f s (%d merges), stages + yama batches %.3f s, replay + unused parts %.3f s\n",
-                tm[1] - tm[0], tm[2] - tm[1], R.nmg, tm[3] - tm[2], mz_now_s() - tm[3]);
-    free(R.mg); free(R.ct);
-
+    mz_multic_lists(&l1, &l2, v, radius, minw, align_cate, stdout, fpw[0], fpw[1]);
     for (a = l1; a; a = a->next)                            /* contigs that only one file has */
         if (fpw[0] && (row2 == 0 || a->components->next != NULL)) mafWrite(fpw[0], a);
     for (a = l2; a; a = a->next)

@@ -44,8 +44,11 @@ static char *arena_strdup(const char *s)
     n = strlen(s) + 1;
     return (char *)memcpy(arena_alloc(n), s, n);
 }
+static int g_arena_users;                 /* records alive: several runs may be pending at once (the tree driver) */
 static void arena_release(void)
 {
+    if (--g_arena_users > 0) return;
+    g_arena_users = 0;
     while (g_arena) { arena_chunk *c = g_arena; g_arena = c->next; free(c); }
 }
 
@@ -249,32 +252,45 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
 /* Stage 1 of every merge, then the pending yama() calls of all of them wave after wave.  The merges are
  * independent of one another, so everything on the host side of the yama() batches -- column packing,
  * rmColDash, the band walk and smooth() before, mafBuild() and mafScoreRange() after -- runs one merge per
- * thread. */
-static void run_merges(record *R, int minw)
+ * thread.  Several RECORDS may be given: the merges of independent multiz runs (sibling nodes of a guide tree,
+ * mz_roast.c) then share the same GPU batches. */
+typedef struct { record *R; int i; } mref;
+
+static void run_merges(record **RR, int nrec, int minw)
 {
-    mz_job *jobs = (mz_job *)mz_xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(mz_job));
-    mz_out *outs = (mz_out *)mz_xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(mz_out));
-    int *who = (int *)mz_xmalloc((size_t)(R->nmg ? R->nmg : 1) * sizeof(int));
-    const int nmg = R->nmg, has2 = R->has2;
+    int nmg = 0, i, r;
+    mz_job *jobs;
+    mz_out *outs;
+    int *who;
+    mref *all;
     const int timing = getenv("MZ_TIMING") != NULL;
     double t0 = mz_now_s(), t1;
-    int i;
+    for (r = 0; r < nrec; ++r) nmg += RR[r]->nmg;
+    jobs = (mz_job *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mz_job));
+    outs = (mz_out *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mz_out));
+    who = (int *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(int));
+    all = (mref *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mref));
+    for (r = 0, nmg = 0; r < nrec; ++r)
+        for (i = 0; i < RR[r]->nmg; ++i) { all[nmg].R = RR[r]; all[nmg++].i = i; }
     mz_score_profile_sync();
-    render_events(R);
+    for (r = 0; r < nrec; ++r) render_events(RR[r]);
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)
     for (i = 0; i < nmg; ++i) {
-        merge *g = &R->mg[i];
+        record *R = all[i].R;
+        merge *g = &R->mg[all[i].i];
         event *e = &R->ev[g->side_ev];
         FILE *m = open_memstream(&e->text, &e->len);
-        g->state = mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, has2 ? m : NULL);
+        g->state = mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, R->has2 ? m : NULL);
         fclose(m);
     }
     t1 = mz_now_s();
-    if (timing) fprintf(stderr, "mz_multiz: stage 1 of %d merges %.3f s\n", nmg, t1 - t0);
+    if (timing) fprintf(stderr, "mz_multiz: stage 1 of %d merges (%d run%s) %.3f s\n", nmg, nrec, nrec == 1 ? "" : "s", t1 - t0);
     for (;;) {
         int n = 0, rc;
-        for (i = 0; i < nmg; ++i)
-            if (R->mg[i].state == MZ_PY_JOB) { jobs[n] = R->mg[i].py.job; who[n++] = i; }
+        for (i = 0; i < nmg; ++i) {
+            merge *g = &all[i].R->mg[all[i].i];
+            if (g->state == MZ_PY_JOB) { jobs[n] = g->py.job; who[n++] = i; }
+        }
         if (n == 0) break;
         t0 = mz_now_s();
         rc = mz_yama_batch(n, jobs, outs);
@@ -282,7 +298,7 @@ static void run_merges(record *R, int minw)
         t1 = mz_now_s();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
         for (i = 0; i < n; ++i) {
-            merge *g = &R->mg[who[i]];
+            merge *g = &all[who[i]].R->mg[all[who[i]].i];
             if (outs[i].status != MZ_OK) {                  /* reported at its place in the output order, see replay() */
                 g->state = MERGE_FAILED; g->bad_job = jobs[i]; g->bad_out = outs[i];
             } else
@@ -299,7 +315,7 @@ static void run_merges(record *R, int minw)
         }
         if (timing) fprintf(stderr, "mz_multiz: yama batch of %d %.3f s (with GPU start-up in the first), next stage %.3f s\n", n, t1 - t0, mz_now_s() - t1);
     }
-    free(jobs); free(outs); free(who);
+    free(jobs); free(outs); free(who); free(all);
 }
 
 static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
@@ -327,30 +343,60 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
     arena_release();
 }
 
-int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
-                    FILE *out, FILE *out1, FILE *out2)
+/* A multiz run in three steps, so that several independent runs can share their GPU batches:
+ *   mz_multiz_prepare()  walks the two lists (reference multiz.c:60-177) and records the output events and merges;
+ *   mz_multiz_align()    runs every pending merge of the given runs: stage 1 on the host threads, the yama() calls
+ *                        of ALL runs as one mz_yama_batch() per wave, stages 2/3;
+ *   mz_multiz_finish()   replays the record of a run into its sinks, in the stock driver's order, and frees it. */
+struct mz_mzrun { record R; int minw; };
+
+struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
+                                   int has_out1, int has_out2)
 {
-    record R;
-    memset(&R, 0, sizeof R);
-    R.has1 = out1 != NULL; R.has2 = out2 != NULL;
+    struct mz_mzrun *run = (struct mz_mzrun *)mz_xmalloc(sizeof *run);
+    memset(run, 0, sizeof *run);
+    run->minw = min_output_wid;
+    run->R.has1 = has_out1; run->R.has2 = has_out2;
+    ++g_arena_users;
     while (*list1 && *list2) {                              /* one reference contig at a time, in file-1 order */
         struct mafAli *wk1 = NULL, *wk2 = NULL;
         char *chr = mz_xstrdup((*list1)->components->src);
         mz_take_chr(list1, &wk1, chr);
         mz_take_chr(list2, &wk2, chr);
         free(chr);
-        walk(&R, &wk1, &wk2, v, radius, min_output_wid);
+        walk(&run->R, &wk1, &wk2, v, radius, min_output_wid);
     }
-    {
-        const int timing = getenv("MZ_TIMING") != NULL, nmerge = R.nmg;
-        const double t0 = mz_now_s();
-        double t1, t2;
-        run_merges(&R, min_output_wid);
-        t1 = mz_now_s();
-        replay(&R, out, out1, out2, min_output_wid);
-        t2 = mz_now_s();
-        if (timing) fprintf(stderr, "mz_multiz: %d merges; yama batches + stage 2/3 %.3f s, replay %.3f s\n", nmerge, t1 - t0, t2 - t1);
-    }
+    return run;
+}
+
+void mz_multiz_align(struct mz_mzrun **runs, int n)
+{
+    record **RR = (record **)mz_xmalloc((size_t)(n ? n : 1) * sizeof *RR);
+    int i;
+    for (i = 0; i < n; ++i) RR[i] = &runs[i]->R;
+    if (n > 0) run_merges(RR, n, runs[0]->minw);            /* (runs of one call share min_output_wid: one command line) */
+    free(RR);
+}
+
+void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2)
+{
+    replay(&run->R, out, out1, out2, run->minw);
+    free(run);
+}
+
+int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
+                    FILE *out, FILE *out1, FILE *out2)
+{
+    const int timing = getenv("MZ_TIMING") != NULL;
+    const double t0 = mz_now_s();
+    double t1, t2;
+    struct mz_mzrun *run = mz_multiz_prepare(list1, list2, v, radius, min_output_wid, out1 != NULL, out2 != NULL);
+    const int nmerge = run->R.nmg;
+    mz_multiz_align(&run, 1);
+    t1 = mz_now_s();
+    mz_multiz_finish(run, out, out1, out2);
+    t2 = mz_now_s();
+    if (timing) fprintf(stderr, "mz_multiz: %d merges; walk + yama batches + stage 2/3 %.3f s, replay %.3f s\n", nmerge, t1 - t0, t2 - t1);
     return 0;
 }
 

@@ -1,0 +1,203 @@
+/* mz_project.c -- projecting a list of blocks onto a reference species, as the tree driver needs it between
+ * merges.
+ *
+ * The stock roast (reference auto_mz.c:84-85,276) runs `maf_project file REF others > out` around every multiz
+ * call: blocks that have a row of the reference get that row on top (reverse-complemented when it lies on the
+ * minus strand), are ordered by their start in the reference contig by contig, and neighbours that continue one
+ * another exactly in every row are fused (reference maf_project.c:61-84 abut, :86-173 accordion + fuse, :616-719
+ * main).  That four-argument form is what is restated here; the "beautify" pass of the stand-alone tool (used only
+ * when no file for the other blocks is named, maf_project.c:367-481) and its from/to and tree arguments are not.
+ */
+#include "mz_drivers.h"
+
+/* complement of a nucleotide code, case kept; anything that is not a code becomes a blank (the table of
+ * reference multi_util.c:34-38) */
+static unsigned char g_compl[256];
+static void compl_init(void)
+{
+    static const char pairs[] = "ATCGBVDHKMRYSSWWXXNN";
+    int i;
+    if (g_compl['A']) return;
+    memset(g_compl, ' ', sizeof g_compl);
+    g_compl['-'] = '-';
+    for (i = 0; pairs[i]; i += 2) {
+        const int a = pairs[i], b = pairs[i + 1];
+        g_compl[a] = (unsigned char)b; g_compl[b] = (unsigned char)a;
+        g_compl[a | 0x20] = (unsigned char)(b | 0x20); g_compl[b | 0x20] = (unsigned char)(a | 0x20);
+    }
+}
+
+/* every row of the block onto the other strand (reference multi_util.c:44-67) */
+static void block_revcomp(struct mafAli *a)
+{
+    struct mafComp *c;
+    compl_init();
+    for (c = a->components; c; c = c->next) {
+        char *s = c->text, *p = c->text + a->textSize - 1;
+        c->start = c->srcSize - (c->start + c->size);
+        c->strand = c->strand == '-' ? '+' : '-';
+        while (s <= p) {
+            const char t = (char)g_compl[(unsigned char)*s];
+            *s = (char)g_compl[(unsigned char)*p];
+            *p = t;
+            ++s; --p;
+        }
+    }
+}
+
+static struct mafComp *row_of(struct mafAli *a, const char *src)
+{
+    struct mafComp *c;
+    for (c = a->components; c; c = c->next)
+        if (strcmp(c->src, src) == 0) return c;
+    return NULL;
+}
+
+/* b continues a exactly: the same sources in both, every row of b starting where its row of a ends
+ * (reference maf_project.c:61-84) */
+static int continues(struct mafAli *a, struct mafAli *b)
+{
+    struct mafComp *c, *d;
+    for (c = a->components; c; c = c->next) {
+        d = row_of(b, c->src);
+        if (!d || d->paralog != c->paralog || c->strand != d->strand || c->start + c->size != d->start) return 0;
+    }
+    for (c = b->components; c; c = c->next) {
+        d = row_of(a, c->src);
+        if (!d || d->paralog != c->paralog || c->strand != d->strand || d->start + d->size != c->start) return 0;
+    }
+    return 1;
+}
+
+/* after a fusion at column n1: if every row has dashes next to the seam, the narrowest such run is squeezed out
+ * (reference maf_project.c:86-111) */
+static void close_seam(struct mafAli *a, int n1)
+{
+    const int n = a->textSize;
+    struct mafComp *c;
+    int i, room = n;
+    for (c = a->components; c; c = c->next) {
+        int sp = 0;
+        for (i = n1 - 1; i >= 0 && c->text[i] == '-'; --i) ++sp;
+        for (i = n1; i < n && c->text[i] == '-'; ++i) ++sp;
+        if (sp < room) room = sp;
+    }
+    if (room <= 0) return;
+    for (c = a->components; c; c = c->next) {
+        for (i = n1; i > 0 && c->text[i - 1] == '-'; --i)
+            ;
+        for (; i + room <= n; ++i) c->text[i] = c->text[i + room];      /* (the terminating 0 moves too) */
+    }
+    a->textSize -= room;
+}
+
+/* b appended to a (reference maf_project.c:114-173); b is left untouched and still owned by the caller */
+static void append_block(struct mafAli *a, struct mafAli *b)
+{
+    const int n1 = a->textSize, n2 = b->textSize, n = n1 + n2;
+    struct mafComp *c, *d, *extra = NULL, *x;
+    a->textSize = n;
+    for (c = a->components; c; c = c->next) {
+        char *t = (char *)mz_xmalloc((size_t)n + 1);
+        memcpy(t, c->text, (size_t)n1);
+        t[n] = 0;
+        d = row_of(b, c->src);
+        if (d) {
+            if (d->strand != c->strand || d->start != c->start + c->size) mz_fatalf("possible use of unprojected alignment");
+            memcpy(t + n1, d->text, (size_t)n2);
+            c->size += d->size;
+        } else memset(t + n1, '-', (size_t)n2);
+        free(c->text);
+        c->text = t;
+    }
+    for (d = b->components; d; d = d->next)              /* rows only b has: dashes on the left, collected in reverse */
+        if (!row_of(a, d->src)) {
+            x = mafCpyComp(d);
+            x->text = (char *)mz_xmalloc((size_t)n + 1);
+            memset(x->text, '-', (size_t)n1);
+            memcpy(x->text + n1, d->text, (size_t)n2);
+            x->text[n] = 0;
+            x->next = extra;
+            extra = x;
+        }
+    for (c = a->components; c->next; c = c->next)
+        ;
+    c->next = extra;
+    close_seam(a, n1);
+    a->score = mafScoreRange(a, 0, a->textSize);
+}
+
+static int by_top_start(const void *x, const void *y)
+{
+    return (*(struct mafAli *const *)x)->components->start - (*(struct mafAli *const *)y)->components->start;
+}
+
+static void fuse_neighbours(struct mafAli *list)
+{
+    struct mafAli *a, *b;
+    for (a = list; (b = a->next) != NULL; )
+        if (continues(a, b)) {
+            append_block(a, b);
+            a->next = b->next;
+            b->next = NULL;
+            mafAliFree(&b);
+        } else a = b;
+}
+
+/* Project `all` (blocks in file order; consumed) onto `target` (a species name or a full source name).  Returns
+ * the projected blocks in output order; blocks without a row of the target go to *others in file order (freed
+ * when others == NULL). */
+struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others)
+{
+    struct mafAli *A = NULL, *out = NULL, *out_tail = NULL, *oth_tail = NULL, *a, *next;
+    if (others) *others = NULL;
+    for (a = all; a; a = next) {
+        struct mafComp *c, *b;
+        next = a->next;
+        a->next = NULL;
+        for (c = a->components; c; c = c->next)
+            if (strcmp(c->name, target) == 0 || strcmp(c->src, target) == 0) break;
+        if (!c) {
+            if (others) { if (oth_tail) oth_tail->next = a; else *others = a; oth_tail = a; }
+            else mafAliFree(&a);
+            continue;
+        }
+        if (c != a->components) {                        /* the target's row to the top */
+            for (b = a->components; b && b->next != c; b = b->next)
+                ;
+            if (!b) mz_fatalf("maf_project: cannot happen");
+            b->next = c->next;
+            c->next = a->components;
+            a->components = c;
+        }
+        if (c->strand == '-') block_revcomp(a);
+        a->next = A;                                     /* (the stock tool collects them back to front) */
+        A = a;
+    }
+    init_scores70();
+    while (A) {                                          /* one reference contig at a time */
+        const char *chr = A->components->src;
+        struct mafAli *B = NULL, *prev, **arr;
+        int n = 0, i;
+        for (prev = a = A; a; a = next) {
+            next = a->next;
+            if (strcmp(chr, a->components->src) != 0) { prev->next = next; a->next = B; B = a; }
+            else prev = a;
+        }
+        for (a = A; a; a = a->next) ++n;
+        arr = (struct mafAli **)mz_xmalloc((size_t)n * sizeof *arr);
+        for (a = A, i = 0; a; a = a->next) arr[i++] = a;
+        qsort(arr, (size_t)n, sizeof *arr, by_top_start);        /* the same library sort on the same order: ties fall alike */
+        for (i = 1; i < n; ++i) arr[i - 1]->next = arr[i];
+        arr[n - 1]->next = NULL;
+        a = arr[0];
+        free(arr);
+        fuse_neighbours(a);
+        fuse_neighbours(a);                              /* (the stock tool's second pass, maf_project.c:690-695) */
+        if (out_tail) out_tail->next = a; else out = a;
+        for (out_tail = a; out_tail->next; out_tail = out_tail->next)
+            ;
+        A = B;
+    }
+    return out;
+}

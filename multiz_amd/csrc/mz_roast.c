@@ -1,0 +1,379 @@
+/* mz_roast.c -- the reference-guided tree driver in ONE process.
+ *
+ * The stock roast (reference auto_mz.c) parses the species tree (speciesTree.c:37-113) and, at every internal node,
+ * glues a pipeline of child programs together with system(): cp / mv / grep on temporary MAF files, maf_project
+ * around the inputs, multiz (or multic) for the merge (auto_mz.c:52-118).  Every multiz of that chain is a fresh
+ * process -- with the GPU aligners on its PATH, a fresh HIP start-up of 0.1-0.2 s each -- and sibling subtrees, whose
+ * merges are independent, run one after the other.
+ *
+ * Here the same chain runs inside one process on MAF text held in memory: the tree is parsed into explicit nodes with
+ * the stock driver's stack discipline and node numbering; a node's "files" are buffers; projection is
+ * mz_project_lists(), the merge is the batched driver of mz_multiz.c / mz_multic.c.  Blocks pass from step to step as
+ * MAF text exactly as they do between the stock programs (what a reader re-derives from the text -- scores printed
+ * with one decimal, sizes, the species/contig split of a source name -- is re-derived here too), but no file is
+ * written and no process started.  Nodes whose children are finished are evaluated together: their multiz runs are
+ * prepared (mz_multiz_prepare), then ALL their pending block-pair alignments go to the GPU as one batch per wave
+ * (mz_multiz_align) -- the per-tree-level batch of BASELINE config 4 -- and each run is replayed into its node.
+ *
+ * Output: the destination file, block for block what the stock roast writes (comment lines differ: the stock ones
+ * carry temp-file names with the process id).  grep -v eof / grep -v maf of the stock chain act on text lines here
+ * as well; like there, a species whose NAME contains "maf" or "eof" would lose its rows to them.
+ */
+#include "mz_drivers.h"
+#include <ctype.h>
+
+#define ROAST_VERSION 3
+#define MAX_NODES 2000
+
+typedef struct { char *p; size_t n; } buf;                 /* MAF text; p == NULL: the "file" does not exist */
+
+typedef struct rnode {
+    int id;                      /* -1 for a leaf, else the stock driver's node number (creation order) */
+    int left, right;             /* children (indices into the node table), -1 for a leaf */
+    char **names; int nnames;    /* leaf species below this node, in the stock driver's order */
+    buf mz;                      /* the node's result: the file <prefix>MZ<id> of the stock driver */
+    int done;
+    /* a multiz step in flight */
+    struct mz_mzrun *run;
+    struct mafAli *l1, *l2;
+    buf left_in, right_in;
+    int both_leaves;
+} rnode;
+
+static struct {
+    rnode nd[MAX_NODES]; int nn;
+    const char *ref, *suffix;
+    int use_multic, radius, minw, verbose, execute;
+} T;
+
+/* ------------------------------------------------------------------------------------------------ text "files" */
+
+static void buf_free(buf *b) { free(b->p); b->p = NULL; b->n = 0; }
+static void buf_append(buf *dst, const char *s, size_t n)
+{
+    dst->p = (char *)realloc(dst->p, dst->n + n + 1);
+    if (!dst->p) mz_fatalf("out of memory");
+    memcpy(dst->p + dst->n, s, n);
+    dst->n += n;
+    dst->p[dst->n] = 0;
+}
+static void buf_puts(buf *dst, const char *s) { buf_append(dst, s, strlen(s)); }
+
+/* grep -v <word> src >> dst : the lines of src that do not contain word; a missing file appends nothing */
+static void append_lines_without(buf *dst, const buf *src, const char *word)
+{
+    const char *p, *end;
+    const size_t wl = strlen(word);
+    if (!src->p) return;
+    for (p = src->p, end = src->p + src->n; p < end; ) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const size_t len = nl ? (size_t)(nl - p) + 1 : (size_t)(end - p);
+        int hit = 0;
+        size_t i;
+        for (i = 0; !hit && i + wl <= len; ++i) hit = memcmp(p + i, word, wl) == 0;
+        if (!hit) buf_append(dst, p, len);
+        p += len;
+    }
+}
+
+static buf read_file(const char *path)
+{
+    buf b = { NULL, 0 };
+    FILE *f = fopen(path, "r");
+    long n;
+    if (!f) mz_fatalf("Cannot open %s.", path);
+    fseek(f, 0, SEEK_END); n = ftell(f); fseek(f, 0, SEEK_SET);
+    b.p = (char *)mz_xmalloc((size_t)n + 1);
+    if (fread(b.p, 1, (size_t)n, f) != (size_t)n) mz_fatalf("Cannot read %s.", path);
+    b.p[n] = 0; b.n = (size_t)n;
+    fclose(f);
+    return b;
+}
+
+static buf leaf_file(const char *species)
+{
+    char path[1200];
+    snprintf(path, sizeof path, "%s.%s%s", T.ref, species, T.suffix);
+    if (T.verbose) printf("read %s\n", path);
+    return read_file(path);
+}
+
+static void free_list(struct mafAli *l) { while (l) { struct mafAli *a = mz_pop_first(&l); mafAliFree(&a); } }
+
+/* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
+static buf project_text(const buf *in, const char *what)
+{
+    buf out = { NULL, 0 };
+    struct mafAli *list, *a;
+    char *text; size_t len;
+    FILE *m;
+    if (!in->p) mz_fatalf("Cannot open %s.", what);
+    list = mz_project_lists(mz_maf_read_mem(in->p, in->n, what), T.ref, NULL);
+    m = open_memstream(&text, &len);
+    fprintf(m, "##maf version=1 scoring=maf_project.v12\n# maf_project.v12 %s %s (in process)\n", what, T.ref);
+    for (a = list; a; a = a->next) mafWrite(m, a);
+    fprintf(m, "##eof maf\n");
+    fclose(m);
+    free_list(list);
+    out.p = text; out.n = len;
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------ the tree */
+
+static int new_node(void)
+{
+    if (T.nn >= MAX_NODES) mz_fatalf("parse_tree: stack overflow");
+    memset(&T.nd[T.nn], 0, sizeof(rnode));
+    T.nd[T.nn].id = T.nd[T.nn].left = T.nd[T.nn].right = -1;
+    return T.nn++;
+}
+
+/* the stock parser's stack machine (speciesTree.c:37-113): a name pushes a leaf, ')' closes a group, and whenever two
+ * finished subtrees lie side by side on the stack they become an internal node, numbered in creation order */
+static int parse_tree(const char *spec)
+{
+    int stack[1000], top = -1, next_id = 0;        /* stack entries: node index, or -1 for '(' */
+    const char *q;
+    for (q = spec; *q; ++q) {
+        if (*q == '(') {
+            if (++top >= 1000) mz_fatalf("parse_tree: stack overflow");
+            stack[top] = -1;
+        } else if (*q == ')') {
+            if (top < 1 || stack[top] < 0 || stack[top - 1] != -1)
+                mz_fatalf("parse error: %.*s", (int)(q - spec) + 1, spec);
+            stack[top - 1] = stack[top];
+            --top;
+        } else if (isalpha((unsigned char)*q)) {
+            const char *s = q;
+            int k;
+            if (++top >= 1000) mz_fatalf("parse_tree: stack overflow");
+            while (isalpha((unsigned char)*q) || isdigit((unsigned char)*q) || *q == '_' || *q == '.') ++q;
+            k = new_node();
+            T.nd[k].names = (char **)mz_xmalloc(sizeof(char *));
+            T.nd[k].names[0] = (char *)mz_xmalloc((size_t)(q - s) + 1);
+            memcpy(T.nd[k].names[0], s, (size_t)(q - s)); T.nd[k].names[0][q - s] = 0;
+            T.nd[k].nnames = 1;
+            T.nd[k].done = 1;
+            stack[top] = k;
+            --q;
+        } else if (*q != ' ')
+            mz_fatalf("improper character in tree specification: %c", *q);
+        if (top > 0 && stack[top - 1] >= 0 && stack[top] >= 0) {
+            const int x = stack[top - 1], y = stack[top], k = new_node();
+            rnode *nd = &T.nd[k];
+            nd->left = x; nd->right = y; nd->id = next_id++;
+            nd->nnames = T.nd[x].nnames + T.nd[y].nnames;
+            nd->names = (char **)mz_xmalloc((size_t)nd->nnames * sizeof(char *));
+            memcpy(nd->names, T.nd[x].names, (size_t)T.nd[x].nnames * sizeof(char *));
+            memcpy(nd->names + T.nd[x].nnames, T.nd[y].names, (size_t)T.nd[y].nnames * sizeof(char *));
+            stack[--top] = k;
+        }
+    }
+    if (top > 0) mz_fatalf("tree specification contains too many '('");
+    if (top != 0 || stack[0] < 0) mz_fatalf("tree specification is improper");
+    return stack[0];
+}
+
+static int has_ref(const rnode *n)
+{
+    int i;
+    for (i = 0; i < n->nnames; ++i) if (strcmp(n->names[i], T.ref) == 0) return 1;
+    return 0;
+}
+static int is_single(const rnode *n, const char *name) { return n->nnames == 1 && (!name || strcmp(n->names[0], name) == 0); }
+
+/* ------------------------------------------------------------------------------------------------ one node
+ * (speciesTree.c:78-90 around mz_merge(), auto_mz.c:52-118).  begin_node() does everything up to the aligner; when
+ * that is multiz the run is left prepared (nd->run) for the shared batch, and end_node() finishes the node. */
+
+static void begin_node(rnode *nd)
+{
+    rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
+    buf left = { NULL, 0 }, right = { NULL, 0 };
+    int l, r;
+
+    if (x->id >= 0) { left = x->mz; x->mz.p = NULL; x->mz.n = 0; }          /* mv MZ<i> left.maf<id> */
+    if (y->id >= 0) { right = y->mz; y->mz.p = NULL; y->mz.n = 0; }
+    buf_free(&nd->mz);
+    { char head[64]; snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head); }
+    nd->run = NULL; nd->l1 = nd->l2 = NULL; nd->both_leaves = 0;
+    nd->left_in.p = nd->right_in.p = NULL; nd->left_in.n = nd->right_in.n = 0;
+
+    if (T.verbose) printf("node %d: %d + %d species\n", nd->id, x->nnames, y->nnames);
+    if (is_single(x, T.ref) || is_single(y, T.ref)) {
+        /* the reference itself on one side: the other side's blocks are already topped by it */
+        const int ref_left = is_single(x, T.ref);
+        rnode *other = ref_left ? y : x;
+        buf *ob = ref_left ? &right : &left;
+        if (other->nnames == 1) { buf f = leaf_file(other->names[0]); append_lines_without(&nd->mz, &f, "eof"); buf_free(&f); }
+        else append_lines_without(&nd->mz, ob, "eof");
+        buf_free(&left); buf_free(&right);               /* rm -f: the closing greps of the parser find nothing */
+        nd->done = 1;
+        return;
+    }
+    if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); }
+    if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); }
+    { buf u = project_text(&left, "left.maf"); buf_free(&left); left = u; }
+    { buf u = project_text(&right, "right.maf"); buf_free(&right); right = u; }
+    l = has_ref(x); r = has_ref(y);
+    if (!l && !r) nd->both_leaves = x->nnames == 1 && y->nnames == 1;
+    else if (r) { buf t = left; left = right; right = t; }
+    nd->left_in = left; nd->right_in = right;
+
+    nd->l1 = mz_maf_read_mem(left.p, left.n, "left.maf");
+    nd->l2 = mz_maf_read_mem(right.p, right.n, "right.maf");
+    if (!T.use_multic)
+        nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
+}
+
+static void end_node(rnode *nd)
+{
+    rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
+    const int v = (has_ref(x) || has_ref(y)) ? 1 : 0;
+    buf out = { NULL, 0 }, u1 = { NULL, 0 }, u2 = { NULL, 0 };
+    FILE *mo, *m1, *m2;
+    struct mafAli *a;
+
+    if (nd->done) return;
+    mo = open_memstream(&out.p, &out.n); m1 = open_memstream(&u1.p, &u1.n); m2 = open_memstream(&u2.p, &u2.n);
+    /* what `multiz M=.. left right v U1 U2` puts on stdout and into U1 / U2 (multiz.c:251-291) */
+    fprintf(mo, "##maf version=1 scoring=%s\n# %s (in process, node %d)\n", T.use_multic ? "multih.c" : "multiz",
+            T.use_multic ? "multic.v12.1" : "multiz.v11.2", nd->id);
+    if (T.use_multic) mz_multic_lists(&nd->l1, &nd->l2, v, T.radius, T.minw, 0, mo, m1, m2);
+    else mz_multiz_finish(nd->run, mo, m1, m2);
+    nd->run = NULL;
+    for (a = nd->l1; a; a = a->next) if (row2 == 0 || a->components->next) mafWrite(m1, a);   /* contigs only one side has */
+    for (a = nd->l2; a; a = a->next) if (row2 == 0 || a->components->next) mafWrite(m2, a);
+    free_list(nd->l1); free_list(nd->l2); nd->l1 = nd->l2 = NULL;
+    fprintf(mo, "##eof maf\n");
+    fclose(mo); fclose(m1); fclose(m2);
+
+    buf_append(&nd->mz, out.p, out.n);                   /* >> MZ<id> */
+    buf_free(&out);
+    if (nd->both_leaves) {
+        /* two leaves, neither the reference: the unused parts follow at once (grep -v -h eof U1 U2), and the parser's
+         * closing greps do not run (both children are leaves) */
+        append_lines_without(&nd->mz, &u1, "eof");
+        append_lines_without(&nd->mz, &u2, "eof");
+    } else if (x->id >= 0 || y->id >= 0) {
+        /* mv U1 left.maf; mv U2 right.maf; then the parser: grep -v maf left.maf<id> right.maf<id> >> MZ<id> */
+        append_lines_without(&nd->mz, &u1, "maf");
+        append_lines_without(&nd->mz, &u2, "maf");
+    }
+    buf_free(&u1); buf_free(&u2);
+    buf_free(&nd->left_in); buf_free(&nd->right_in);
+    nd->done = 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ command line */
+
+int mz_roast_main(int argc, char **argv)
+{
+    static char cmd[64];
+    const char *usage =
+        "args: [+-] [R=?] [M=?] [P=?] [T=?] [X=?] [C=?] E=reference-species species-guid-tree maf-source destination\n"
+        "\tR(30) dynamic programming radius.\n"
+        "\tM(1) minimum block length of output.\n"
+        "\tP(multiz) multiz: single coverage for reference row multic: no requirement on single coverage.\n"
+        "\tT(/tmp) accepted for compatibility: this driver writes no temporary files\n"
+        "\tX(0) utilize maf files with different suffix from differnt post processing.\n\t\t0: .sing.maf from single coverage pairwise alignment\n\t\t1: .toast.maf from full size toast\n\t\t2: .toast2.maf from reduced size toast\n";
+    const char *destination;
+    char *cmdline;
+    size_t na = 64;
+    int i, root, rounds = 0, batches = 0;
+    double t0 = mz_now_s();
+    FILE *dst;
+
+    snprintf(cmd, sizeof cmd, "roast.v%d", ROAST_VERSION);
+    argv0 = cmd;
+    if (argc == 4 && strcmp(argv[1], "--project") == 0) {
+        /* test hook: `--project file.maf REF` prints what `maf_project file.maf REF others` prints (no comment echo) */
+        buf in = read_file(argv[2]), out;
+        memset(&T, 0, sizeof T);
+        T.ref = argv[3];
+        out = project_text(&in, argv[2]);
+        fwrite(out.p, 1, out.n, stdout);
+        return 0;
+    }
+    if (argc < 5) mz_fatalf("roast -- reference guided multiple alignment.\n%s", usage);
+    destination = argv[argc - 1];
+    for (i = 1; i < argc; ++i) na += strlen(argv[i]) + 1;
+    cmdline = (char *)mz_xmalloc(na + 8);
+    sprintf(cmdline, "# %s", cmd);
+    for (i = 1; i < argc; ++i) { strcat(cmdline, " "); strcat(cmdline, argv[i]); }
+
+    memset(&T, 0, sizeof T);
+    T.suffix = ".sing.maf"; T.radius = 30; T.minw = 1; T.execute = 1;
+    if (argc > 1 && strcmp(argv[1], "-") == 0) { T.execute = 0; T.verbose = 1; --argc; ++argv; }
+    else if (argc > 1 && strcmp(argv[1], "+") == 0) { T.verbose = 1; --argc; ++argv; }
+    while (argc > 1 && argv[1][0] && strchr("RMEPXCT", argv[1][0]) && argv[1][1] == '=') {
+        const char *val = argv[1] + 2;
+        switch (argv[1][0]) {
+        case 'E': T.ref = val; break;
+        case 'P':
+            if (strstr("multic", val)) T.use_multic = 1;
+            else if (!strstr("multiz", val)) mz_fatalf("the optional multiple aligner can be multiz or multic only.\n%s", usage);
+            break;
+        case 'T': break;
+        case 'X': {
+            const int X = atoi(val);
+            if (X == 1) T.suffix = ".toast.maf";
+            else if (X == 2) T.suffix = ".toast2.maf";
+            else if (X != 0) mz_fatalf("Parameter X can only be 0, 1, 2, 3.\n%s", usage);
+            break; }
+        case 'C': { const int c = atoi(val); if (c < 0 || c > 100) mz_fatalf("%s\n", usage); break; }
+        case 'R': T.radius = atoi(val); if (T.radius < 0) mz_fatalf("radius cannot be negative"); break;
+        case 'M': T.minw = atoi(val); if (T.minw < 0) mz_fatalf("MIN_OUTPUT_WID cannot be negative"); break;
+        }
+        --argc; ++argv;
+    }
+    if (!T.ref) mz_fatalf("fatal -- reference is not specified.\n%s", usage);
+    if (argc < 3) mz_fatalf("roast -- reference guided multiple alignment.\n%s", usage);
+
+    mz_tune_malloc();
+    init_scores70();
+    root = parse_tree(argv[1]);
+    if (!T.execute) {                                     /* "-": show the plan */
+        for (i = 0; i < T.nn; ++i) if (T.nd[i].id >= 0)
+            printf("node %d: children %d %d, %d species\n", T.nd[i].id, T.nd[T.nd[i].left].id, T.nd[T.nd[i].right].id, T.nd[i].nnames);
+        return 0;
+    }
+
+    /* rounds: every node whose children are finished is begun; the multiz runs of the round share their GPU
+     * batches; then the nodes are finished in the stock driver's order */
+    for (;;) {
+        struct mz_mzrun *runs[MAX_NODES];
+        int ready[MAX_NODES], nready = 0, nruns = 0;
+        for (i = 0; i < T.nn; ++i) {
+            rnode *nd = &T.nd[i];
+            if (nd->id >= 0 && !nd->done && T.nd[nd->left].done && T.nd[nd->right].done) ready[nready++] = i;
+        }
+        if (nready == 0) break;
+        for (i = 0; i < nready; ++i) {
+            begin_node(&T.nd[ready[i]]);
+            if (T.nd[ready[i]].run) runs[nruns++] = T.nd[ready[i]].run;
+        }
+        if (nruns) { mz_multiz_align(runs, nruns); ++batches; }
+        for (i = 0; i < nready; ++i) end_node(&T.nd[ready[i]]);
+        ++rounds;
+    }
+    if (T.nd[root].id < 0) mz_fatalf("tree specification is improper");
+
+    dst = fopen(destination, "w");
+    if (!dst) mz_fatalf("Cannot open %s.", destination);
+    fprintf(dst, "##maf version=1 scoring=%s.%d\n%s\n", cmd, ROAST_VERSION, cmdline);
+    {
+        buf fin = project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0 };
+        append_lines_without(&body, &fin, "eof");
+        if (body.n) fwrite(body.p, 1, body.n, dst);
+        buf_free(&fin); buf_free(&body);
+    }
+    fprintf(dst, "##eof maf\n");
+    fclose(dst);
+    if (getenv("MZ_TIMING"))
+        fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s\n",
+                T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0);
+    free(cmdline);
+    return 0;
+}

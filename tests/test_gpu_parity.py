@@ -341,11 +341,11 @@ def test_no_global_score_range_limit(mz):
     # The reference has no bound on K*L*(M+N) (mz_yama.c:50-71).  Round 1 refused every pair whose WORST-CASE path
     # score could pass 2^30; now only the guard-dropping kernels are restricted (by the plan), the row-parallel
     # kernels re-base and the exact ones compute in the reference's int32.  Shapes that used to die with MZ_E_RANGE:
-    # a 30-way merge of 13 000 columns, a 100-way block pair (K*L = 2 500) of 4 000 columns, a long 20-way pair on
+    # a 40-way merge of 13 000 columns, a 100-way block pair (K*L = 2 500) of 4 000 columns, a long 20-way pair on
     # the exact kernels.  Real scores stay far inside int32 (checked against the oracle's finals).
     from multiz_amd import synth
     rng = np.random.default_rng(31)
-    pairs = [inputs.make_pair(rng, 15, 15, 6500, 6480, 30, "diag", mo.smooth),
+    pairs = [inputs.make_pair(rng, 20, 20, 6500, 6480, 30, "diag", mo.smooth),
              inputs.make_pair(rng, 50, 50, 2000, 2000, 30, "diag", mo.smooth),
              inputs.make_pair(rng, 29, 1, 9000, 9100, 30, "diag", mo.smooth),
              inputs.make_pair(rng, 10, 10, 15000, 14900, 30, "diag", mo.smooth),
@@ -368,7 +368,7 @@ def test_no_global_score_range_limit(mz):
             assert m_ == w.OM, (which, i, int(res["mode"][i]))
             assert np.array_equal(out[o0: o0 + m_ * (p[0].shape[1] + p[1].shape[1])].reshape(m_, -1), w.cols), (which, i, int(res["mode"][i]))
             assert res["final3"][i].max() == w.final.max(), (which, i)
-    assert seen[7] + seen[8] > 0 and seen[0] > 0, seen
+    assert seen[5] + seen[6] > 0 and seen[7] + seen[8] > 0 and seen[0] > 0, seen
     _kernels(mz, 2)
 
 
