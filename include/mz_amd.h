@@ -97,7 +97,7 @@ typedef struct mz_dev_batch {
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare,
-                              [8] pairs of more than 127 rows, [9] their work counter, [10] the batch chase's pair counter; 32 entries in all */
+                              [8] pairs of more than 127 rows, [9] their work counter, [10] the batch chase's pair counter, [11] rows (K+L) of all valid pairs; 32 entries in all */
     int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */
@@ -174,6 +174,37 @@ typedef struct mz_out {
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
 /* free() every outs[i].cols of a finished call and reset them to NULL */
 void mz_free_outs(int n, mz_out *outs);
+
+/* ---------------------------------------------------------------- pre_yama() batches: block text in, block text out
+ *
+ * N independent one-stage merges -- pre_yama(a1, a2, beg, end, radius, v = 1, ...) of reference mz_preyama.c:152-262
+ * -- given as the TEXT of the two blocks over their overlap.  Everything between the text and the text happens on
+ * the GPU (kernels/prepost.inc around the DP): column packing, removal of all-dash columns (rmColDash), the band from
+ * the shared reference row and smooth(), yama() itself, the merged columns back to rows with their base counts and
+ * mafScoreRange() of the block that mafBuild() would assemble (rows without a base left out).  The caller keeps
+ * what only it knows: names, strands and start coordinates of the rows. */
+typedef struct mz_prejob {
+    int K;                        /* rows of the first block (all of them take part when v = 1)             */
+    int L1;                       /* rows of the second block INCLUDING its top (reference) row: L = L1 - 1 */
+    int M_all, N_all;             /* columns of the two slices (cend - cbeg + 1 of mz_preyama.c:167-172)    */
+    int radius;
+    const char *const *rows1;     /* K pointers: row r of the first slice is rows1[r][0 .. M_all)           */
+    const char *const *rows2;     /* L1 pointers, the reference row first                                   */
+} mz_prejob;
+
+typedef struct mz_preout {
+    int status, badrow;           /* as in mz_out (yama()'s own refusals, limits of this build)             */
+    int null_result;              /* 1: pre_yama() returns NULL -- no column of the second block is left    */
+    int M, N;                     /* yama()'s M and N (after the dash columns went)                         */
+    int OM;                       /* columns of the merged block                                            */
+    double score;                 /* mafScoreRange(block, 0, OM) over the rows that keep a base             */
+    const int *size;              /* bases per row, K + L entries (inside the `rows` allocation)            */
+    unsigned char *rows;          /* malloc()ed, caller frees: K + L rows of OM bytes, row after row        */
+} mz_preout;
+
+/* Returns the number of pairs without a block (refused or NULL), -1 on a device error, -2 when the current score
+ * tables lack the structure the device form of mafScoreRange() needs (symmetric classes): use the host path then. */
+int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs);
 
 /* ---------------------------------------------------------------- device-resident API */
 

@@ -5,4 +5,4 @@ The product is libmzamd.so (multiz_amd/csrc: hand-written HIP kernels + a C host
 this package is only the Python binding used by the tests and bench.py.
 """
 from .api import (lib, build, yama_batch, yama_one, set_scores_hoxd70, set_scores_hoxd85,  # noqa: F401
-                  MZ_STATUS, DevBatch, LIB_PATH)
+                  MZ_STATUS, DevBatch, LIB_PATH, preyama_batch)

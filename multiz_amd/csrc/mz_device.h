@@ -19,6 +19,24 @@ int mzk_emit(const mz_dev_batch *b, void *stream);
 int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
 int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);
 int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream);
+/* device side of pre_yama() around the DP (kernels/prepost.inc): all device pointers */
+typedef struct mz_pre_batch {
+    int n;
+    const int32_t *K, *L, *Ma, *Na, *rad;
+    const int64_t *offT1, *offT2;
+    const uint8_t *txt;
+    const int64_t *offScr;
+    int32_t *scr;
+    int32_t *nullres;
+} mz_pre_batch;
+typedef struct mz_post_batch {
+    uint8_t *rows;
+    const int64_t *offRow;
+    int32_t *size;
+    int64_t *score;
+} mz_post_batch;
+int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
+int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream);
 const char *mzk_last_error(void);
 #ifdef __cplusplus
 }

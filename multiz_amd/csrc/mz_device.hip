@@ -124,6 +124,7 @@ __device__ __forceinline__ int t_hi(const int *LB, int M, int c)        // last 
 #include "kernels/dispatch.inc"
 #include "kernels/walk.inc"
 #include "kernels/emit.inc"
+#include "kernels/prepost.inc"
 // ------------------------------------------------------------------------------------------
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
@@ -239,21 +240,19 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp)
 {
     if (count <= 0) return 0;
-    // The run-following walk, a wave per pair -- except for batches above 16 Ki pairs that run BESIDE the DP of a
-    // neighbouring batch (mz_dev_run_async, the chunks of mz_yama_batch): there the step-by-step chase with a lane
-    // per pair is used, latency-bound but almost free in instruction issue, which is what that DP needs; on
-    // alignments whose paths turn every few steps (the synthetic C2 pairs drift out of their band) 50 000
-    // run-following waves cost the DP beside them 10 %.
-    // MZ_WALK=wave|direct forces one (tests, measurements).
+    // Serial form: the run-following walk, a wave per pair.  Beside another batch's DP (mz_dev_run_async, the chunks
+    // of mz_yama_batch) the choice between it and the lane-per-pair chase depends on the batch (walk_by_chase(),
+    // kernels/walk.inc) and is made on the device from the plan's totals: both kernels are launched and the one not
+    // chosen returns at once.  MZ_WALK=wave|direct forces one (tests, measurements).
     static int force = -1;
     if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
-    if (force ? force == 1 : (!beside_dp || count <= 16384))
-        hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    else
-    {
+    const bool both = !force && beside_dp && count > 16384;
+    if (force ? force == 1 : true)
+        hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+    if (force ? force == 2 : both) {
         const int waves = (count + WALK_LANES - 1) / WALK_LANES;
         CK(hipMemsetAsync(&b->totals[10], 0, sizeof(int64_t), (hipStream_t)stream), "walk counter");      // the chase's pair counter
-        hipLaunchKernelGGL(k_walk, dim3(waves < WALK_GRID ? waves : WALK_GRID), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+        hipLaunchKernelGGL(k_walk, dim3(waves < WALK_GRID ? waves : WALK_GRID), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
     }
     CK(hipGetLastError(), "walk launch");
     return 0;
@@ -264,6 +263,20 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
     hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "emit launch");
+    return 0;
+}
+extern "C" int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream)
+{
+    if (q->n <= 0) return 0;
+    hipLaunchKernelGGL(k_pre, dim3(q->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *b);
+    CK(hipGetLastError(), "pre launch");
+    return 0;
+}
+extern "C" int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_post, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *b);
+    CK(hipGetLastError(), "post launch");
     return 0;
 }
 extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)   { return mzk_dp_range(b, 0, b->n, stream); }

@@ -83,6 +83,7 @@ typedef struct mz_ctx {
     int scores_ok;                         /* the device's copy of the score model is current */
     /* grow-only buffers of the host-buffer path */
     gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS], d_band[MZ_SETS];
+    gbuf d_pre[6], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
     struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
@@ -155,6 +156,8 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->bdone[s]);
         hipEventDestroy(X->bplan[s]);
     }
+    for (i = 0; i < 6; ++i) if (X->d_pre[i].p) { hipFree(X->d_pre[i].p); X->d_pre[i].p = NULL; X->d_pre[i].cap = 0; }
+    for (i = 0; i < 2; ++i) if (X->h_pre[i].p) { hipHostFree(X->h_pre[i].p); X->h_pre[i].p = NULL; X->h_pre[i].cap = 0; }
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);
     for (i = 0; i < MZ_WS_MAX; ++i) if (X->ws[i].used) { hipEventDestroy(X->ws[i].done); X->ws[i].used = 0; }
@@ -896,6 +899,175 @@ void mz_free_outs(int n, mz_out *outs)
 {
     int p;
     for (p = 0; p < n; ++p) { free(outs[p].cols); outs[p].cols = NULL; }
+}
+
+/* ------------------------------------------------------------------ pre_yama() batches */
+
+/* One pass over one GPU (the primary context): the slices' text goes up once, k_pre derives A, B and the band where
+ * the DP kernels read them, the usual plan / DP / walk / emit run on those pools, k_post turns the merged columns
+ * into rows with base counts and score, and rows + per-row results come back.  Calls of more than ~1 GB of text are
+ * cut into several passes. */
+static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs)
+{
+    hipStream_t st = X->stream;
+    mz_dev_batch b;
+    mz_pre_batch q;
+    mz_post_batch r;
+    size_t txt = 0, szA = 0, szB = 0, nband = 0, nscr = 0, nrow = 0, hdr, in_bytes, res_bytes;
+    int64_t *hT1, *hT2, *hoA, *hoB, *hoBand, *hoScr, *hoRow, totals[16];
+    int32_t *hK, *hL, *hMa, *hNa, *hRad;
+    char *h, *d, *hres;
+    uint8_t *hTxt;
+    int p, failed = 0, oom = 0;
+
+    for (p = 0; p < n; ++p) {
+        const mz_prejob *j = &jobs[p];
+        if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1) return set_err("mz_preyama_batch: job %d has an empty block or slice", p);
+        txt += (size_t)j->K * j->M_all + (size_t)j->L1 * j->N_all;
+        szA += (size_t)j->K * j->M_all; szB += (size_t)(j->L1 - 1) * j->N_all;
+        nband += (size_t)j->M_all + 1; nscr += 2 * ((size_t)j->N_all + 2) + 2 * ((size_t)j->M_all + 2);
+        nrow += (size_t)j->K + j->L1 - 1;
+    }
+    /* pinned staging: K L Ma Na rad (int32 x n), offT1 offT2 offA offB offBand offScr offRow (int64 x n), text */
+    hdr = 5 * al256(4 * (size_t)n) + 7 * al256(8 * (size_t)n);
+    in_bytes = hdr + al256(txt);
+    if (host_reserve(&X->h_pre[0], in_bytes) || dev_reserve(&X->d_pre[0], in_bytes) ||
+        dev_reserve(&X->d_pre[1], al256(szA) + al256(szB) + 256) || dev_reserve(&X->d_pre[2], 2 * al256(4 * nband)) ||
+        dev_reserve(&X->d_pre[3], 4 * nscr + 256)) return -1;
+    h = (char *)X->h_pre[0].p; d = (char *)X->d_pre[0].p;
+    memset(&b, 0, sizeof b); memset(&q, 0, sizeof q); memset(&r, 0, sizeof r);
+    b.n = q.n = n;
+#define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += al256(bytes); d += al256(bytes); } while (0)
+    SL(hK, int32_t, q.K, 4 * (size_t)n); SL(hL, int32_t, q.L, 4 * (size_t)n); SL(hMa, int32_t, q.Ma, 4 * (size_t)n);
+    SL(hNa, int32_t, q.Na, 4 * (size_t)n); SL(hRad, int32_t, q.rad, 4 * (size_t)n);
+    SL(hT1, int64_t, q.offT1, 8 * (size_t)n); SL(hT2, int64_t, q.offT2, 8 * (size_t)n);
+    SL(hoA, int64_t, b.offA, 8 * (size_t)n); SL(hoB, int64_t, b.offB, 8 * (size_t)n); SL(hoBand, int64_t, b.offBand, 8 * (size_t)n);
+    SL(hoScr, int64_t, q.offScr, 8 * (size_t)n); SL(hoRow, int64_t, r.offRow, 8 * (size_t)n);
+    SL(hTxt, uint8_t, q.txt, txt);
+#undef SL
+    {
+        size_t ot = 0, oa = 0, ob = 0, od = 0, os = 0, orow = 0;
+        for (p = 0; p < n; ++p) {
+            const mz_prejob *j = &jobs[p];
+            hK[p] = j->K; hL[p] = j->L1 - 1; hMa[p] = j->M_all; hNa[p] = j->N_all; hRad[p] = j->radius;
+            hT1[p] = (int64_t)ot; ot += (size_t)j->K * j->M_all;
+            hT2[p] = (int64_t)ot; ot += (size_t)j->L1 * j->N_all;
+            hoA[p] = (int64_t)oa; oa += (size_t)j->K * j->M_all;
+            hoB[p] = (int64_t)ob; ob += (size_t)(j->L1 - 1) * j->N_all;     /* (upper bound: dash columns go on the device) */
+            hoBand[p] = (int64_t)od; od += (size_t)j->M_all + 1;
+            hoScr[p] = (int64_t)os; os += 2 * ((size_t)j->N_all + 2) + 2 * ((size_t)j->M_all + 2);
+            hoRow[p] = (int64_t)orow; orow += (size_t)j->K + j->L1 - 1;
+        }
+#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
+        for (p = 0; p < n; ++p) {
+            const mz_prejob *j = &jobs[p];
+            int k;
+            for (k = 0; k < j->K; ++k) memcpy(hTxt + hT1[p] + (size_t)k * j->M_all, j->rows1[k], (size_t)j->M_all);
+            for (k = 0; k < j->L1; ++k) memcpy(hTxt + hT2[p] + (size_t)k * j->N_all, j->rows2[k], (size_t)j->N_all);
+        }
+    }
+    HIPCK(hipMemcpyAsync(X->d_pre[0].p, X->h_pre[0].p, in_bytes, hipMemcpyHostToDevice, st));
+    b.poolA = (const uint8_t *)X->d_pre[1].p; b.poolB = (const uint8_t *)X->d_pre[1].p + al256(szA);
+    b.poolLB = (const int32_t *)X->d_pre[2].p; b.poolRB = (const int32_t *)((char *)X->d_pre[2].p + al256(4 * nband));
+    q.scr = (int32_t *)X->d_pre[3].p;
+    /* K L M N of the device batch, the NULL flags, sizes, scores: one more device block */
+    if (dev_reserve(&X->d_pre[4], 5 * al256(4 * (size_t)n) + al256(4 * nrow) + al256(8 * (size_t)n))) return -1;
+    {
+        char *e = (char *)X->d_pre[4].p;
+        b.K = (const int32_t *)e; e += al256(4 * (size_t)n); b.L = (const int32_t *)e; e += al256(4 * (size_t)n);
+        b.M = (const int32_t *)e; e += al256(4 * (size_t)n); b.N = (const int32_t *)e; e += al256(4 * (size_t)n);
+        q.nullres = (int32_t *)e; e += al256(4 * (size_t)n);
+        r.size = (int32_t *)e; e += al256(4 * nrow);
+        r.score = (int64_t *)e;
+    }
+    if (mzk_pre(&q, &b, st)) return set_err("%s", mzk_last_error());
+
+    if (dev_reserve(&X->d_plan[0], mz_dev_plan_bytes(n))) return -1;
+    mz_dev_carve(&b, X->d_plan[0].p);
+    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;
+    if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (dev_reserve(&X->d_tb[0], 4 * (size_t)totals[0] + 256) || dev_reserve(&X->d_script[0], (size_t)totals[1] + 256) ||
+        dev_reserve(&X->d_out[0], (size_t)totals[2] + 256) || dev_reserve(&X->d_prep[0], 4 * (size_t)totals[4] + 256) ||
+        dev_reserve(&X->d_pre[5], (size_t)totals[2] + 256)) return -1;
+    b.tbw = (uint32_t *)X->d_tb[0].p; b.script = (uint8_t *)X->d_script[0].p; b.out = (uint8_t *)X->d_out[0].p;
+    b.prep = (uint32_t *)X->d_prep[0].p; b.capPrep = (int64_t)(X->d_prep[0].cap / 4);
+    b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = (int64_t)X->d_out[0].cap;
+    r.rows = (uint8_t *)X->d_pre[5].p;
+    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 0) || mzk_emit(&b, st) || mzk_post(&r, &b, st))
+        return set_err("%s", mzk_last_error());
+
+    /* results: status badrow om M N nullres (int32 x n), offOut score (int64 x n), sizes (int32 x rows), the rows */
+    res_bytes = 6 * al256(4 * (size_t)n) + 2 * al256(8 * (size_t)n) + al256(4 * nrow) + al256((size_t)totals[2]);
+    if (host_reserve(&X->h_pre[1], res_bytes)) return -1;
+    hres = (char *)X->h_pre[1].p;
+    {
+        char *o = hres;
+#define DOWN(src, bytes) do { HIPCK(hipMemcpyAsync(o, src, bytes, hipMemcpyDeviceToHost, st)); o += al256(bytes); } while (0)
+        DOWN(b.status, 4 * (size_t)n); DOWN(b.badrow, 4 * (size_t)n); DOWN(b.om, 4 * (size_t)n);
+        DOWN(b.M, 4 * (size_t)n); DOWN(b.N, 4 * (size_t)n); DOWN(q.nullres, 4 * (size_t)n);
+        DOWN(b.offOut, 8 * (size_t)n); DOWN(r.score, 8 * (size_t)n); DOWN(r.size, 4 * nrow);
+        if (totals[2] > 0) HIPCK(hipMemcpyAsync(o, r.rows, (size_t)totals[2], hipMemcpyDeviceToHost, st));
+#undef DOWN
+    }
+    HIPCK(hipStreamSynchronize(st));
+    {
+        const int32_t *rs = (const int32_t *)hres, *rb = (const int32_t *)(hres + al256(4 * (size_t)n)),
+                      *ro = (const int32_t *)(hres + 2 * al256(4 * (size_t)n)), *rM = (const int32_t *)(hres + 3 * al256(4 * (size_t)n)),
+                      *rN = (const int32_t *)(hres + 4 * al256(4 * (size_t)n)), *rnull = (const int32_t *)(hres + 5 * al256(4 * (size_t)n));
+        const int64_t *roff = (const int64_t *)(hres + 6 * al256(4 * (size_t)n)), *rsc = roff + al256(8 * (size_t)n) / 8;
+        const int32_t *rsz = (const int32_t *)((const char *)rsc + al256(8 * (size_t)n));
+        const uint8_t *rrows = (const uint8_t *)rsz + al256(4 * nrow);
+#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) reduction(+:failed) reduction(|:oom) if (n > 256)
+        for (p = 0; p < n; ++p) {
+            mz_preout *o = &outs[p];
+            const int W = jobs[p].K + jobs[p].L1 - 1;
+            memset(o, 0, sizeof *o);
+            o->null_result = rnull[p];
+            o->status = rnull[p] ? MZ_OK : rs[p]; o->badrow = rb[p]; o->M = rM[p]; o->N = rN[p];
+            if (rnull[p] || rs[p] != MZ_OK) { failed++; continue; }
+            o->OM = ro[p];
+            o->score = (double)rsc[p];
+            {
+                const size_t nb = (size_t)W * (size_t)ro[p], pad = (nb + 7) & ~(size_t)7;
+                o->rows = (unsigned char *)malloc(pad + 4 * (size_t)W + 8);
+                if (!o->rows) { oom = 1; o->status = MZ_E_DEVICE; continue; }
+                memcpy(o->rows, rrows + roff[p], nb);
+                memcpy(o->rows + pad, rsz + hoRow[p], 4 * (size_t)W);
+                o->size = (const int *)(o->rows + pad);
+            }
+        }
+    }
+    if (oom) return set_err("out of memory for the merged rows");
+    return failed;
+}
+
+int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
+{
+    int done = 0, failed = 0, a, b;
+    if (n <= 0) return 0;
+    pthread_mutex_lock(&g_big);
+    if (ensure_init() || sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+    for (a = 0; a < 128; ++a)                              /* k_post's pair sums need ss[x][y] == ss[y][x] */
+        for (b = 0; b < a; ++b)
+            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); set_err("score table is not symmetric"); return -2; }
+    if (hipSetDevice(G.device) != hipSuccess) { pthread_mutex_unlock(&g_big); return set_err("hipSetDevice failed"); }
+    while (done < n) {
+        size_t bytes = 0;
+        int m = 0, rc;
+        while (done + m < n && m < (1 << 20) && bytes < ((size_t)1 << 30)) {
+            const mz_prejob *j = &jobs[done + m];
+            bytes += (size_t)(j->K > 0 ? j->K : 0) * (size_t)(j->M_all > 0 ? j->M_all : 0) + (size_t)(j->L1 > 0 ? j->L1 : 0) * (size_t)(j->N_all > 0 ? j->N_all : 0);
+            ++m;
+        }
+        rc = preyama_pass(&G, m, jobs + done, outs + done);
+        if (rc < 0) { pthread_mutex_unlock(&g_big); return -1; }
+        failed += rc;
+        done += m;
+    }
+    pthread_mutex_unlock(&g_big);
+    return failed;
 }
 
 /* ------------------------------------------------------------------ yama(): a batch of one */

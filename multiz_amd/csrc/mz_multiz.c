@@ -256,6 +256,115 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
  * mz_roast.c) then share the same GPU batches. */
 typedef struct { record *R; int i; } mref;
 
+/* what mafBuild() does with yama()'s columns (reference mz_preyama.c:38-81), from the rows, base counts and score
+ * that mz_preyama_batch() brings back: bookkeeping of the rows only -- sources in order (all of a1, then a2 below
+ * its top row), starts advanced by the bases left of the slice, rows without a base dropped */
+static struct mafAli *block_from_rows(const mz_preout *o, struct mafAli *a1, int cbeg1, struct mafAli *a2, int cbeg2)
+{
+    struct mafAli *blk = (struct mafAli *)mz_xmalloc(sizeof *blk);
+    struct mafComp *src = a1->components, *tail = NULL, *nc;
+    int skip = cbeg1, i, j, second = 0;
+    memset(blk, 0, sizeof *blk);
+    blk->textSize = o->OM;
+    for (i = 0; ; ++i, src = src->next) {
+        int start;
+        if (src == NULL) {
+            if (second) break;
+            second = 1; src = a2->components->next; skip = cbeg2;
+            if (src == NULL) break;
+        }
+        if (o->size[i] == 0) continue;
+        for (start = src->start, j = 0; j < skip; ++j) start += src->text[j] != '-';
+        nc = mafCpyComp(src);
+        nc->start = start;
+        nc->size = o->size[i];
+        nc->text = (char *)mz_xmalloc((size_t)o->OM + 1);
+        memcpy(nc->text, o->rows + (size_t)i * (size_t)o->OM, (size_t)o->OM);
+        nc->text[o->OM] = 0;
+        if (tail) tail->next = nc; else blk->components = nc;
+        tail = nc;
+    }
+    if (!blk->components) { free(blk); return NULL; }
+    blk->score = o->score;
+    return blk;
+}
+
+/* The one-stage merges (v == 1) with everything between block text and block text on the GPU (SURVEY.md 8 f2,
+ * mz_preyama_batch()): the host only locates the overlap columns and assembles the result's bookkeeping.  Returns 0
+ * when the score tables do not allow it (the caller then takes the host stages for these merges too). */
+static int run_merges_device(mref *all, int nmg, int minw, int timing)
+{
+    mz_prejob *jobs;
+    mz_preout *outs;
+    const char **ptrs;
+    int *who, *cb1, *cb2, n = 0, i, rc;
+    size_t nptr = 0, at = 0;
+    double t0 = mz_now_s(), t1;
+    for (i = 0; i < nmg; ++i) {
+        merge *g = &all[i].R->mg[all[i].i];
+        struct mafComp *c;
+        if (g->v != 1) continue;
+        ++n;
+        for (c = g->a1->components; c; c = c->next) ++nptr;
+        for (c = g->a2->components; c; c = c->next) ++nptr;
+    }
+    if (n == 0) return 1;
+    jobs = (mz_prejob *)mz_xmalloc((size_t)n * sizeof *jobs);
+    outs = (mz_preout *)mz_xmalloc((size_t)n * sizeof *outs);
+    who = (int *)mz_xmalloc((size_t)n * sizeof(int));
+    cb1 = (int *)mz_xmalloc((size_t)n * sizeof(int)); cb2 = (int *)mz_xmalloc((size_t)n * sizeof(int));
+    ptrs = (const char **)mz_xmalloc((nptr ? nptr : 1) * sizeof *ptrs);
+    for (i = 0, n = 0; i < nmg; ++i) {
+        merge *g = &all[i].R->mg[all[i].i];
+        struct mafComp *c;
+        mz_prejob *j;
+        int ce1, ce2;
+        if (g->v != 1) continue;
+        j = &jobs[n];
+        cb1[n] = mafPos2Col(g->a1->components, g->beg, g->a1->textSize);
+        ce1 = mafPos2Col(g->a1->components, g->end, g->a1->textSize);
+        cb2[n] = mafPos2Col(g->a2->components, g->beg, g->a2->textSize);
+        ce2 = mafPos2Col(g->a2->components, g->end, g->a2->textSize);
+        j->M_all = ce1 - cb1[n] + 1; j->N_all = ce2 - cb2[n] + 1; j->radius = g->radius;
+        j->rows1 = ptrs + at;
+        for (c = g->a1->components, j->K = 0; c; c = c->next, ++j->K) ptrs[at++] = c->text + cb1[n];
+        j->rows2 = ptrs + at;
+        for (c = g->a2->components, j->L1 = 0; c; c = c->next, ++j->L1) ptrs[at++] = c->text + cb2[n];
+        who[n++] = i;
+    }
+    rc = mz_preyama_batch(n, jobs, outs);
+    if (rc == -2) { free(jobs); free(outs); free(who); free(cb1); free(cb2); free(ptrs); return 0; }
+    if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+    t1 = mz_now_s();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
+    for (i = 0; i < n; ++i) {
+        merge *g = &all[who[i]].R->mg[all[who[i]].i];
+        const mz_preout *o = &outs[i];
+        if (o->null_result) { g->state = MZ_PY_DONE; g->result = NULL; continue; }
+        if (o->status != MZ_OK) {
+            /* yama() refused the job: the message names LB / RB entries, so the host builds the job after all (rare) */
+            if (mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, NULL) != MZ_PY_JOB) { g->state = MZ_PY_DONE; continue; }
+            g->state = MERGE_FAILED; g->bad_job = g->py.job;
+            memset(&g->bad_out, 0, sizeof g->bad_out);
+            g->bad_out.status = o->status; g->bad_out.badrow = o->badrow; g->bad_out.OM = o->OM;
+            continue;
+        }
+        g->result = block_from_rows(o, g->a1, cb1[i], g->a2, cb2[i]);
+        g->state = MZ_PY_DONE;
+        free(o->rows);
+        if (g->result && g->result->components->size >= minw) {
+            FILE *m = open_memstream(&g->text, &g->len);
+            mafWrite(m, g->result);
+            fclose(m);
+        }
+        mafAliFree(&g->result);
+    }
+    if (timing) fprintf(stderr, "mz_multiz: %d one-stage merges, block text to block text on the GPU %.3f s, blocks assembled and rendered %.3f s\n",
+                        n, t1 - t0, mz_now_s() - t1);
+    free(jobs); free(outs); free(who); free(cb1); free(cb2); free(ptrs);
+    return 1;
+}
+
 static void run_merges(record **RR, int nrec, int minw)
 {
     int nmg = 0, i, r;
@@ -274,12 +383,22 @@ static void run_merges(record **RR, int nrec, int minw)
         for (i = 0; i < RR[r]->nmg; ++i) { all[nmg].R = RR[r]; all[nmg++].i = i; }
     mz_score_profile_sync();
     for (r = 0; r < nrec; ++r) render_events(RR[r]);
+    /* v == 1: slicing, dash columns, band, yama(), transposition, base counts and score all on the GPU (MZ_HOST_PREP=1
+     * keeps them on the host stages below, as every v == 0 merge is) */
+    {
+        const char *e = getenv("MZ_HOST_PREP");
+        if (!(e && atoi(e) != 0) && run_merges_device(all, nmg, minw, timing))
+            for (i = 0; i < nmg; ++i) { merge *g = &all[i].R->mg[all[i].i]; if (g->v == 1 && g->state == 0) g->state = MZ_PY_DONE; }
+    }
+    t0 = mz_now_s();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)
     for (i = 0; i < nmg; ++i) {
         record *R = all[i].R;
         merge *g = &R->mg[all[i].i];
         event *e = &R->ev[g->side_ev];
-        FILE *m = open_memstream(&e->text, &e->len);
+        FILE *m;
+        if (g->state == MZ_PY_DONE || g->state == MERGE_FAILED) continue;      /* taken care of on the device path */
+        m = open_memstream(&e->text, &e->len);
         g->state = mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, R->has2 ? m : NULL);
         fclose(m);
     }

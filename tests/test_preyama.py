@@ -241,3 +241,80 @@ def test_product_preyama2_matches_reference(product, tmp_path):
         assert same_block(outs[1], outs[0])
         done += outs[0] is not None
     assert done >= 30
+
+
+# ------------------------------------------------------------------ device-side prep / post
+
+def _prejob(a1, a2, beg, end, radius):
+    cb1, ce1 = mo.pos2col(a1.rows[0], beg, a1.textSize), mo.pos2col(a1.rows[0], end, a1.textSize)
+    cb2, ce2 = mo.pos2col(a2.rows[0], beg, a2.textSize), mo.pos2col(a2.rows[0], end, a2.textSize)
+    return ([r.text[cb1:ce1 + 1].encode() for r in a1.rows], [r.text[cb2:ce2 + 1].encode() for r in a2.rows], radius), cb1, cb2
+
+
+def _assemble(res, a1, cb1, a2, cb2):
+    """what the caller of mz_preyama_batch() still does (mafBuild, mz_preyama.c:46-70): bookkeeping of the rows --
+    sources in order, starts advanced by the bases left of the slice, rows without a base dropped"""
+    if res["null"] or res["rows"] is None:
+        return None
+    src = [(r, cb1) for r in a1.rows] + [(r, cb2) for r in a2.rows[1:]]
+    rows = []
+    for (r, cb), text, size in zip(src, res["rows"], res["size"]):
+        if size == 0:
+            continue
+        rows.append(mo.Row(src=r.src, start=r.start + sum(ch != "-" for ch in r.text[:cb]), size=size, strand=r.strand,
+                           srcSize=r.srcSize, text=text.decode()))
+    return mo.Block(rows=rows, score=res["score"]) if rows else None
+
+
+@pytest.mark.gpu
+def test_device_prep_and_post_match_the_oracle_on_golden_blocks(product):
+    # the 60 reference-generated block pairs, every one as a one-stage merge (v = 1): text in, text out through
+    # mz_preyama_batch() -- rmColDash, band walk, smooth, yama, transposition, base counts and mafScoreRange on the GPU --
+    # against the oracle's restatement of pre_yama (itself pinned to the compiled reference above)
+    import multiz_amd as m
+    jobs, meta = [], []
+    for g in GOLD:
+        a1, a2 = to_block(g["a1"]), to_block(g["a2"])
+        j, cb1, cb2 = _prejob(a1, a2, g["beg"], g["end"], g["radius"])
+        jobs.append(j); meta.append((a1, cb1, a2, cb2, g))
+    res = m.preyama_batch(jobs)
+    for r, (a1, cb1, a2, cb2, g) in zip(res, meta):
+        want, _ = mo.pre_yama(a1, a2, g["beg"], g["end"], g["radius"], 1)
+        assert r["status"] == 0
+        assert same_block(_assemble(r, a1, cb1, a2, cb2), want)
+        if g["v"] == 1:
+            assert same_block(_assemble(r, a1, cb1, a2, cb2), to_block(g["out"]))       # the reference's own output
+
+
+@pytest.mark.gpu
+def test_device_prep_and_post_random_blocks(product):
+    # random block pairs: many rows, dash-heavy second blocks (columns removed, rows left without a base), small
+    # radii, long overlaps; one batch
+    import multiz_amd as m
+    rng = np.random.default_rng(2)
+    jobs, meta = [], []
+    while len(jobs) < 150:
+        n1, n2 = int(rng.integers(1, 9)), int(rng.integers(2, 9))
+        a1, a2, beg, end = inputs.random_block_pair(rng, n1, n2, int(rng.integers(60, 900)))
+        if end - beg < 12:
+            continue
+        R = int(rng.choice([15, 30, 50]))
+        try:
+            want, _ = mo.pre_yama(a1, a2, beg, end, R, 1)
+        except RuntimeError:
+            continue
+        j, cb1, cb2 = _prejob(a1, a2, beg, end, R)
+        jobs.append(j); meta.append((a1, cb1, a2, cb2, want))
+    res = m.preyama_batch(jobs)
+    dropped = 0
+    for r, (a1, cb1, a2, cb2, want) in zip(res, meta):
+        assert r["status"] == 0
+        got = _assemble(r, a1, cb1, a2, cb2)
+        assert same_block(got, want)
+        dropped += sum(s == 0 for s in r["size"]) if r["size"] else 0
+    # a second block that is nothing but dashes under the overlap: pre_yama() returns NULL
+    a1, a2, beg, end = inputs.random_block_pair(rng, 2, 2, 200)
+    a2.rows[1].text = "-" * a2.textSize
+    j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
+    r = m.preyama_batch([j])[0]
+    assert r["null"] and r["rows"] is None and mo.pre_yama(a1, a2, beg, end, 30, 1)[0] is None
