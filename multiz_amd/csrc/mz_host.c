@@ -178,8 +178,9 @@ static int init_devices(int ngpu, const int *devices, int first)
     for (i = 0; i < ngpu; ++i) {
         const int d = devices ? devices[i] : first + i;
         if (d < 0 || d >= count) return set_err("HIP device %d out of range (%d present)", d, count);
-        for (j = 0; j < i; ++j)
-            if ((devices ? devices[j] : first + j) == d) return set_err("mz_init_multi: device %d listed twice", d);
+        for (j = 0; j < i; ++j)       /* (MZ_ALLOW_DUP_DEVICES=1: several contexts on one GPU, to exercise the dealing on a one-GPU box) */
+            if ((devices ? devices[j] : first + j) == d && !(getenv("MZ_ALLOW_DUP_DEVICES") && atoi(getenv("MZ_ALLOW_DUP_DEVICES"))))
+                return set_err("mz_init_multi: device %d listed twice", d);
     }
     if (g_ndev) mz_finalize();
     for (i = 0; i < ngpu; ++i)
@@ -536,7 +537,7 @@ typedef struct chunk {
     const mz_job *jobs;
     mz_out *outs;
     mz_dev_batch b;
-    int64_t out_bytes;
+    int64_t out_bytes, in_bytes;
     double t_pack, t_plan;
 } chunk;
 
@@ -651,6 +652,7 @@ static int chunk_upload(mz_ctx *X, chunk *c, int set, int n, const mz_job *jobs,
     }
     free(csz);
     c->t_pack = now_s() - t0;
+    c->in_bytes = (int64_t)in_bytes;
     HIPCK(hipMemcpyAsync(X->d_in[set].p, X->h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
     if (mzk_unband(n, dLen, b.offBand, doC, dFmt, dC, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st)) return set_err("%s", mzk_last_error());
 
@@ -742,8 +744,9 @@ static int chunk_collect(chunk *c)
     }
     if (oom) return set_err("out of memory for the output columns");
     if (getenv("MZ_TIMING"))
-        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, wait for H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms\n",
-                n, 1e3 * c->t_pack, 1e3 * c->t_plan, 1e3 * (t1 - t0), 1e3 * (now_s() - t1));
+        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, wait for H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms; %.0f B per pair to the device, %.0f B back\n",
+                n, 1e3 * c->t_pack, 1e3 * c->t_plan, 1e3 * (t1 - t0), 1e3 * (now_s() - t1), (double)c->in_bytes / n,
+                (double)(c->out_bytes + 32 * (int64_t)n) / n);
     return failed;
 }
 
@@ -1040,6 +1043,9 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
         }
     }
     if (oom) return set_err("out of memory for the merged rows");
+    if (getenv("MZ_TIMING"))
+        fprintf(stderr, "mz_preyama_batch pass(%d): %.1f MB to the device (%.0f B per merge), %.1f MB back (%.0f B per merge)\n",
+                n, in_bytes / 1e6, (double)in_bytes / n, res_bytes / 1e6, (double)res_bytes / n);
     return failed;
 }
 

@@ -1,0 +1,83 @@
+"""Several GPUs in one process (include/mz_amd.h: mz_init_multi, MZ_NGPU) and the N > 1 forms of bench.py, as far as
+a one-GPU box can exercise them: the context table, the dealing of a host batch over contexts with one host thread
+each (two contexts on GPU 0, MZ_ALLOW_DUP_DEVICES=1), MZ_NGPU from the environment, and bench.py's rank spawning,
+weak-scaling and --scatter (RCCL-style scatter / device compute / gather; gloo here, both ranks on GPU 0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import multiz_amd as mz
+from multiz_amd import api, synth
+from oracle import mzoracle as mo
+lib = mz.lib()
+lib.mz_init_multi.argtypes = [C.c_int, C.POINTER(C.c_int)]
+mode = sys.argv[1]
+if mode == "dup":
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.mz_init_multi(2, devs) == 0, lib.mz_last_error()
+    assert lib.mz_device_count() == 2
+elif mode == "env":
+    pass                                            # MZ_NGPU=1 MZ_DEVICE=0 from the environment, on first use
+elif mode == "bad":
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.mz_init_multi(2, devs) == -1 and b"listed twice" in lib.mz_last_error()
+    assert lib.mz_init_multi(64, None) == -1
+    devs = (C.c_int * 2)(0, 7)
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert lib.mz_init_multi(2, devs) == -1 and b"out of range" in lib.mz_last_error()
+    assert lib.mz_device_count() == 0
+    print("multi ok"); sys.exit(0)
+n = 9000
+batch = synth.make_batch(n, 0, 0, 200, 600, 30, first_pair=11)          # tree workload: pairs of very different cost
+jobs, outs = api.host_jobs(batch)
+for rep in range(2):
+    assert api.yama_batch_records(jobs, outs) == 0
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=16)
+    assert bad == 0 and (outs["status"] == 0).all() and np.array_equal(outs["OM"], om)
+    W = batch["K"].astype(np.int64) + batch["L"]
+    for i in range(0, n, 7):
+        got = np.frombuffer(C.string_at(int(outs["cols"][i]), int(om[i]) * int(W[i])), dtype=np.uint8)
+        assert mo.fnv1a_np(got, mo.fnv1a_np(np.array([om[i]], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
+    api.free_outs(outs)
+assert lib.mz_device_count() == (2 if mode == "dup" else 1)
+print("multi ok")
+'''
+
+
+@pytest.mark.parametrize("mode,env", [("dup", {"MZ_ALLOW_DUP_DEVICES": "1"}), ("env", {"MZ_NGPU": "1", "MZ_DEVICE": "0"}), ("bad", {})])
+def test_contexts_and_dealing(mode, env):
+    p = subprocess.run([sys.executable, "-c", CODE, mode], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, timeout=900)
+    assert p.returncode == 0 and b"multi ok" in p.stdout, p.stderr.decode()[-3000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--scatter"]])
+def test_bench_two_ranks_on_one_gpu(extra):
+    # `--gpus 2` without a distributed environment: bench.py starts the ranks itself; MZ_BENCH_SHARE_GPU=1 puts both on
+    # GPU 0 over gloo (development switch; the number is not a scaling measurement, the control flow is the real one)
+    env = dict(os.environ, MZ_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "c4", "--pairs", "3000", "--steps", "3", "--warmup", "1"] + extra,
+                       cwd=ROOT, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == 6000 and d["value"] > 0
+    if extra:
+        assert d["exchange"]["ranks_used"] == 2 and "RCCL" in d["config"]["parallelism"]
+
+
+def test_bench_refuses_a_mismatched_world():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--steps", "1"], cwd=ROOT, env=env, capture_output=True, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
