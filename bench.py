@@ -33,13 +33,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # PMC figures of one launch of the dominant kernel on the DEFAULT c2 batch (50 000 pairs), from the separate rocprofv3
 # --pmc passes summarised in profiles/r2_pmc_summary.txt.  Measured, never estimated; reported only for that batch.
-#   FETCH_SIZE 355 553 KB (narrow coalesced reads: x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2 438 496 KB
-PMC_C2 = {"traffic": (2 * 355553 + 2438496) * 1024, "valu_insts": 2835120086}
+#   FETCH_SIZE 355 227 KB (coalesced reads: x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2 438 500 KB; SQ_INSTS_VALU
+PMC_C2 = {"traffic": (2 * 355227 + 2438500) * 1024, "valu_insts": 2731186455}
 # VALU issue: integer max / dot2 / cndmask / DPP wave-instructions occupy a SIMD for 4 shader cycles on gfx950
 # (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt; v_add/v_sub/v_and: 2-3); 1024 SIMDs.
 VALU_CYCLES = 4.0
 SIMDS = 1024
-CLOCK_GHZ = 2.4
+CLOCK_GHZ = 2.35          # GRBM_GUI_ACTIVE / 8 / kernel time of the same launch (profiles/r2_pmc_summary.txt)
 
 
 def spawn_ranks(args):

@@ -81,7 +81,9 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
 
 typedef struct mz_dev_batch {
     int32_t n;
-    int32_t pad_;
+    int32_t walk_hint;     /* 0: let the device choose the traceback-walk kernel of a batch that runs beside another batch's
+                              DP (both kernels are launched, one returns at once); MZ_WALK_RUNS / MZ_WALK_CHASE: the caller
+                              has read the plan's totals and chosen (mz_walk_choice()) -- one launch */
     /* inputs (device pointers) */
     const int32_t *K, *L, *M, *N;
     const int64_t *offA, *offB, *offBand;
@@ -109,6 +111,10 @@ typedef struct mz_dev_batch {
     int32_t *om;           /* OM per pair                          */
     int32_t *final3;       /* C,D,I at (M,N), 3 per pair           */
 } mz_dev_batch;
+
+enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
+/* the choice the device would make, from the plan's totals (host copy) of an n-pair batch */
+int mz_walk_choice(int n, const int64_t *totals);
 
 typedef struct mz_score_model {
     int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */

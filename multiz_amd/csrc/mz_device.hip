@@ -246,10 +246,11 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     // chosen returns at once.  MZ_WALK=wave|direct forces one (tests, measurements).
     static int force = -1;
     if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
-    const bool both = !force && beside_dp && count > 16384;
-    if (force ? force == 1 : true)
+    const int hint = (force || !beside_dp || count <= 16384) ? 0 : b->walk_hint;
+    const bool both = !force && beside_dp && count > 16384 && hint == MZ_WALK_AUTO;
+    if (force ? force == 1 : (both || hint != MZ_WALK_CHASE))
         hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
-    if (force ? force == 2 : both) {
+    if (force ? force == 2 : (both || hint == MZ_WALK_CHASE)) {
         const int waves = (count + WALK_LANES - 1) / WALK_LANES;
         CK(hipMemsetAsync(&b->totals[10], 0, sizeof(int64_t), (hipStream_t)stream), "walk counter");      // the chase's pair counter
         hipLaunchKernelGGL(k_walk, dim3(waves < WALK_GRID ? waves : WALK_GRID), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
@@ -257,6 +258,13 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     CK(hipGetLastError(), "walk launch");
     return 0;
 }
+// the host-side twin of walk_by_chase() (kernels/walk.inc), for callers that hold a copy of the plan's totals
+extern "C" int mz_walk_choice(int n, const int64_t *totals)
+{
+    const long long ok = (long long)n - totals[3];
+    return (n > 16384 && totals[11] < 8 * (ok > 0 ? ok : 1)) ? MZ_WALK_CHASE : MZ_WALK_RUNS;
+}
+
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;

@@ -684,6 +684,7 @@ static int chunk_launch(chunk *c)
         return -1;
     b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = (uint8_t *)X->d_out[set].p;
     b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
+    b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
 
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit(&b, st))
