@@ -378,104 +378,128 @@ struct mafAli *pre_yama(struct mafAli *a1, struct mafAli *a2, int beg, int end, 
 extern int connectionAgreement2(struct mafAli *a2, struct mafAli *a3, int cbeg2, int cend2, int cbeg3, int cend3,
                                 struct pwuAliFiles *pws) __attribute__((weak));
 
-/* the reference's must_equal(), mz_preyama.c:361-383: same text on stderr (no program-name prefix), exit(1) */
-static void rows_must_agree(char x, char y, int pos, struct mafComp *c1, int cbeg1, int cend1,
-                            struct mafComp *c2, int cbeg2, int cend2, int file2)
+/* ---- pre_yama2 in the same three steps as pre_yama(): describe the job, run it on the GPU, build the block.
+ *
+ * The band comes from the pairwise block a1, whose two rows are sequence X (the top row of a2) and sequence Y (the top
+ * row of a3): column k of a1's slice has consumed tx(k) bases of X and ty(k) bases of Y, the tx-th base of X sits in
+ * column colA[tx] of the a2 slice and the ty-th base of Y in column colB[ty] of the a3 slice, so column k ties row
+ * colA[tx(k)] of the DP to column colB[ty(k)].  Per row the first non-zero and the last such column are the raw bounds
+ * (the reference's running form of the same, mz_preyama.c:461-497, including its use of 0 as "not set"). */
+
+/* the base columns of a row slice: col[t] (t = 1..) = 1-based slice column of its t-th base; returns the count */
+static int base_columns(const char *text, int cbeg, int cend, int **cols)
 {
-    int i;
-    char z;
-    if (toupper((unsigned char)x) == toupper((unsigned char)y)) return;
+    int *c = (int *)xmalloc(((size_t)(cend - cbeg) + 3) * sizeof(int)), n = 0, k;
+    c[0] = 0;
+    for (k = cbeg; k <= cend; ++k)
+        if (text[k] != '-') c[++n] = k - cbeg + 1;
+    *cols = c;
+    return n;
+}
+
+/* the two copies of a sequence disagree at a base: the reference's report (mz_preyama.c:361-383: plain stderr, no
+ * program name) and exit(1) */
+static void report_disagreement(char x, char y, int pos, const struct mafComp *r1, int cb1, int ce1,
+                                const struct mafComp *r2, int cb2, int ce2, int which_file)
+{
+    const struct mafComp *rows[2] = { r1, r2 };
+    const int lo[2] = { cb1, cb2 }, hi[2] = { ce1, ce2 };
+    int w, k;
     fprintf(stderr, "%c != %c\n", x, y);
-    fprintf(stderr, "in file 1, positions %d... of %s are:\n  ", pos, c1->src);
-    for (i = cbeg1; i <= cend1; ++i)
-        if ((z = c1->text[i]) != '-') fputc(z, stderr);
-    fputc('\n', stderr);
-    fprintf(stderr, "while in file %d they are:\n  ", file2);
-    for (i = cbeg2; i <= cend2; ++i)
-        if ((z = c2->text[i]) != '-') fputc(z, stderr);
-    fputc('\n', stderr);
+    fprintf(stderr, "in file 1, positions %d... of %s are:\n  ", pos, r1->src);
+    for (w = 0; w < 2; ++w) {
+        if (w == 1) fprintf(stderr, "while in file %d they are:\n  ", which_file);
+        for (k = lo[w]; k <= hi[w]; ++k)
+            if (rows[w]->text[k] != '-') fputc(rows[w]->text[k], stderr);
+        fputc('\n', stderr);
+    }
     exit(1);
+}
+
+static int count_rows(const struct mafAli *a) { int n = 0; const struct mafComp *c; for (c = a->components; c; c = c->next) ++n; return n; }
+
+/* top rows of the pairwise block and of a multi-row block must be the same sequence (messages of mz_preyama.c:403-418;
+ * `second`: the wording for a1's second row against a3) */
+static void same_sequence_or_die(const struct mafComp *p, const struct mafComp *q, const struct mafComp *size_shown, int second)
+{
+    if (strcmp(p->src, q->src) != 0)
+        mz_fatalf(second ? "pre_yama: first rows (2) for sequences %s != %s" : "pre_yama: first rows for sequences %s != %s", p->src, q->src);
+    if (p->srcSize != q->srcSize)
+        mz_fatalf(second ? "pre_yama: first row (2) srcSizes %d != %d" : "pre_yama: first row srcSizes %d != %d", p->srcSize, size_shown->srcSize);
+    if (p->strand != q->strand)
+        mz_fatalf(second ? "pre_yama: first rows (2) on opposite strands" : "pre_yama: first rows on opposite strands");
 }
 
 struct mafAli *pre_yama2(struct mafAli *a1, struct mafAli *a2, struct mafAli *a3, int beg1, int end1,
                          int begN, int endN, int radius, struct pwuAliFiles *pws)
 {
-    struct mafAli *val;
-    struct mafComp *c, *c1, *c2, *c3, *d;
-    int cbeg1, cend1, cbeg2, cend2, cbeg3, cend3, i, j, k, M, N, K, L, M_new, *LB, *RB;
-    uchar **A, **B, **AL_new;
+    typedef int (*agree_fn)(struct mafAli *, struct mafAli *, int, int, int, int, struct pwuAliFiles *);
+    struct mafComp *X = a1->components, *Y = X ? X->next : NULL, *topA, *topB, *c;
+    struct mafAli *blk;
+    mz_job job;
+    uchar **A, **B, *flat;
+    int *colA, *colB, *LB, *RB;
+    int cb1, ce1, cbA, ceA, cbB, ceB, K, L, M, N, nA, nB, tx = 0, ty = 0, k, r, om;
+    agree_fn agree;
 
-    if ((c = a1->components) == NULL || (c1 = c->next) == NULL) mz_fatalf("pre_yama: cannot find c and c1");
-    if (c1->next != NULL) mz_fatalf("pre_yama: a1 is not a pairwise alignment");
-    for (d = c2 = a2->components, K = 0; d != NULL; ++K, d = d->next)
-        ;
-    for (d = c3 = a3->components, L = 0; d != NULL; ++L, d = d->next)
-        ;
+    if (!X || !Y) mz_fatalf("pre_yama: cannot find c and c1");
+    if (Y->next) mz_fatalf("pre_yama: a1 is not a pairwise alignment");
+    K = count_rows(a2); L = count_rows(a3);
     if (K == 0 || L == 0) mz_fatalf("pre_yama: an alignment has 0 rows");
-    if (strcmp(c->src, c2->src) != 0) mz_fatalf("pre_yama: first rows for sequences %s != %s", c->src, c2->src);
-    if (c->srcSize != c2->srcSize)          /* (the reference prints c1's size as the second number) */
-        mz_fatalf("pre_yama: first row srcSizes %d != %d", c->srcSize, c1->srcSize);
-    if (c->strand != c2->strand) mz_fatalf("pre_yama: first rows on opposite strands");
-    if (strcmp(c1->src, c3->src) != 0) mz_fatalf("pre_yama: first rows (2) for sequences %s != %s", c1->src, c3->src);
-    if (c1->srcSize != c3->srcSize) mz_fatalf("pre_yama: first row (2) srcSizes %d != %d", c1->srcSize, c3->srcSize);
-    if (c1->strand != c3->strand) mz_fatalf("pre_yama: first rows (2) on opposite strands");
+    topA = a2->components; topB = a3->components;
+    same_sequence_or_die(X, topA, Y, 0);          /* (the reference prints Y's size as the second number here) */
+    same_sequence_or_die(Y, topB, topB, 1);
 
-    cbeg1 = mafPos2Col(c, beg1, a1->textSize);
-    cend1 = mafPos2Col(c, end1, a1->textSize);
-    if (cbeg1 != mafPos2Col(c1, begN, a1->textSize)) mz_fatalf("pre_yama: mismatch of beg1 and begN");
-    if (cend1 != mafPos2Col(c1, endN, a1->textSize)) mz_fatalf("pre_yama: mismatch of end1 and endN");
-    cbeg2 = mafPos2Col(c2, beg1, a2->textSize);
-    cend2 = mafPos2Col(c2, end1, a2->textSize);
-    cbeg3 = mafPos2Col(c3, begN, a3->textSize);
-    cend3 = mafPos2Col(c3, endN, a3->textSize);
+    cb1 = mafPos2Col(X, beg1, a1->textSize); ce1 = mafPos2Col(X, end1, a1->textSize);
+    if (cb1 != mafPos2Col(Y, begN, a1->textSize)) mz_fatalf("pre_yama: mismatch of beg1 and begN");
+    if (ce1 != mafPos2Col(Y, endN, a1->textSize)) mz_fatalf("pre_yama: mismatch of end1 and endN");
+    cbA = mafPos2Col(topA, beg1, a2->textSize); ceA = mafPos2Col(topA, end1, a2->textSize);
+    cbB = mafPos2Col(topB, begN, a3->textSize); ceB = mafPos2Col(topB, endN, a3->textSize);
 
-    {   /* the executable's (weak reference, bound when the library is loaded) or one loaded later (tests) */
-        typedef int (*agree_fn)(struct mafAli *, struct mafAli *, int, int, int, int, struct pwuAliFiles *);
-        agree_fn agree = connectionAgreement2 ? connectionAgreement2 : (agree_fn)dlsym(RTLD_DEFAULT, "connectionAgreement2");
-        if (!agree) mz_fatalf("pre_yama2: connectionAgreement2() (align_util.c) is not linked in");
-        if (agree(a2, a3, cbeg2, cend2, cbeg3, cend3, pws) == 0) return NULL;
-    }
+    /* the caller's connectionAgreement2() (align_util.c): bound when the library was loaded, or found now */
+    agree = connectionAgreement2 ? connectionAgreement2 : (agree_fn)dlsym(RTLD_DEFAULT, "connectionAgreement2");
+    if (!agree) mz_fatalf("pre_yama2: connectionAgreement2() (align_util.c) is not linked in");
+    if (agree(a2, a3, cbA, ceA, cbB, ceB, pws) == 0) return NULL;
 
-    M = cend2 - cbeg2 + 1;
-    N = cend3 - cbeg3 + 1;
-    if ((M > N ? M : N) < 2) return NULL;
+    M = ceA - cbA + 1; N = ceB - cbB + 1;
+    if (M < 2 && N < 2) return NULL;
 
-    A = cols_new(M, K);
-    for (i = 1; i <= M; ++i)
-        for (j = 0, d = c2; j < K; ++j, d = d->next) A[i][j] = (uchar)d->text[cbeg2 + i - 1];
-    B = cols_new(N, L);
-    for (i = 1; i <= N; ++i)
-        for (j = 0, d = c3; j < L; ++j, d = d->next) B[i][j] = (uchar)d->text[cbeg3 + i - 1];
+    A = cols_new(M, K); B = cols_new(N, L);
+    for (r = 0, c = topA; r < K; ++r, c = c->next)
+        for (k = 1; k <= M; ++k) A[k][r] = (uchar)c->text[cbA + k - 1];
+    for (r = 0, c = topB; r < L; ++r, c = c->next)
+        for (k = 1; k <= N; ++k) B[k][r] = (uchar)c->text[cbB + k - 1];
+    nA = base_columns(topA->text, cbA, ceA, &colA);
+    nB = base_columns(topB->text, cbB, ceB, &colB);
 
-    /* the band: column k of a1 pairs column i of A with column j of B; for a given i, LB[i] / RB[i] are the least
-     * and greatest such j (mz_preyama.c:461-497) */
     LB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
     RB = (int *)xmalloc(((size_t)M + 1) * sizeof(int));
-    for (i = 0; i <= M; ++i) { LB[i] = 0; RB[i] = N; }
-    for (i = j = 0, k = cbeg1; k <= cend1; ++k) {
-        uchar x, y, z;
-        if ((x = (uchar)c->text[k]) != '-') {
-            do {
-                if (++i > M) mz_fatalf("pre_yama: bad scene");
-            } while ((z = A[i][0]) == '-');
-            rows_must_agree((char)x, (char)z, beg1, c, cbeg1, cend1, c2, cbeg2, cend2, 2);
+    for (k = 0; k <= M; ++k) { LB[k] = 0; RB[k] = N; }
+    for (k = cb1; k <= ce1; ++k) {
+        const char x = X->text[k], y = Y->text[k];
+        if (x != '-') {
+            if (++tx > nA) mz_fatalf("pre_yama: bad scene");
+            if (toupper((unsigned char)x) != toupper(A[colA[tx]][0])) report_disagreement(x, (char)A[colA[tx]][0], beg1, X, cb1, ce1, topA, cbA, ceA, 2);
         }
-        if ((y = (uchar)c1->text[k]) != '-') {
-            do {
-                if (++j > N) mz_fatalf("pre_yama: ouch");
-            } while ((z = B[j][0]) == '-');
-            rows_must_agree((char)y, (char)z, begN, c1, cbeg1, cend1, c3, cbeg3, cend3, 3);
+        if (y != '-') {
+            if (++ty > nB) mz_fatalf("pre_yama: ouch");
+            if (toupper((unsigned char)y) != toupper(B[colB[ty]][0])) report_disagreement(y, (char)B[colB[ty]][0], begN, Y, cb1, ce1, topB, cbB, ceB, 3);
         }
-        if (LB[i] == 0) LB[i] = j;
-        RB[i] = j;
+        if (LB[colA[tx]] == 0) LB[colA[tx]] = colB[ty];
+        RB[colA[tx]] = colB[ty];
     }
-    if (i != M || j != N) mz_fatalf("pre_yama: i = %d, M = %d, j = %d, N = %d", i, M, j, N);
+    if (colA[tx] != M || colB[ty] != N) mz_fatalf("pre_yama: i = %d, M = %d, j = %d, N = %d", colA[tx], M, colB[ty], N);
+    free(colA); free(colB);
 
     smooth(LB, RB, M, N, radius);
-    yama(A, K, M, B, L, N, LB, RB, &AL_new, &M_new);
-    val = mafBuild(AL_new, K + L, M_new, a2, cbeg2, a3, cbeg3, 1);
-
-    cols_free(AL_new); cols_free(A); cols_free(B);
+    job.K = K; job.L = L; job.M = M; job.N = N; job.A = A[1]; job.B = B[1]; job.LB = LB; job.RB = RB;
+    mz_py_run_one(&job, &flat, &om);
+    {
+        uchar **merged = cols_wrap(flat, om, K + L);
+        blk = mafBuild(merged, K + L, om, a2, cbA, a3, cbB, 1);
+        cols_free(merged);
+    }
+    cols_free(A); cols_free(B);
     free(LB); free(RB);
-    return val;
+    return blk;
 }
