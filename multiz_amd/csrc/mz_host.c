@@ -754,127 +754,49 @@ static int chunk_collect(chunk *c)
 /* A batch of any size on ONE context: chunks of 1 Ki - 16 Ki pairs / at most ~1 GB of input columns go through four
  * rotating sets of staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
  * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit.
- * Three host threads work a chunk's three steps as an assembly line -- the packer (chunk_upload: pack into pinned
- * memory, H2D, plan, the plan's totals back), the calling thread (chunk_launch: workspaces, kernels, D2H) and the
- * collector (chunk_collect: unpack into the caller's outs) -- so packing chunk k+2, the kernels of chunk k+1 and the
- * unpacking of chunk k overlap with one another and with both PCIe directions; a buffer set is reused once its chunk
- * is collected.  (The first version ran the three steps of successive chunks in turn on one thread: the host's own
- * pack / unpack time and its waits added up, 17 ms per 50 000 C2 pairs against 10-11 ms here.)
- * On a device error everything in flight is drained and every pair not yet collected is left marked MZ_E_DEVICE with
- * cols == NULL (mz_yama_batch() pre-marks all of them), so a caller may clean up outs. */
-typedef struct pipeline {
-    mz_ctx *X;
-    int n, max_pairs;
-    const mz_job *jobs;
-    mz_out *outs;
-    chunk ck[MZ_SETS];
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    int uploaded, launched, collected;       /* chunks through each step */
-    int total;                               /* chunks in all; -1 until the packer has cut the last one */
-    int err, failed;
-    char errmsg[512];
-} pipeline;
-
-static void pipe_fail(pipeline *P)
-{
-    pthread_mutex_lock(&P->mu);
-    if (!P->err) { P->err = 1; snprintf(P->errmsg, sizeof P->errmsg, "%s", g_err); }
-    pthread_cond_broadcast(&P->cv);
-    pthread_mutex_unlock(&P->mu);
-}
-
-static void *pipe_packer(void *arg)
-{
-    pipeline *P = (pipeline *)arg;
-    int k = 0, first = 0;
-    if (hipSetDevice(P->X->device) != hipSuccess) { set_err("hipSetDevice(%d) failed", P->X->device); pipe_fail(P); return NULL; }
-    while (first < P->n) {
-        size_t bytes = 0;
-        int m = 0;
-        while (first + m < P->n && m < P->max_pairs && bytes < ((size_t)1 << 30)) {
-            const mz_job *j = &P->jobs[first + m];
-            if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1)
-                bytes += (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1);
-            ++m;
-        }
-        pthread_mutex_lock(&P->mu);
-        while (!P->err && k - P->collected >= MZ_SETS) pthread_cond_wait(&P->cv, &P->mu);     /* its buffer set is free again */
-        if (P->err) { pthread_mutex_unlock(&P->mu); return NULL; }
-        pthread_mutex_unlock(&P->mu);
-        if (chunk_upload(P->X, &P->ck[k % MZ_SETS], k % MZ_SETS, m, P->jobs + first, P->outs + first)) { pipe_fail(P); return NULL; }
-        first += m; ++k;
-        pthread_mutex_lock(&P->mu);
-        P->uploaded = k;
-        if (first >= P->n) P->total = k;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-    return NULL;
-}
-
-static void *pipe_collector(void *arg)
-{
-    pipeline *P = (pipeline *)arg;
-    int k = 0, rc;
-    if (hipSetDevice(P->X->device) != hipSuccess) { set_err("hipSetDevice(%d) failed", P->X->device); pipe_fail(P); return NULL; }
-    for (;; ++k) {
-        pthread_mutex_lock(&P->mu);
-        while (!P->err && P->launched <= k && !(P->total >= 0 && k >= P->total)) pthread_cond_wait(&P->cv, &P->mu);
-        if (P->err || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); return NULL; }
-        pthread_mutex_unlock(&P->mu);
-        rc = chunk_collect(&P->ck[k % MZ_SETS]);
-        if (rc < 0) { pipe_fail(P); return NULL; }
-        pthread_mutex_lock(&P->mu);
-        P->failed += rc;
-        P->collected = k + 1;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-}
-
+ * Up to four chunks are in flight on four buffer sets and streams: while chunk k is uploaded and planned the host
+ * packs chunk k+1; when the plan's totals of chunk k are in, its kernels and the copy of its results are issued;
+ * chunk k-1 is computing or copying back; chunk k-2 is unpacked.  The host does not wait for a copy or a kernel it
+ * could work beside.  On a device error everything in flight is drained and every pair not yet collected is left
+ * marked MZ_E_DEVICE with cols == NULL (mz_yama_batch() pre-marks all of them), so a caller may clean up outs. */
 static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int max_pairs)
 {
-    pipeline P;
-    pthread_t tp, tc;
-    int k, s, have_p, have_c;
+    chunk ck[MZ_SETS];
+    int k = 0, up = 0, done = 0, failed = 0, rc = 0, s;
+#define NEXT_CHUNK(first, count) do { size_t bytes_ = 0; int m_ = 0; \
+        while ((first) + m_ < n && m_ < max_pairs && bytes_ < ((size_t)1 << 30)) { \
+            const mz_job *j_ = &jobs[(first) + m_]; \
+            if (j_->K >= 1 && j_->L >= 1 && j_->M >= 1 && j_->N >= 1) \
+                bytes_ += (size_t)j_->K * j_->M + (size_t)j_->L * j_->N + 8 * ((size_t)j_->M + 1); \
+            ++m_; } (count) = m_; } while (0)
+#define STEP(call) do { rc = (call); if (rc < 0) goto fail; } while (0)
     if (hipSetDevice(X->device) != hipSuccess) return set_err("hipSetDevice(%d) failed", X->device);
-    if (n <= max_pairs) {                                  /* one chunk (yama() itself, small calls): no threads */
-        chunk c;
-        int rc;
-        if (chunk_upload(X, &c, 0, n, jobs, outs) || chunk_launch(&c) || (rc = chunk_collect(&c)) < 0) {
-            if (X->bstream[0]) hipStreamSynchronize(X->bstream[0]);
-            return -1;
+    {
+        int m0;
+        NEXT_CHUNK(0, m0);
+        STEP(chunk_upload(X, &ck[0], 0, m0, jobs, outs));
+        up = m0;
+    }
+    for (k = 0; done < n; ++k) {
+        chunk *cur = &ck[k % MZ_SETS];
+        if (up < n) {                                    /* pack + upload the next chunk beside this one's copy */
+            int m1;
+            NEXT_CHUNK(up, m1);
+            STEP(chunk_upload(X, &ck[(k + 1) % MZ_SETS], (k + 1) % MZ_SETS, m1, jobs + up, outs + up));
+            up += m1;
         }
-        return rc;
+        STEP(chunk_launch(cur));
+        if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
+        done += cur->n;
     }
-    memset(&P, 0, sizeof P);
-    P.X = X; P.n = n; P.jobs = jobs; P.outs = outs; P.max_pairs = max_pairs; P.total = -1;
-    pthread_mutex_init(&P.mu, NULL);
-    pthread_cond_init(&P.cv, NULL);
-    have_p = pthread_create(&tp, NULL, pipe_packer, &P) == 0;
-    have_c = have_p && pthread_create(&tc, NULL, pipe_collector, &P) == 0;
-    if (!have_p || !have_c) { set_err("cannot start the host threads of the chunk pipeline"); pipe_fail(&P); }
-    for (k = 0; ; ++k) {                                   /* this thread: the kernels of chunk k as soon as its plan is in */
-        pthread_mutex_lock(&P.mu);
-        while (!P.err && P.uploaded <= k && !(P.total >= 0 && k >= P.total)) pthread_cond_wait(&P.cv, &P.mu);
-        if (P.err || (P.total >= 0 && k >= P.total)) { pthread_mutex_unlock(&P.mu); break; }
-        pthread_mutex_unlock(&P.mu);
-        if (chunk_launch(&P.ck[k % MZ_SETS])) { pipe_fail(&P); break; }
-        pthread_mutex_lock(&P.mu);
-        P.launched = k + 1;
-        pthread_cond_broadcast(&P.cv);
-        pthread_mutex_unlock(&P.mu);
-    }
-    if (have_p) pthread_join(tp, NULL);
-    if (have_c) pthread_join(tc, NULL);
-    pthread_mutex_destroy(&P.mu);
-    pthread_cond_destroy(&P.cv);
-    if (P.err) {
-        for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
-        return set_err("%s", P.errmsg);
-    }
-    return P.failed;
+    if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
+    STEP(chunk_collect(&ck[(k - 1) % MZ_SETS])); failed += rc;
+    return failed;
+fail:
+    for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
+    return -1;
+#undef NEXT_CHUNK
+#undef STEP
 }
 
 /* host thread of one further GPU (mz_yama_batch with several contexts) */
@@ -924,11 +846,10 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     use = g_ndev;
     while (use > 1 && n / use < MZ_MULTI_MIN) --use;
     {
-        /* chunk size: about an eighth of a GPU's share, so that even a few thousand pairs overlap their copies, their
-         * kernels and the host's packing, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU)
-         * and at most 16 Ki */
+        /* chunk size: about a quarter of a GPU's share, so that even a few thousand pairs overlap their copies with
+         * their kernels, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU) and at most 16 Ki */
         const int share = (n + use - 1) / use;
-        max_pairs = env_pairs ? env_pairs : (share + 7) / 8 < 1024 ? 1024 : (share + 7) / 8 > 16384 ? 16384 : (share + 7) / 8;
+        max_pairs = env_pairs ? env_pairs : (share + 3) / 4 < 1024 ? 1024 : (share + 3) / 4 > 16384 ? 16384 : (share + 3) / 4;
     }
     if (use == 1) {
         g_copy_threads = MZ_COPY_THREADS;
