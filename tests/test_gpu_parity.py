@@ -142,7 +142,7 @@ def _hash(cols, om):
     return mo.fnv1a_np(cols, mo.fnv1a_np(np.array([om], dtype=np.int32).view(np.uint8)))
 
 
-@pytest.mark.parametrize("cfg,pairs", [("c2", 3000), ("c3", 120)])
+@pytest.mark.parametrize("cfg,pairs", [("c2", 10000), ("c3", 1000)])
 def test_config_sized_batches_device_resident(mz, cfg, pairs):
     # BASELINE.json shapes through the device-resident API (what bench.py times): every pair against the
     # oracle by hash of (OM, merged columns), plus the size-independent properties of the merge
@@ -154,7 +154,7 @@ def test_config_sized_batches_device_resident(mz, cfg, pairs):
     db.run()
     res = db.results()
     assert (res["status"] == 0).all()
-    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=8)
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
     assert bad == 0 and cells == int(res["cells"].sum())
     host_out = db.out.cpu().numpy()
     for i in range(pairs):
@@ -314,17 +314,19 @@ def test_pipelined_batches_rotating_workspaces(mz):
 
 
 def test_long_block_regime(mz):
-    # configs[4] shape (R=30, ~100k x 100k columns): traceback spills to HBM (6 MB per pair)
+    # configs[4] shape (R=30, ~100k x 100k columns): traceback spills to HBM (6 MB per pair); 64 pairs of the batch
     from multiz_amd import synth
-    batch = synth.make_batch(3, 2, 2, 95000, 105000, 30, first_pair=3)
+    npairs = 64
+    batch = synth.make_batch(npairs, 2, 2, 95000, 105000, 30, first_pair=3)
     _kernels(mz, 2)
     db = mz.DevBatch(batch)
     db.run()
     res = db.results()
     assert (res["status"] == 0).all()
-    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=3)
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
+    assert bad == 0 and cells == int(res["cells"].sum())
     host_out = db.out.cpu().numpy()
-    for i in range(3):
+    for i in range(npairs):
         m_, o0 = int(res["om"][i]), int(res["offOut"][i])
         assert m_ == om[i] and _hash(host_out[o0: o0 + m_ * 4], m_) == int(hs[i])
     # these pairs run on the row-parallel kernels, whose scores are re-based every 64 rows: the final triple
@@ -401,6 +403,124 @@ def test_blocks_of_more_than_127_rows(mz):
     for p, r in zip(mixed, mz.yama_batch(mixed)):
         w = mo.yama(*p, variant="profile")
         assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols)
+
+
+def _indel_band_pair(rng, rate, mean_len=3.0):
+    """C2-shaped pair whose band is what pre_yama derives from blocks with indels against the shared reference row
+    (mz_preyama.c:240-258, then smooth): the centre stands still over columns only the first block has and jumps over
+    columns only the second block has"""
+    M = int(rng.integers(900, 1101))
+    centre = np.zeros(M + 1, dtype=np.int64)
+    c, i = 0, 1
+    while i <= M:
+        u = rng.random()
+        if u < rate / 2 and i > 1:
+            for _ in range(min(int(rng.geometric(1.0 / mean_len)), M - i + 1)):
+                centre[i] = c; i += 1
+            continue
+        if u < rate:
+            c += int(rng.geometric(1.0 / mean_len))
+        c += 1
+        centre[i] = c; i += 1
+    N = int(max(c, 11))
+    LB = np.minimum(centre, N).astype(np.int32); RB = LB.copy(); LB[0] = 0; RB[M] = N
+    LB, RB = mo.smooth(LB, RB, M, N, 30)
+    A = inputs.random_block(rng, M, 2, dash=0.08, odd=0.05)
+    return A, inputs.noisy_copy(rng, A, N, 2, dash=0.08), LB, RB
+
+
+@pytest.mark.parametrize("events", [2, 10, 30])
+def test_bands_with_indels(mz, events):
+    # Real MAF blocks: insertions in either block widen the rows or heighten the columns of the band around them, so
+    # pairs leave the row-parallel kernels (rows <= 63 wide or columns <= 63 high) for the tagged wavefront as the indel
+    # rate grows.  Every pair, whatever kernel the plan picks, against the oracle by hash; the mix is reported by
+    # tests/tools/indel_bands.py (DESIGN.md section 8)
+    from multiz_amd import synth
+    rng = np.random.default_rng(100 + events)
+    n = 1500
+    pairs = [_indel_band_pair(rng, events / 1000.0) for _ in range(n)]
+    batch = synth.pack_pairs(pairs)
+    _kernels(mz, 2)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    hist = np.bincount(res["mode"], minlength=13)
+    assert hist[3] + hist[5] + hist[6] == n, hist                       # tagged wavefront, ROW, COL
+    if events >= 10:
+        assert hist[3] > n // 2                                         # (the open item: most such pairs are off the row kernels)
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
+    assert bad == 0 and cells == int(res["cells"].sum())
+    out = db.out.cpu().numpy()
+    for i in range(n):
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == om[i] and _hash(out[o0: o0 + m_ * 4], m_) == int(hs[i]), (i, int(res["mode"][i]))
+
+
+def test_pipelined_form_from_a_cold_start():
+    # mz_dev_run_async() as the FIRST call of a process (its helper streams are created on first use) and again after
+    # mz_finalize(): results equal the serial form's
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+import multiz_amd as mz
+from multiz_amd import synth
+batch = synth.make_batch(400, 2, 2, 200, 400, 30, first_pair=5)
+for rep in range(2):
+    mz.api.init(0)
+    a = mz.DevBatch(batch); b = a.alternate()
+    for k in range(4): (a, b)[k % 2].run_async()
+    a.wait()
+    ra, rb = a.results(), b.results()
+    ref = mz.DevBatch(batch); ref.run(); r0 = ref.results()
+    for r in (ra, rb):
+        assert np.array_equal(r["om"], r0["om"]) and np.array_equal(r["final3"], r0["final3"]) and (r["status"] == 0).all()
+    del a, b, ref
+    mz.lib().mz_finalize()
+print("cold ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, timeout=600)
+    assert p.returncode == 0 and b"cold ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+def test_score_tables_edited_in_place_are_noticed(mz):
+    # the caller's ss / gop are read at call time (mz_scores.h:8-11): a table changed IN PLACE -- same pointers -- must
+    # reach the GPU too (a checksum of the class scores, gop and gap_extend decides, not pointer identity)
+    lib = mz.lib()
+    rng = np.random.default_rng(8)
+    pairs = [inputs.make_pair(rng, 2, 2, 150, 160, 30, "diag", mo.smooth) for _ in range(6)]
+    lib.init_scores70()
+    before = mz.yama_batch(pairs)
+    ss = C.POINTER(C.POINTER(C.c_int)).in_dll(lib, "ss")
+    gap_extend = C.c_int.in_dll(lib, "gap_extend")
+    old = {}
+    try:
+        for x in b"Aa":
+            for y in b"Aa":
+                old[(x, y)] = ss[x][y]
+                ss[x][y] = 40                                          # A:A 91 -> 40, class structure kept
+        gap_extend.value = 45                                          # (the table's dash entries stay -30: the globals are read as they are)
+        sc = mo.scores70()                                             # the same edit on the oracle's copy of the tables
+        for x in b"Aa":
+            for y in b"Aa":
+                sc.ss[x][y] = 40
+        sc.gap_extend = 45
+        after = mz.yama_batch(pairs)
+        for p_, r in zip(pairs, after):
+            w = mo.yama(*p_, sc=sc)
+            assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols) and np.array_equal(r.score, w.final)
+        assert sum(not np.array_equal(a.score, b.score) for a, b in zip(before, after)) == len(pairs)
+    finally:
+        for (x, y), v in old.items():
+            ss[x][y] = v
+        gap_extend.value = 30
+        lib.init_scores70()
+    again = mz.yama_batch(pairs)
+    for a, b in zip(before, again):
+        assert np.array_equal(a.score, b.score) and np.array_equal(a.cols, b.cols)
 
 
 def test_empty_and_tiny_batches(mz):
