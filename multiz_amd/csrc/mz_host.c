@@ -962,7 +962,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
             hoScr[p] = (int64_t)os; os += 2 * ((size_t)j->N_all + 2) + 2 * ((size_t)j->M_all + 2);
             hoRow[p] = (int64_t)orow; orow += (size_t)j->K + j->L1 - 1;
         }
-#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
         for (p = 0; p < n; ++p) {
             const mz_prejob *j = &jobs[p];
             int k;
@@ -1023,7 +1023,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
         const int64_t *roff = (const int64_t *)(hres + 6 * al256(4 * (size_t)n)), *rsc = roff + al256(8 * (size_t)n) / 8;
         const int32_t *rsz = (const int32_t *)((const char *)rsc + al256(8 * (size_t)n));
         const uint8_t *rrows = (const uint8_t *)rsz + al256(4 * nrow);
-#pragma omp parallel for schedule(static) num_threads(MZ_COPY_THREADS) reduction(+:failed) reduction(|:oom) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(g_copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
         for (p = 0; p < n; ++p) {
             mz_preout *o = &outs[p];
             const int W = jobs[p].K + jobs[p].L1 - 1;
@@ -1050,16 +1050,11 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
     return failed;
 }
 
-int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
+/* a context's share of a call, in passes of at most ~1 GB of text */
+static int preyama_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs)
 {
-    int done = 0, failed = 0, a, b;
-    if (n <= 0) return 0;
-    pthread_mutex_lock(&g_big);
-    if (ensure_init() || sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
-    for (a = 0; a < 128; ++a)                              /* k_post's pair sums need ss[x][y] == ss[y][x] */
-        for (b = 0; b < a; ++b)
-            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); set_err("score table is not symmetric"); return -2; }
-    if (hipSetDevice(G.device) != hipSuccess) { pthread_mutex_unlock(&g_big); return set_err("hipSetDevice failed"); }
+    int done = 0, failed = 0;
+    if (hipSetDevice(X->device) != hipSuccess) return set_err("hipSetDevice(%d) failed", X->device);
     while (done < n) {
         size_t bytes = 0;
         int m = 0, rc;
@@ -1068,13 +1063,75 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
             bytes += (size_t)(j->K > 0 ? j->K : 0) * (size_t)(j->M_all > 0 ? j->M_all : 0) + (size_t)(j->L1 > 0 ? j->L1 : 0) * (size_t)(j->N_all > 0 ? j->N_all : 0);
             ++m;
         }
-        rc = preyama_pass(&G, m, jobs + done, outs + done);
-        if (rc < 0) { pthread_mutex_unlock(&g_big); return -1; }
+        rc = preyama_pass(X, m, jobs + done, outs + done);
+        if (rc < 0) return -1;
         failed += rc;
         done += m;
     }
-    pthread_mutex_unlock(&g_big);
     return failed;
+}
+
+typedef struct pre_task { mz_ctx *X; int n, rc; const mz_prejob *jobs; mz_preout *outs; char err[600]; } pre_task;
+static void *pre_worker(void *arg)
+{
+    pre_task *t = (pre_task *)arg;
+    t->rc = preyama_on_ctx(t->X, t->n, t->jobs, t->outs);
+    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, g_err);
+    return NULL;
+}
+
+int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
+{
+    int failed = 0, a, b, use, rc, p;
+    if (n <= 0) return 0;
+    pthread_mutex_lock(&g_big);
+    if (ensure_init() || sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+    for (a = 0; a < 128; ++a)                              /* k_post's pair sums need ss[x][y] == ss[y][x] */
+        for (b = 0; b < a; ++b)
+            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); set_err("score table is not symmetric"); return -2; }
+    for (p = 0; p < n; ++p) { memset(&outs[p], 0, sizeof outs[p]); outs[p].status = MZ_E_DEVICE; }
+    use = g_ndev;
+    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
+    if (use == 1) {
+        rc = preyama_on_ctx(&G, n, jobs, outs);
+        pthread_mutex_unlock(&g_big);
+        return rc;
+    }
+    {
+        /* several GPUs: contiguous ranges of about equal text volume, one host thread per GPU (as mz_yama_batch) */
+        pre_task task[MZ_MAX_DEV];
+        pthread_t th[MZ_MAX_DEV];
+        double total = 0.0, acc = 0.0;
+        int d = 0, start = 0, started[MZ_MAX_DEV];
+        for (p = 0; p < n; ++p) total += (double)jobs[p].K * jobs[p].M_all + (double)jobs[p].L1 * jobs[p].N_all;
+        for (p = 0; p < n && d < use; ++p) {
+            acc += (double)jobs[p].K * jobs[p].M_all + (double)jobs[p].L1 * jobs[p].N_all;
+            if (d == use - 1) { p = n - 1; acc = total; }
+            if (acc >= total * (d + 1) / use || p == n - 1) {
+                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
+                task[d].n = p + 1 - start; task[d].rc = 0; task[d].err[0] = 0;
+                start = p + 1; ++d;
+            }
+        }
+        use = d;
+        g_copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
+        for (d = 1; d < use; ++d) {
+            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, pre_worker, &task[d]) == 0;
+            if (!started[d] && task[d].n > 0) pre_worker(&task[d]);
+        }
+        if (task[0].n > 0) pre_worker(&task[0]);
+        rc = 0;
+        for (d = 0; d < use; ++d) {
+            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
+            if (task[d].n <= 0) continue;
+            if (task[d].rc < 0) { rc = -1; set_err("%s", task[d].err); }
+            else failed += task[d].rc;
+        }
+        hipSetDevice(G.device);
+        g_copy_threads = MZ_COPY_THREADS;
+        pthread_mutex_unlock(&g_big);
+        return rc < 0 ? -1 : failed;
+    }
 }
 
 /* ------------------------------------------------------------------ yama(): a batch of one */

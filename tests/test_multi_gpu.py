@@ -50,6 +50,27 @@ for rep in range(2):
         assert mo.fnv1a_np(got, mo.fnv1a_np(np.array([om[i]], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
     api.free_outs(outs)
 assert lib.mz_device_count() == (2 if mode == "dup" else 1)
+if mode == "dup":
+    # block text in / block text out over both contexts (mz_preyama_batch): 60 distinct block pairs, 4 800 jobs
+    import inputs
+    from test_preyama import _prejob, _assemble, same_block
+    rng = np.random.default_rng(3)
+    base = []
+    while len(base) < 60:
+        a1, a2, beg, end = inputs.random_block_pair(rng, int(rng.integers(1, 5)), int(rng.integers(2, 5)), int(rng.integers(80, 400)))
+        if end - beg < 12:
+            continue
+        try:
+            want, _ = mo.pre_yama(a1, a2, beg, end, 30, 1)
+        except RuntimeError:
+            continue
+        j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
+        base.append((j, a1, cb1, a2, cb2, want))
+    jobs = [base[i % 60][0] for i in range(4800)]
+    res = mz.preyama_batch(jobs)
+    for i, r in enumerate(res):
+        j, a1, cb1, a2, cb2, want = base[i % 60]
+        assert r["status"] == 0 and same_block(_assemble(r, a1, cb1, a2, cb2), want), i
 print("multi ok")
 '''
 
