@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmzamd.so")
+LIB_PATH = os.environ.get("MZ_LIB_PATH") or os.path.join(HERE, "libmzamd.so")     # (MZ_LIB_PATH: experimental builds, tests/tools)
 CSRC = os.path.join(HERE, "csrc")
 
 MZ_STATUS = {0: "ok", 1: "termination", 2: "narrow", 3: "lb_mono", 4: "rb_mono", 5: "traceback", 6: "emit",
