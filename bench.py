@@ -110,10 +110,15 @@ def cpu_leg(spec_path):
     om, hs, ccells, bad = run_cpu(sample)
     cpu_s = time.perf_counter() - t
     np.savez(spec["out"], idx=idx, om=om, hs=hs)
+    # one thread, for the record (SURVEY 8d asks for both): a few pairs, ~2 s
+    one = synth.subset(batch, idx[: max(1, min(len(idx), int(2.0 / max(per_pair * cores, 1e-6))))])
+    t = time.perf_counter()
+    _, _, cells1, _ = (mo.ref_batch(one, threads=1) if use_ref else mo.yama_batch(one, variant=0, threads=1))
+    one_s = time.perf_counter() - t
     what = ("reference yama() (oracle/_ref/libref.so, gcc -O2 -fcommon)" if use_ref
             else "oracle faithful O(K*L)/cell restatement (gcc -O2)")
     print(json.dumps({"value": round(ccells / cpu_s / 1e9, 5), "unit": "GCUPS", "cores": cores, "model": model,
-                      "kind": "reference" if use_ref else "port", "bad": int(bad),
+                      "kind": "reference" if use_ref else "port", "bad": int(bad), "one_thread": round(cells1 / one_s / 1e9, 5),
                       "sample": f"{nsample} of the {pairs} pairs (seeded), {ccells} band cells in {cpu_s:.1f} s; {what}, "
                                 f"OpenMP one pair per thread on the {cores} physical cores of one socket"}))
 
