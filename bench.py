@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The pipelined form keeps up to nine HIP streams busy (DPs of consecutive small batches side by side, plan, walk + emit);
+# the runtime maps streams onto 4 hardware queues by default and streams sharing a queue serialise.  Must be in the
+# environment before the HIP runtime starts (torch starts it here, before the library could).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # PMC figures of one launch of the dominant kernel on the DEFAULT c2 batch (50 000 pairs), from the separate rocprofv3
@@ -243,7 +247,10 @@ def main():
         batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=rank * pairs)
         db = mz.DevBatch(batch, device=dev)                      # inputs now resident in HBM
         pairs_here = pairs
-    ring = [db, db.alternate(), db.alternate()]                  # three rotating workspaces for the pipelined form
+    # rotating workspaces for the pipelined form: three, or one more than the batches whose DPs the library runs side by
+    # side when a batch is too small to fill the GPU (c3: 5 000 pairs, c5: 1 000)
+    nws = max(3, api.lib().mz_dev_pipeline_depth(pairs_here) + 1)
+    ring = [db] + [db.alternate() for _ in range(nws - 1)]
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -265,16 +272,16 @@ def main():
     # the closing synchronisation.  The parity gate below checks what these pipelined steps left in EVERY
     # workspace they used.
     for i in range(args.warmup):
-        ring[i % 3].run_async()
+        ring[i % nws].run_async()
     db.wait()
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ring[(args.warmup + i) % 3].run_async()
+        ring[(args.warmup + i) % nws].run_async()
     db.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    workspaces = ring[:min(3, args.warmup + args.steps)]
+    workspaces = ring[:min(nws, args.warmup + args.steps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -234,11 +234,14 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4]);
  * batches.  Calls in flight at the same time must use different workspaces (tbw/script/out/prep and the plan
  * arrays); the library keys a workspace by its tbw pointer and orders its reuse after the walk/emit of the
  * batch that used it last (at most 8 workspaces in rotation).  Three rotating workspaces keep everything but
- * the DP off the critical path; two work, with less overlap.  The batch's inputs must be complete when the
+ * the DP off the critical path; two work, with less overlap (small batches: mz_dev_pipeline_depth() + 1).  The batch's inputs must be complete when the
  * call is made, or ready_event (a hipEvent_t recorded after their producer) must be given; NULL otherwise.
  * mz_dev_wait() makes `stream` wait for everything issued so far; results of a batch are valid after it. */
 int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event);
 int mz_dev_wait(void *stream);
+/* Batches of at most 16 Ki pairs do not fill the GPU on their own: mz_dev_run_async() runs the DPs of up to this many
+ * consecutive batches side by side (on its own streams beside `stream`).  Rotate one workspace more than this. */
+int mz_dev_pipeline_depth(int n);
 
 #ifdef __cplusplus
 }

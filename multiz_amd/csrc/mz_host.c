@@ -78,6 +78,8 @@ typedef struct mz_ctx {
     hipStream_t stream;
     hipStream_t stream2;                   /* pipelined form: traceback walk + emit of batch k beside the DP of batch k+1 */
     hipStream_t stream3;                   /* pipelined form: plan of batch k+1 beside the DP of batch k */
+    hipStream_t stream_dp[4];              /* pipelined form, small batches: the DPs of consecutive batches side by side */
+    unsigned dp_turn;
     hipEvent_t ev[5];
     hipEvent_t evs[MZ_SLICES + 1];
     int scores_ok;                         /* the device's copy of the score model is current */
@@ -163,6 +165,7 @@ static void ctx_close(mz_ctx *X)
     for (i = 0; i < MZ_WS_MAX; ++i) if (X->ws[i].used) { hipEventDestroy(X->ws[i].done); X->ws[i].used = 0; }
     if (X->stream2) { hipStreamSynchronize(X->stream2); hipStreamDestroy(X->stream2); }
     if (X->stream3) { hipStreamSynchronize(X->stream3); hipStreamDestroy(X->stream3); }
+    for (i = 0; i < 4; ++i) if (X->stream_dp[i]) { hipStreamSynchronize(X->stream_dp[i]); hipStreamDestroy(X->stream_dp[i]); X->stream_dp[i] = NULL; }
     hipStreamDestroy(X->stream);
     X->ready = 0;
 }
@@ -172,6 +175,10 @@ static void ctx_close(mz_ctx *X)
 static int init_devices(int ngpu, const int *devices, int first)
 {
     int count = 0, i, j;
+    /* the pipelined form keeps up to nine streams busy; the HIP runtime multiplexes streams onto 4 hardware queues
+     * unless told otherwise, and streams that share a queue run one after the other (C5: 313 -> 381 GCUPS with 8).
+     * Effective only if the runtime is not up yet; an application that starts it first sets the variable itself. */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return set_err("no HIP device available (this library has no CPU path)");
     if (ngpu < 1 || ngpu > MZ_MAX_DEV) return set_err("mz_init_multi: %d GPUs requested (1..%d supported)", ngpu, MZ_MAX_DEV);
@@ -472,6 +479,19 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
  * on `stream`, so the batch's inputs must be complete when the call is made, or `ready_event` (a hipEvent_t
  * recorded after their producer) must be given.  mz_dev_wait() makes `stream` wait for everything issued. */
 
+/* how many batches of n pairs should be in flight for the GPU to be busy: their DPs run side by side on that many
+ * streams (mz_dev_run_async); a caller rotates one workspace more than that.  MZ_DP_STREAMS=<k> overrides. */
+int mz_dev_pipeline_depth(int n)
+{
+    static int forced = -1;
+    int d;
+    if (forced < 0) { const char *e = getenv("MZ_DP_STREAMS"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return forced > 5 ? 5 : forced;
+    if (n > 16384 || n <= 0) return 1;
+    d = (5 * 1024 + n - 1) / n;                      /* waves wanted: five per SIMD, 1024 SIMDs */
+    return d < 2 ? 2 : d > 5 ? 5 : d;
+}
+
 int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
 {
     hipStream_t s;
@@ -496,9 +516,26 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
     if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.evs[3], G.stream3));
-    HIPCK(hipStreamWaitEvent(s, G.evs[3], 0));
-    if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
-    HIPCK(hipEventRecord(G.evs[2], s));
+    /* Small batches -- at most a few waves per SIMD: the 1 000 long pairs of C5, the 5 000 of C3 -- leave the GPU
+     * half empty while their last waves finish, and a lone wave per SIMD is latency-bound throughout (section 4.1 of
+     * 14.9 / 8.3 / 6.6 / 5.35 / 5.27 ms per C2 batch at 1..5 waves per SIMD).  Their DPs therefore go round
+     * up to five streams (the caller's and four of the library's), so that the DPs of consecutive batches run side by
+     * side, as many as it takes to put about five waves on a SIMD (mz_dev_pipeline_depth()); batches above 16 Ki pairs
+     * fill the GPU on their own and keep the caller's stream. */
+    {
+        hipStream_t sd = s;
+        const int depth = mz_dev_pipeline_depth(b->n);
+        if (depth > 1) {
+            const unsigned turn = G.dp_turn++ % (unsigned)depth;
+            if (turn > 0) {
+                if (lazy_stream(&G.stream_dp[turn - 1])) return -1;
+                sd = G.stream_dp[turn - 1];
+            }
+        }
+        HIPCK(hipStreamWaitEvent(sd, G.evs[3], 0));
+        if (mzk_dp(b, sd)) return set_err("%s", mzk_last_error());
+        HIPCK(hipEventRecord(G.evs[2], sd));
+    }
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
     if (mzk_walk(b, G.stream2, 1) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.ws[slot].done, G.stream2));
