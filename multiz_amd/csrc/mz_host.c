@@ -487,8 +487,8 @@ int mz_dev_pipeline_depth(int n)
     int d;
     if (forced < 0) { const char *e = getenv("MZ_DP_STREAMS"); forced = e ? atoi(e) : 0; }
     if (forced > 0) return forced > 5 ? 5 : forced;
-    if (n <= 0 || n > 65536) return 1;               /* (C4's 125 000-pair batches: side by side 5 % slower, 467 against 492 GCUPS) */
-    if (n > 16384) return 2;                         /* the next batch's DP fills the tail of this one (C2: 585 -> 603 GCUPS) */
+    if (n <= 0) return 1;
+    if (n > 16384) return 2;                         /* the next batch's DP fills the tail of this one (C2: 585 -> 603 GCUPS, C4 497 -> 508) */
     d = (5 * 1024 + n - 1) / n;                      /* waves wanted: five per SIMD, 1024 SIMDs */
     return d < 2 ? 2 : d > 5 ? 5 : d;
 }
@@ -521,8 +521,8 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
      * half empty while their last waves finish, and a lone wave per SIMD is latency-bound throughout (section 4.1 of
      * 14.9 / 8.3 / 6.6 / 5.35 / 5.27 ms per C2 batch at 1..5 waves per SIMD).  Their DPs therefore go round
      * up to five streams (the caller's and four of the library's), so that the DPs of consecutive batches run side by
-     * side, as many as it takes to put about five waves on a SIMD (mz_dev_pipeline_depth()); batches up to 64 Ki pairs
-     * go two abreast (the second fills the first's tail), larger ones keep the caller's stream. */
+     * side, as many as it takes to put about five waves on a SIMD (mz_dev_pipeline_depth()); larger batches
+     * go two abreast (the second fills the first's tail). */
     {
         hipStream_t sd = s;
         const int depth = mz_dev_pipeline_depth(b->n);
