@@ -25,7 +25,7 @@
 #define ROAST_VERSION 3
 #define MAX_NODES 2000
 
-typedef struct { char *p; size_t n; } buf;                 /* MAF text; p == NULL: the "file" does not exist */
+typedef struct { char *p; size_t n, cap; } buf;            /* MAF text; p == NULL: the "file" does not exist */
 
 typedef struct rnode {
     int id;                      /* -1 for a leaf, else the stock driver's node number (creation order) */
@@ -48,11 +48,17 @@ static struct {
 
 /* ------------------------------------------------------------------------------------------------ text "files" */
 
-static void buf_free(buf *b) { free(b->p); b->p = NULL; b->n = 0; }
+static double g_t[8];                                      /* MZ_TIMING: read, project, parse, walk, align, replay + render, line filters */
+#define TIMED(slot, stmt) do { const double t_ = mz_now_s(); stmt; g_t[slot] += mz_now_s() - t_; } while (0)
+
+static void buf_free(buf *b) { free(b->p); b->p = NULL; b->n = 0; b->cap = 0; }
 static void buf_append(buf *dst, const char *s, size_t n)
 {
-    dst->p = (char *)realloc(dst->p, dst->n + n + 1);
-    if (!dst->p) mz_fatalf("out of memory");
+    if (dst->n + n + 1 > dst->cap) {
+        dst->cap = (dst->n + n + 1) * 2 + 4096;
+        dst->p = (char *)realloc(dst->p, dst->cap);
+        if (!dst->p) mz_fatalf("out of memory");
+    }
     memcpy(dst->p + dst->n, s, n);
     dst->n += n;
     dst->p[dst->n] = 0;
@@ -78,14 +84,14 @@ static void append_lines_without(buf *dst, const buf *src, const char *word)
 
 static buf read_file(const char *path)
 {
-    buf b = { NULL, 0 };
+    buf b = { NULL, 0, 0 };
     FILE *f = fopen(path, "r");
     long n;
     if (!f) mz_fatalf("Cannot open %s.", path);
     fseek(f, 0, SEEK_END); n = ftell(f); fseek(f, 0, SEEK_SET);
     b.p = (char *)mz_xmalloc((size_t)n + 1);
     if (fread(b.p, 1, (size_t)n, f) != (size_t)n) mz_fatalf("Cannot read %s.", path);
-    b.p[n] = 0; b.n = (size_t)n;
+    b.p[n] = 0; b.n = (size_t)n; b.cap = (size_t)n + 1;
     fclose(f);
     return b;
 }
@@ -95,7 +101,7 @@ static buf leaf_file(const char *species)
     char path[1200];
     snprintf(path, sizeof path, "%s.%s%s", T.ref, species, T.suffix);
     if (T.verbose) printf("read %s\n", path);
-    return read_file(path);
+    { buf b; TIMED(0, b = read_file(path)); return b; }
 }
 
 static void free_list(struct mafAli *l) { while (l) { struct mafAli *a = mz_pop_first(&l); mafAliFree(&a); } }
@@ -103,19 +109,22 @@ static void free_list(struct mafAli *l) { while (l) { struct mafAli *a = mz_pop_
 /* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
 static buf project_text(const buf *in, const char *what)
 {
-    buf out = { NULL, 0 };
+    buf out = { NULL, 0, 0 };
     struct mafAli *list, *a;
     char *text; size_t len;
     FILE *m;
     if (!in->p) mz_fatalf("Cannot open %s.", what);
-    list = mz_project_lists(mz_maf_read_mem(in->p, in->n, what), T.ref, NULL);
+    TIMED(2, list = mz_maf_read_mem(in->p, in->n, what));
+    { const double t_ = mz_now_s(); list = mz_project_lists(list, T.ref, NULL); g_t[1] += mz_now_s() - t_; }
+    { const double t_ = mz_now_s();
     m = open_memstream(&text, &len);
     fprintf(m, "##maf version=1 scoring=maf_project.v12\n# maf_project.v12 %s %s (in process)\n", what, T.ref);
     for (a = list; a; a = a->next) mafWrite(m, a);
     fprintf(m, "##eof maf\n");
     fclose(m);
     free_list(list);
-    out.p = text; out.n = len;
+    g_t[5] += mz_now_s() - t_; }
+    out.p = text; out.n = len; out.cap = len + 1;
     return out;
 }
 
@@ -190,15 +199,15 @@ static int is_single(const rnode *n, const char *name) { return n->nnames == 1 &
 static void begin_node(rnode *nd)
 {
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
-    buf left = { NULL, 0 }, right = { NULL, 0 };
+    buf left = { NULL, 0, 0 }, right = { NULL, 0, 0 };
     int l, r;
 
-    if (x->id >= 0) { left = x->mz; x->mz.p = NULL; x->mz.n = 0; }          /* mv MZ<i> left.maf<id> */
-    if (y->id >= 0) { right = y->mz; y->mz.p = NULL; y->mz.n = 0; }
+    if (x->id >= 0) { left = x->mz; x->mz.p = NULL; x->mz.n = x->mz.cap = 0; }          /* mv MZ<i> left.maf<id> */
+    if (y->id >= 0) { right = y->mz; y->mz.p = NULL; y->mz.n = y->mz.cap = 0; }
     buf_free(&nd->mz);
     { char head[64]; snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head); }
     nd->run = NULL; nd->l1 = nd->l2 = NULL; nd->both_leaves = 0;
-    nd->left_in.p = nd->right_in.p = NULL; nd->left_in.n = nd->right_in.n = 0;
+    memset(&nd->left_in, 0, sizeof nd->left_in); memset(&nd->right_in, 0, sizeof nd->right_in);
 
     if (T.verbose) printf("node %d: %d + %d species\n", nd->id, x->nnames, y->nnames);
     if (is_single(x, T.ref) || is_single(y, T.ref)) {
@@ -214,24 +223,36 @@ static void begin_node(rnode *nd)
     }
     if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); }
     if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); }
-    { buf u = project_text(&left, "left.maf"); buf_free(&left); left = u; }
-    { buf u = project_text(&right, "right.maf"); buf_free(&right); right = u; }
+    /* maf_project left REF > U1; mv U1 left (and the same on the right), then the aligner reads both: the projected
+     * blocks go on as lists -- what the stock chain's write-and-read-again would re-derive (sizes, text lengths, scores
+     * with one decimal: printing a score twice gives what printing it once gives) is already in them -- and the two
+     * sides are parsed and projected on two threads */
+    if (!left.p) mz_fatalf("Cannot open %s.", "left.maf");
+    if (!right.p) mz_fatalf("Cannot open %s.", "right.maf");
+    {
+        const double t_ = mz_now_s();
+#pragma omp parallel sections num_threads(2)
+        {
+#pragma omp section
+            nd->l1 = mz_project_lists(mz_maf_read_mem(left.p, left.n, "left.maf"), T.ref, NULL);
+#pragma omp section
+            nd->l2 = mz_project_lists(mz_maf_read_mem(right.p, right.n, "right.maf"), T.ref, NULL);
+        }
+        g_t[2] += mz_now_s() - t_;
+    }
+    buf_free(&left); buf_free(&right);
     l = has_ref(x); r = has_ref(y);
     if (!l && !r) nd->both_leaves = x->nnames == 1 && y->nnames == 1;
-    else if (r) { buf t = left; left = right; right = t; }
-    nd->left_in = left; nd->right_in = right;
-
-    nd->l1 = mz_maf_read_mem(left.p, left.n, "left.maf");
-    nd->l2 = mz_maf_read_mem(right.p, right.n, "right.maf");
+    else if (r) { struct mafAli *t = nd->l1; nd->l1 = nd->l2; nd->l2 = t; }
     if (!T.use_multic)
-        nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
+        TIMED(3, nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1));
 }
 
 static void end_node(rnode *nd)
 {
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
     const int v = (has_ref(x) || has_ref(y)) ? 1 : 0;
-    buf out = { NULL, 0 }, u1 = { NULL, 0 }, u2 = { NULL, 0 };
+    buf out = { NULL, 0, 0 }, u1 = { NULL, 0, 0 }, u2 = { NULL, 0, 0 };
     FILE *mo, *m1, *m2;
     struct mafAli *a;
 
@@ -354,8 +375,8 @@ int mz_roast_main(int argc, char **argv)
             begin_node(&T.nd[ready[i]]);
             if (T.nd[ready[i]].run) runs[nruns++] = T.nd[ready[i]].run;
         }
-        if (nruns) { mz_multiz_align(runs, nruns); ++batches; }
-        for (i = 0; i < nready; ++i) end_node(&T.nd[ready[i]]);
+        if (nruns) { TIMED(4, mz_multiz_align(runs, nruns)); ++batches; }
+        for (i = 0; i < nready; ++i) TIMED(5, end_node(&T.nd[ready[i]]));
         ++rounds;
     }
     if (T.nd[root].id < 0) mz_fatalf("tree specification is improper");
@@ -364,7 +385,7 @@ int mz_roast_main(int argc, char **argv)
     if (!dst) mz_fatalf("Cannot open %s.", destination);
     fprintf(dst, "##maf version=1 scoring=%s.%d\n%s\n", cmd, ROAST_VERSION, cmdline);
     {
-        buf fin = project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0 };
+        buf fin = project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
         append_lines_without(&body, &fin, "eof");
         if (body.n) fwrite(body.p, 1, body.n, dst);
         buf_free(&fin); buf_free(&body);
@@ -372,8 +393,9 @@ int mz_roast_main(int argc, char **argv)
     fprintf(dst, "##eof maf\n");
     fclose(dst);
     if (getenv("MZ_TIMING"))
-        fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s\n",
-                T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0);
+        fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s (reading leaves %.3f, final projection %.3f, parsing + projecting the inputs %.3f, "
+                "list walks %.3f, alignment batches with their host stages %.3f, replay + rendering + line filters %.3f)\n",
+                T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5]);
     free(cmdline);
     return 0;
 }
