@@ -77,7 +77,8 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
        MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */,
        MZ_MODE_ROWR = 7, MZ_MODE_COLR = 8 /* ROW / COL for scores too large for the 2^30 ring lift: the prefix
                                              maximum runs on lanes rotated to the band start (two ds_bpermute) */,
-       MZ_MODE_WIDE = 9, MZ_MODE_WIDESTRIP = 10 /* blocks of 128..255 rows: WF64 / STRIP with int16 gap vectors */ };
+       MZ_MODE_WIDE = 9, MZ_MODE_WIDESTRIP = 10 /* blocks of 128..255 rows: WF64 / STRIP with int16 gap vectors */,
+       MZ_MODE_LAG = 11 /* ROW for bands with rows of 65..127 columns: the 64-column periods run a few rows apart (kernels/lag.inc) */ };
 
 typedef struct mz_dev_batch {
     int32_t n;

@@ -13,7 +13,8 @@
 //    a lane owns a band column (a ring over the columns), the wave computes one whole band row
 //    per iteration, C and D come from the previous row (one DPP rotate for the diagonal) and the
 //    along-the-row I recurrence is a DPP prefix maximum.  Bands that fit neither that form nor
-//    its transposed twin fall back to anti-diagonal wavefronts (kernels/wavefront_*.inc: lane =
+//    its transposed twin because some rows are wider than 64 columns run the same scheme with the column periods
+//    lagged against one another (kernels/lag.inc); what is left falls back to anti-diagonal wavefronts (kernels/wavefront_*.inc: lane =
 //    DP row mod 64, step t handles cells (r, t-r)) or to 64-row strips (kernels/strip.inc).
 //    Column records sit in an LDS ring, row records in an LDS block, both built in-kernel.
 //  * traceback entries are 2-bit pick tags in three streams (reference bytes in the exact
@@ -41,8 +42,9 @@
 // row-parallel family (lane = column / transposed: lane = row) and its transposed members
 #define MODE_IS_ROWFAM(m) ((m) >= MZ_MODE_ROW && (m) <= MZ_MODE_COLR)
 #define MODE_IS_COLFAM(m) ((m) == MZ_MODE_COL || (m) == MZ_MODE_COLR)
+#define MODE_IS_TAGGED(m) ((m) == MZ_MODE_FASTT || MODE_IS_ROWFAM(m) || (m) == MZ_MODE_LAG)
 
-struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -120,6 +122,7 @@ __device__ __forceinline__ int t_hi(const int *LB, int M, int c)        // last 
 #include "kernels/wavefront_exact.inc"
 #include "kernels/wavefront_fast.inc"
 #include "kernels/row.inc"
+#include "kernels/lag.inc"
 #include "kernels/strip.inc"
 #include "kernels/dispatch.inc"
 #include "kernels/walk.inc"
@@ -149,6 +152,7 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.maxS = 0;
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
     h.row_on = m->row;
+    { const char *e = getenv("MZ_NO_LAG"); h.lag_on = !(e && e[0] == '1'); }      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
@@ -234,6 +238,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
     hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
     hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_dp_lag, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
     CK(hipGetLastError(), "dp launch");
     return 0;
 }

@@ -44,7 +44,7 @@ ms = np.zeros(4)
 for _ in range(3): ms += np.array(db.run(timed=True))
 w = (batch["poolRB"].astype(np.int64) - batch["poolLB"] + 1)
 print(f"{n} pairs, {sys.argv[2]} indel events / 1000 columns, mean length {mean_len}: widest row {int(w.max())}, mean width {w.mean():.1f}")
-print("modes", np.bincount(res["mode"], minlength=9), "failed", int((res["status"] != 0).sum()),
+print("modes", np.bincount(res["mode"], minlength=12), "failed", int((res["status"] != 0).sum()),
       "kernel ms", np.round(ms / 3, 3), "GCUPS(dp)", round(cells / (ms[1] / 3 * 1e-3) / 1e9, 1), "GCUPS(serial)", round(cells / (ms.sum() / 3 * 1e-3) / 1e9, 1))
 if "nocheck" in sys.argv: sys.exit(0)
 om, hs, ccells, bad = mo.yama_batch(batch, variant=1, threads=64)

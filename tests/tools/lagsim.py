@@ -67,3 +67,47 @@ for rate in (2, 10, 30):
     res = np.array(res, dtype=float)
     print(f"{rate} events/1000: schedule ok {res[:,0].mean():.2f}, max lag spread in a row {res[:,1].max():.0f} (mean {res[:,1].mean():.1f}), "
           f"iterations / rows {res[:,2].mean():.3f}, wide rows {res[:,3].mean():.2f}, final lag {res[:,4].mean():.1f}")
+
+# ---- the coarser form: one lag per 64-column period (at most three periods in flight, segment heads always on lane 0)
+def period_lag(LB, RB, M, N):
+    tlo, thi = col_ranges(LB, RB, M, N)
+    nper = (N >> 6) + 1
+    lam = np.zeros(nper, dtype=np.int64); step = np.zeros(nper, dtype=np.int64)
+    for k in range(nper - 1):
+        c = np.arange(64 * k, min(64 * k + 64, N + 1 - 64))
+        d = int((thi[c] - tlo[c + 64] + 1).max()) if len(c) else 1
+        step[k + 1] = max(1, d); lam[k + 1] = lam[k] + step[k + 1]
+    return lam, step
+
+print("per-period lags:")
+for rate in (2, 10, 30, 60):
+    res = []
+    for _ in range(80):
+        LB, RB, M, N = indel_band(rng, rate / 1000.0)
+        lam, step = period_lag(LB, RB, M, N)
+        width = int((RB - LB + 1).max())
+        cells = int((RB - LB + 1).sum())
+        T = M + int(lam[-1])
+        elig = step.max() <= 31 and width <= 127 and RB[0] <= 63
+        res.append((elig, step.max(), width, T / M, cells / (64.0 * T), cells / (64.0 * M)))
+    res = np.array(res, dtype=float)
+    print(f"{rate} events/1000: eligible {res[:,0].mean():.2f}, largest step {res[:,1].max():.0f} (mean of max {res[:,1].mean():.1f}), widest row {res[:,2].max():.0f}, "
+          f"iterations / rows {res[:,3].mean():.3f}, lanes busy {res[:,4].mean():.3f} (cells / 64 rows {res[:,5].mean():.3f})")
+
+print("per-period lags with a bubble at each re-arm (step >= depth + 1), two consecutive steps within 32:")
+for rate in (2, 10, 30, 60):
+    res = []
+    for _ in range(200):
+        LB, RB, M, N = indel_band(rng, rate / 1000.0)
+        tlo, thi = col_ranges(LB, RB, M, N)
+        nper = (N >> 6) + 1
+        step = np.ones(nper, dtype=np.int64)
+        for k in range(nper - 1):
+            c = np.arange(64 * k, min(64 * k + 64, N + 1 - 64))
+            if len(c): step[k + 1] = max(1, int((thi[c] - tlo[c + 64] + 2).max()))
+        two = int((step[1:] + step[:-1]).max()) if nper > 1 else 0
+        T = M + int(step[1:].sum())
+        cells = int((RB - LB + 1).sum())
+        res.append((two <= 32 and step.max() <= 31 and (RB - LB).max() <= 126 and RB[0] <= 63, two, T / M, cells / (64.0 * T)))
+    res = np.array(res, dtype=float)
+    print(f"{rate} events/1000: eligible {res[:,0].mean():.3f}, two steps max {res[:,1].max():.0f} mean {res[:,1].mean():.1f}, iterations / rows {res[:,2].mean():.3f}, lanes busy {res[:,3].mean():.3f}")
