@@ -82,6 +82,9 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
 
 typedef struct mz_dev_batch {
     int32_t n;
+    int32_t dp_hint;       /* 0: unknown -- every DP kernel is launched, one after the other; else mz_dp_hint() of the plan's totals:
+                              only the kernels that have pairs are launched, side by side when there are several */
+    int32_t pad_;
     int32_t walk_hint;     /* 0: let the device choose the traceback-walk kernel of a batch that runs beside another batch's
                               DP (both kernels are launched, one returns at once); MZ_WALK_RUNS / MZ_WALK_CHASE: the caller
                               has read the plan's totals and chosen (mz_walk_choice()) -- one launch */
@@ -99,8 +102,9 @@ typedef struct mz_dev_batch {
     int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
-    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6] their work counter, [7] spare,
-                              [8] pairs of more than 127 rows, [9] their work counter, [10] the batch chase's pair counter, [11] rows (K+L) of all valid pairs; 32 entries in all */
+    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6], [7] spare,
+                              [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
+                              [11] rows (K+L) of all valid pairs, [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
     int32_t *packList;     /* spare (n entries)                                                        */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */
@@ -116,6 +120,9 @@ typedef struct mz_dev_batch {
 enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
 /* the choice the device would make, from the plan's totals (host copy) of an n-pair batch */
 int mz_walk_choice(int n, const int64_t *totals);
+/* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint), from the plan's totals (host copy) */
+enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16 };
+int mz_dp_hint(int n, const int64_t *totals);
 
 typedef struct mz_score_model {
     int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */

@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -230,15 +231,71 @@ extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
     return 0;
 }
 
+// Side streams of mzk_dp_range, one set per device (created on first use; a device's calls come from one host thread)
+struct DpSide { int ready; hipStream_t s[3]; hipEvent_t fork, join[3]; };
+static DpSide g_side[16];
+static std::mutex g_side_mu;
+static DpSide *dp_side(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    DpSide *S = &g_side[dev];
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    if (!S->ready) {
+        for (int i = 0; i < 3; ++i)
+            if (hipStreamCreateWithFlags(&S->s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&S->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&S->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        S->ready = 1;
+    }
+    return S;
+}
+
+extern "C" int mz_dp_hint(int n, const int64_t *totals)
+{
+    const long long failed = totals[3], wf = totals[5], wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
+    const long long row = (long long)n - failed - wf - wide - lag;
+    return MZ_DP_KNOWN | (row > 0 ? MZ_DP_ROW : 0) | (wf > 0 ? MZ_DP_WAVEFRONT : 0) | (wide > 0 ? MZ_DP_WIDE : 0) | (lag > 0 ? MZ_DP_LAG : 0);
+}
+
+// The DP of pairs [first, first+count): k_dp_row (a block per pair; pairs of other modes leave at once), and the three
+// kernels that take their pairs from a counter (wavefront / strip, blocks of 128..255 rows, lagged row-parallel).
+// Without a hint all four go onto `stream`, one after the other.  With the plan's totals in hand (b->dp_hint) only the
+// kernels that have pairs are launched -- and side by side, on side streams forked from and joined back into `stream`,
+// when several do: a kernel that got a few hundred pairs takes as long as its longest pair, and back to back those
+// tails cost a mixed batch a quarter of its DP time (20 000 pairs with indels: 0.29 + 0.95 + 3.0 ms).
 extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_dp_lag, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
+    if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
+    hipStream_t main_s = (hipStream_t)stream;
+    const int hint = (b->dp_hint & MZ_DP_KNOWN) ? b->dp_hint : (MZ_DP_ROW | MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG);
+    const int kinds[4] = { MZ_DP_LAG, MZ_DP_ROW, MZ_DP_WAVEFRONT, MZ_DP_WIDE };     // (the first with pairs stays on `stream`)
+    int nk = 0;
+    for (int i = 0; i < 4; ++i) nk += (hint & kinds[i]) != 0;
+    if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
+        CK(hipMemsetAsync(&b->totals[16], 0, 3 * sizeof(int64_t), main_s), "dp counters");
+    DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
+    if (S) CK(hipEventRecord(S->fork, main_s), "dp fork");
+    int used = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!(hint & kinds[i])) continue;
+        hipStream_t s = main_s;
+        if (S && used > 0) { s = S->s[used - 1]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
+        if (kinds[i] == MZ_DP_ROW)
+            hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count);
+        else if (kinds[i] == MZ_DP_WAVEFRONT)
+            hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, s, *b, first, count);
+        else if (kinds[i] == MZ_DP_WIDE)
+            hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, s, *b, first, count);
+        else
+            hipLaunchKernelGGL(k_dp_lag, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, s, *b, first, count);
+        if (S && used > 0) { CK(hipEventRecord(S->join[used - 1], s), "dp join"); CK(hipStreamWaitEvent(main_s, S->join[used - 1], 0), "dp join wait"); }
+        ++used;
+    }
     CK(hipGetLastError(), "dp launch");
     return 0;
 }
