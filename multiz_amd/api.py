@@ -329,7 +329,9 @@ class DevBatch:
         return dict(status=self._view(self.c.status, n, np.int32), mode=self._view(self.c.mode, n, np.int32),
                     cells=self._view(self.c.cells, n, np.int64), om=self._view(self.c.om, n, np.int32),
                     final3=self._view(self.c.final3, 3 * n, np.int32).reshape(n, 3),
-                    offOut=self._view(self.c.offOut, n, np.int64), totals=self._view(self.c.totals, 8, np.int64))
+                    offOut=self._view(self.c.offOut, n, np.int64), totals=self._view(self.c.totals, 8, np.int64),
+                    offPrep=self._view(self.c.offPrep, n, np.int64), edgeLo=self._view(self.c.edgeLo, n, np.int32),
+                    edgeHi=self._view(self.c.edgeHi, n, np.int32))
 
     def output_cols(self, i: int, res: dict, K: int, L: int):
         om, off = int(res["om"][i]), int(res["offOut"][i])

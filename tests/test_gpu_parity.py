@@ -459,6 +459,77 @@ def test_bands_with_indels(mz, events):
         assert m_ == om[i] and _hash(out[o0: o0 + m_ * 4], m_) == int(hs[i]), (i, int(res["mode"][i]))
 
 
+def _lag_steps(LB, RB):
+    """LAG steps per 64-column period from their definition (kernels/lag.inc): 1 + the most rows any column c of the
+    period before shares with column c+64, at least 1"""
+    M = len(LB) - 1; N = int(RB[M])
+    tlo = np.searchsorted(RB, np.arange(N + 1), side="left")            # first row with RB >= c
+    thi = np.searchsorted(LB, np.arange(N + 1), side="right") - 1       # last row with LB <= c
+    step = np.ones((N >> 6) + 1, dtype=np.int64); step[0] = 0
+    for k in range(len(step) - 1):
+        c = np.arange(64 * k, min(64 * k + 64, N + 1 - 64))
+        if len(c):
+            step[k + 1] = max(1, int((thi[c] - tlo[c + 64] + 2).max()))
+    return step
+
+
+def test_lagged_schedule(mz):
+    # MZ_MODE_LAG: the plan's table (one LAG per 64-column period, in the pair's prep slice) equals the definition,
+    # pairs are taken exactly when the band fits the kernel's limits, and the result equals the oracle's -- on bands
+    # with long indels (steps up to the limit), short pairs (one or two periods) and radii from 10 to 30
+    from multiz_amd import synth
+    rng = np.random.default_rng(77)
+    pairs = []
+    for i in range(600):
+        M = int(rng.integers(70, 500))
+        rate, mean_len = rng.choice([0.01, 0.03, 0.06, 0.1]), rng.choice([3.0, 6.0, 10.0])
+        centre = np.zeros(M + 1, dtype=np.int64)
+        c, r = 0, 1
+        while r <= M:
+            u = rng.random()
+            if u < rate / 2 and r > 1:
+                for _ in range(min(int(rng.geometric(1.0 / mean_len)), M - r + 1)):
+                    centre[r] = c; r += 1
+                continue
+            if u < rate:
+                c += int(rng.geometric(1.0 / mean_len))
+            c += 1
+            centre[r] = c; r += 1
+        N = int(max(c, 11))
+        LB = np.minimum(centre, N).astype(np.int32); RB = LB.copy(); LB[0] = 0; RB[M] = N
+        LB, RB = mo.smooth(LB, RB, M, N, int(rng.integers(10, 31)))      # (yama wants rows of at least 11 columns)
+        A = inputs.random_block(rng, M, 2, dash=0.1, odd=0.05)
+        pairs.append((A, inputs.noisy_copy(rng, A, N, 3, dash=0.1), LB, RB))
+    batch = synth.pack_pairs(pairs)
+    _kernels(mz, 2)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    prep = db.prep.cpu().numpy()
+    assert (res["status"] == 0).all()
+    nlag = 0
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        M, N = len(LB) - 1, int(RB[-1])
+        step = _lag_steps(LB, RB)
+        wide = int((RB - LB).max()) > 62 and not all(LB[r + 63] > RB[r] for r in range(M + 1 - 63))   # fits neither ROW nor COL
+        fits = (step.max() <= 31 and (len(step) < 2 or int((step[1:] + step[:-1]).max()) <= 32) and
+                int((RB - LB).max()) <= 126 and RB[0] <= 63)
+        if res["mode"][i] == 11:
+            nlag += 1
+            assert fits, i
+            o = int(res["offPrep"][i])
+            lam = np.cumsum(step)
+            assert np.array_equal(prep[o: o + len(step)], lam), (i, prep[o: o + len(step)], lam)
+            assert prep[o + len(step)] == M + lam[-1]
+            assert res["edgeHi"][i] == min(int(np.argmax(RB == N)) + lam[N >> 6], M + lam[LB[M] >> 6])
+        elif wide and res["mode"][i] not in (5, 6):
+            assert not fits, (i, int(res["mode"][i]), step)
+        w = mo.yama(A, B, LB, RB, variant="profile")
+        m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+        assert m_ == w.OM and np.array_equal(db.out[o0: o0 + m_ * 5].cpu().numpy().reshape(m_, 5), w.cols), (i, int(res["mode"][i]))
+    assert nlag > 50, nlag
+
+
 def test_pipelined_form_from_a_cold_start():
     # mz_dev_run_async() as the FIRST call of a process (its helper streams are created on first use) and again after
     # mz_finalize(): results equal the serial form's
