@@ -273,9 +273,11 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
     hipStream_t main_s = (hipStream_t)stream;
     const int hint = (b->dp_hint & MZ_DP_KNOWN) ? b->dp_hint : (MZ_DP_ROW | MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG);
-    const int kinds[4] = { MZ_DP_LAG, MZ_DP_ROW, MZ_DP_WAVEFRONT, MZ_DP_WIDE };     // (the first with pairs stays on `stream`)
-    int nk = 0;
-    for (int i = 0; i < 4; ++i) nk += (hint & kinds[i]) != 0;
+    // launch order: the kernels whose pairs take longest first (a wavefront pair has twice the steps), the one that
+    // fills the GPU last -- on `stream` itself; the others get their CUs before its blocks have taken all the LDS
+    const int kinds[4] = { MZ_DP_WAVEFRONT, MZ_DP_WIDE, MZ_DP_ROW, MZ_DP_LAG };
+    int nk = 0, last = 0;
+    for (int i = 0; i < 4; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
         CK(hipMemsetAsync(&b->totals[16], 0, 3 * sizeof(int64_t), main_s), "dp counters");
     DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
@@ -283,8 +285,9 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     int used = 0;
     for (int i = 0; i < 4; ++i) {
         if (!(hint & kinds[i])) continue;
+        const bool side = S && i != last;
         hipStream_t s = main_s;
-        if (S && used > 0) { s = S->s[used - 1]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
+        if (side) { s = S->s[used]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
         if (kinds[i] == MZ_DP_ROW)
             hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count);
         else if (kinds[i] == MZ_DP_WAVEFRONT)
@@ -293,9 +296,9 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
             hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, s, *b, first, count);
         else
             hipLaunchKernelGGL(k_dp_lag, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, s, *b, first, count);
-        if (S && used > 0) { CK(hipEventRecord(S->join[used - 1], s), "dp join"); CK(hipStreamWaitEvent(main_s, S->join[used - 1], 0), "dp join wait"); }
-        ++used;
+        if (side) { CK(hipEventRecord(S->join[used], s), "dp join"); ++used; }
     }
+    for (int i = 0; i < used; ++i) CK(hipStreamWaitEvent(main_s, S->join[i], 0), "dp join wait");
     CK(hipGetLastError(), "dp launch");
     return 0;
 }
