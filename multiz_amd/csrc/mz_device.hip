@@ -62,6 +62,57 @@ __device__ __forceinline__ int byte_class(unsigned ch)
     return c;
 }
 
+struct __attribute__((packed, aligned(1))) u32_any { uint32_t v; };     // a dword at any byte address (gfx950 global memory takes it)
+
+// What the kernels need of one column of a block (n bytes at p; q: the column before, or null): the counts of A, C,
+// G, T (four byte counters), of dashes and of anything else, and the rows that have a base here and before (n00) or
+// a dash here and before (n11).  Four bytes at a time: a byte equals a code where the XOR with the code repeated is
+// zero, (x & 0x7f..) + 0x7f.. carries into bit 7 of every non-zero byte without crossing bytes, and the counts are
+// population counts of the 0x80 marks -- ~11 instructions per byte against ~33 for compare-and-select byte by byte,
+// which made the staging of blocks of 20-30 rows cost as much as two thirds of the recurrence it feeds.
+struct ByteCounts { unsigned acgt; int dash, other, n00, n11; };
+__device__ __forceinline__ unsigned zero_bytes(unsigned x)          // 0x80 in every byte of x that is zero
+{
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ ByteCounts count_bytes(const uint8_t *p, const uint8_t *q, int n)
+{
+    unsigned acgt = 0;                                               // four byte counters (n <= 255)
+    int dash = 0, n00 = 0, n11 = 0;
+    int i = 0;
+#pragma unroll 1
+    for (; i + 4 <= n; i += 4) {
+        const unsigned w = ((const u32_any *)(p + i))->v;
+        const unsigned u = w | 0x20202020u;                          // (case folded as byte_class does)
+        const unsigned zD = zero_bytes(w ^ 0x2d2d2d2du);
+        const unsigned zP = q ? zero_bytes(((const u32_any *)(q + i))->v ^ 0x2d2d2d2du) : 0u;
+        acgt += __popc(zero_bytes(u ^ 0x61616161u));
+        acgt += __popc(zero_bytes(u ^ 0x63636363u)) << 8;
+        acgt += __popc(zero_bytes(u ^ 0x67676767u)) << 16;
+        acgt += __popc(zero_bytes(u ^ 0x74747474u)) << 24;
+        dash += __popc(zD);
+        n00 += __popc(~(zD | zP) & 0x80808080u);
+        n11 += __popc(zD & zP);
+    }
+    // (of the dwords, what is neither a base nor a dash: by difference)
+    int other = (n & ~3) - (int)((acgt & 0xff) + ((acgt >> 8) & 0xff) + ((acgt >> 16) & 0xff) + (acgt >> 24)) - dash;
+    for (; i < n; ++i) {                                             // the last n & 3 bytes, one at a time
+        const unsigned ch = p[i];
+        const bool d = ch == '-', pd = q ? (q[i] == '-') : false;
+        const int cl = byte_class(ch);
+        acgt += (cl < 4) ? (1u << (cl << 3)) : 0u;
+        other += cl == 5;
+        dash += d;
+        n00 += (!d) & (!pd);
+        n11 += d & pd;
+    }
+    ByteCounts r;
+    r.acgt = acgt;
+    r.dash = dash; r.n00 = n00; r.n11 = n11;
+    r.other = other;
+    return r;
+}
+
 __device__ __forceinline__ int pack4(int b0, int b1, int b2, int b3)
 {
     return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((b3 & 0xff) << 24);
