@@ -149,3 +149,35 @@ def write_maf(path: str, blocks) -> None:
             b.score = score_range(b, 0, b.textSize)
             f.write(format_block(b))
         f.write("##eof maf\n")
+
+
+def indel_band(rng, M, rate, mean_len, radius):
+    """the band pre_yama derives for blocks with indels against the shared reference row (mz_preyama.c:240-258, then
+    smooth): the centre stands still over columns only the first block has and jumps over columns only the second has"""
+    from oracle import mzoracle as mo
+    centre = np.zeros(M + 1, dtype=np.int64)
+    c, i = 0, 1
+    while i <= M:
+        u = rng.random()
+        if u < rate / 2 and i > 1:
+            for _ in range(min(int(rng.geometric(1.0 / mean_len)), M - i + 1)):
+                centre[i] = c; i += 1
+            continue
+        if u < rate:
+            c += int(rng.geometric(1.0 / mean_len))
+        c += 1
+        centre[i] = c; i += 1
+    N = int(max(c, 11))
+    LB = np.minimum(centre, N).astype(np.int32); RB = LB.copy(); LB[0] = 0; RB[M] = N
+    LB, RB = mo.smooth(LB, RB, M, N, radius)
+    return LB, RB, N
+
+
+def random_indel_pair(rng):
+    """a block pair of 1-6 rows each, 30-900 columns, indels of mean length 2-12 at 5-100 events per 1 000 columns,
+    radius 10-30, up to 40 % dashes"""
+    M = int(rng.integers(30, 900))
+    LB, RB, N = indel_band(rng, M, rng.choice([0.005, 0.02, 0.05, 0.1]), rng.choice([2.0, 5.0, 12.0]), int(rng.integers(10, 31)))
+    K, L = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    A = random_block(rng, M, K, dash=float(rng.choice([0.0, 0.1, 0.4])), odd=0.05)
+    return A, noisy_copy(rng, A, N, L, dash=float(rng.choice([0.0, 0.1, 0.4]))), LB, RB

@@ -528,6 +528,41 @@ def test_lagged_schedule(mz):
         m_, o0 = int(res["om"][i]), int(res["offOut"][i])
         assert m_ == w.OM and np.array_equal(db.out[o0: o0 + m_ * 5].cpu().numpy().reshape(m_, 5), w.cols), (i, int(res["mode"][i]))
     assert nlag > 50, nlag
+    # the same batch without the caller's hints (mz_dev_batch.dp_hint = walk_hint = 0: every DP kernel launched, one
+    # after the other, the device choosing the walk) gives the same bytes
+    db2 = mz.DevBatch(batch)
+    db2.c.dp_hint = 0
+    db2.c.walk_hint = 0
+    db2.run()
+    res2 = db2.results()
+    assert np.array_equal(res2["om"], res["om"]) and np.array_equal(res2["mode"], res["mode"])
+    o1, o2 = db.out.cpu().numpy(), db2.out.cpu().numpy()
+    for i in range(len(pairs)):                                          # (the slack between the pairs' slices is not written)
+        a, e = int(res["offOut"][i]), int(res["offOut"][i]) + 5 * int(res["om"][i])
+        assert res2["offOut"][i] == res["offOut"][i] and np.array_equal(o1[a:e], o2[a:e]), i
+
+
+def test_lagged_kernel_random_blocks(mz):
+    # blocks of 1-6 rows, short and long pairs, long indels, many dashes -- among them bands whose last rows are wide (a
+    # column that stays in the band down to row M while the column 64 to its right, lagged, still has rows to come:
+    # the lane leaves it at the first row beyond M).  Every pair against the oracle by hash.
+    from multiz_amd import synth
+    rng = np.random.default_rng(3)
+    pairs = [inputs.random_indel_pair(rng) for _ in range(4000)]
+    batch = synth.pack_pairs(pairs)
+    _kernels(mz, 2)
+    db = mz.DevBatch(batch)
+    db.run()
+    res = db.results()
+    assert (res["status"] == 0).all()
+    hist = np.bincount(res["mode"], minlength=13)
+    assert hist[11] > 400, hist
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
+    assert bad == 0 and cells == int(res["cells"].sum())
+    out = db.out.cpu().numpy()
+    for i, (A, B, _, _) in enumerate(pairs):
+        m_, o0, W = int(res["om"][i]), int(res["offOut"][i]), A.shape[1] + B.shape[1]
+        assert m_ == om[i] and _hash(out[o0: o0 + m_ * W], m_) == int(hs[i]), (i, int(res["mode"][i]))
 
 
 def test_pipelined_form_from_a_cold_start():
