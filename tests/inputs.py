@@ -181,3 +181,20 @@ def random_indel_pair(rng):
     K, L = int(rng.integers(1, 7)), int(rng.integers(1, 7))
     A = random_block(rng, M, K, dash=float(rng.choice([0.0, 0.1, 0.4])), odd=0.05)
     return A, noisy_copy(rng, A, N, L, dash=float(rng.choice([0.0, 0.1, 0.4]))), LB, RB
+
+
+def random_walk_band(rng, M):
+    """a valid band that no aligner would produce: both edges random monotone walks with occasional jumps, rows 11 to
+    ~120 columns wide, every row touching the one before"""
+    LB = np.zeros(M + 1, dtype=np.int64); RB = np.zeros(M + 1, dtype=np.int64)
+    lo, hi = 0, int(rng.integers(11, 64))
+    for r in range(M + 1):
+        LB[r], RB[r] = lo, hi
+        prev_hi = hi
+        hi += int(rng.choice([0, 1, 1, 1, 2, 3, int(rng.integers(0, 40))], p=[0.15, 0.3, 0.2, 0.1, 0.1, 0.1, 0.05]))
+        lo += int(rng.choice([0, 1, 1, 1, 2, 3, int(rng.integers(0, 40))], p=[0.15, 0.3, 0.2, 0.1, 0.1, 0.1, 0.05]))
+        lo = min(lo, prev_hi, hi - 11)                   # touches the row before, at least 11 columns wide
+        lo = max(lo, int(LB[r]))
+        if hi - lo > 120: lo = hi - 120
+    N = int(RB[M])
+    return LB.astype(np.int32), RB.astype(np.int32), N

@@ -476,28 +476,18 @@ def _lag_steps(LB, RB):
 def test_lagged_schedule(mz):
     # MZ_MODE_LAG: the plan's table (one LAG per 64-column period, in the pair's prep slice) equals the definition,
     # pairs are taken exactly when the band fits the kernel's limits, and the result equals the oracle's -- on bands
-    # with long indels (steps up to the limit), short pairs (one or two periods) and radii from 10 to 30
+    # with long indels (steps up to the limit), short pairs (one or two periods), radii from 10 to 30, and on random
+    # monotone bands (both edges random walks with jumps)
     from multiz_amd import synth
     rng = np.random.default_rng(77)
     pairs = []
-    for i in range(600):
+    for i in range(900):
         M = int(rng.integers(70, 500))
-        rate, mean_len = rng.choice([0.01, 0.03, 0.06, 0.1]), rng.choice([3.0, 6.0, 10.0])
-        centre = np.zeros(M + 1, dtype=np.int64)
-        c, r = 0, 1
-        while r <= M:
-            u = rng.random()
-            if u < rate / 2 and r > 1:
-                for _ in range(min(int(rng.geometric(1.0 / mean_len)), M - r + 1)):
-                    centre[r] = c; r += 1
-                continue
-            if u < rate:
-                c += int(rng.geometric(1.0 / mean_len))
-            c += 1
-            centre[r] = c; r += 1
-        N = int(max(c, 11))
-        LB = np.minimum(centre, N).astype(np.int32); RB = LB.copy(); LB[0] = 0; RB[M] = N
-        LB, RB = mo.smooth(LB, RB, M, N, int(rng.integers(10, 31)))      # (yama wants rows of at least 11 columns)
+        if i % 3 == 2:                                                   # a third: bands no aligner would produce
+            LB, RB, N = inputs.random_walk_band(rng, M)
+        else:
+            LB, RB, N = inputs.indel_band(rng, M, rng.choice([0.01, 0.03, 0.06, 0.1]), rng.choice([3.0, 6.0, 10.0]),
+                                          int(rng.integers(10, 31)))    # (yama wants rows of at least 11 columns)
         A = inputs.random_block(rng, M, 2, dash=0.1, odd=0.05)
         pairs.append((A, inputs.noisy_copy(rng, A, N, 3, dash=0.1), LB, RB))
     batch = synth.pack_pairs(pairs)
@@ -513,7 +503,7 @@ def test_lagged_schedule(mz):
         step = _lag_steps(LB, RB)
         wide = int((RB - LB).max()) > 62 and not all(LB[r + 63] > RB[r] for r in range(M + 1 - 63))   # fits neither ROW nor COL
         fits = (step.max() <= 31 and (len(step) < 2 or int((step[1:] + step[:-1]).max()) <= 32) and
-                int((RB - LB).max()) <= 126 and RB[0] <= 63)
+                int((RB - LB).max()) <= 126 and RB[0] <= 62)
         if res["mode"][i] == 11:
             nlag += 1
             assert fits, i
@@ -549,6 +539,11 @@ def test_lagged_kernel_random_blocks(mz):
     from multiz_amd import synth
     rng = np.random.default_rng(3)
     pairs = [inputs.random_indel_pair(rng) for _ in range(4000)]
+    for _ in range(1000):                                                # and bands no aligner would produce
+        M = int(rng.integers(40, 400))
+        LB, RB, N = inputs.random_walk_band(rng, M)
+        A = inputs.random_block(rng, M, int(rng.integers(1, 5)), dash=0.1, odd=0.05)
+        pairs.append((A, inputs.noisy_copy(rng, A, N, int(rng.integers(1, 5)), dash=0.1), LB, RB))
     batch = synth.pack_pairs(pairs)
     _kernels(mz, 2)
     db = mz.DevBatch(batch)

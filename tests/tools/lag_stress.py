@@ -9,6 +9,12 @@ from oracle import mzoracle as mo
 mz.api.init(0)
 n = int(sys.argv[1]); rng = np.random.default_rng(int(sys.argv[2]))
 pairs = [inputs.random_indel_pair(rng) for _ in range(n)]
+for _ in range(n // 3):                                   # and bands no aligner would produce
+    M = int(rng.integers(40, 400))
+    LB, RB, N = inputs.random_walk_band(rng, M)
+    A = inputs.random_block(rng, M, int(rng.integers(1, 5)), dash=0.1, odd=0.05)
+    pairs.append((A, inputs.noisy_copy(rng, A, N, int(rng.integers(1, 5)), dash=0.1), LB, RB))
+n = len(pairs)
 batch = synth.pack_pairs(pairs)
 db = mz.DevBatch(batch); db.run(); res = db.results()
 om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
