@@ -173,12 +173,12 @@ def indel_band(rng, M, rate, mean_len, radius):
     return LB, RB, N
 
 
-def random_indel_pair(rng):
-    """a block pair of 1-6 rows each, 30-900 columns, indels of mean length 2-12 at 5-100 events per 1 000 columns,
+def random_indel_pair(rng, max_rows=6):
+    """a block pair of 1-max_rows rows each, 30-900 columns, indels of mean length 2-12 at 5-100 events per 1 000 columns,
     radius 10-30, up to 40 % dashes"""
     M = int(rng.integers(30, 900))
     LB, RB, N = indel_band(rng, M, rng.choice([0.005, 0.02, 0.05, 0.1]), rng.choice([2.0, 5.0, 12.0]), int(rng.integers(10, 31)))
-    K, L = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    K, L = int(rng.integers(1, max_rows + 1)), int(rng.integers(1, max_rows + 1))
     A = random_block(rng, M, K, dash=float(rng.choice([0.0, 0.1, 0.4])), odd=0.05)
     return A, noisy_copy(rng, A, N, L, dash=float(rng.choice([0.0, 0.1, 0.4]))), LB, RB
 

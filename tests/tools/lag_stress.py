@@ -8,7 +8,8 @@ from multiz_amd import synth
 from oracle import mzoracle as mo
 mz.api.init(0)
 n = int(sys.argv[1]); rng = np.random.default_rng(int(sys.argv[2]))
-pairs = [inputs.random_indel_pair(rng) for _ in range(n)]
+max_rows = int(os.environ.get("LAG_STRESS_ROWS", "6"))
+pairs = [inputs.random_indel_pair(rng, max_rows) for _ in range(n)]
 for _ in range(n // 3):                                   # and bands no aligner would produce
     M = int(rng.integers(40, 400))
     LB, RB, N = inputs.random_walk_band(rng, M)
