@@ -102,7 +102,7 @@ typedef struct mz_dev_batch {
     int32_t *edgeHi;       /* first step with a cell in column N                          */
     int64_t *szTb, *szScript, *szOut, *szPrep;     /* per-pair sizes (dwords, bytes, bytes, dwords) */
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
-    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels, [6], [7] spare,
+    int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
                               [11] rows (K+L) of all valid pairs, [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
     int32_t *packList;     /* spare (n entries)                                                        */
@@ -121,7 +121,7 @@ enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
 /* the choice the device would make, from the plan's totals (host copy) of an n-pair batch */
 int mz_walk_choice(int n, const int64_t *totals);
 /* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint), from the plan's totals (host copy) */
-enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16 };
+enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32 };
 int mz_dp_hint(int n, const int64_t *totals);
 
 typedef struct mz_score_model {

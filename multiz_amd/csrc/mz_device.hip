@@ -118,6 +118,7 @@ __device__ __forceinline__ int pack4(int b0, int b1, int b2, int b3)
     return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((b3 & 0xff) << 24);
 }
 __device__ __forceinline__ int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }      // full-rate multiply of factors below 2^23
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot4(int a, int b, int acc) { return __builtin_amdgcn_sdot4(a, b, acc, false); }
@@ -283,7 +284,7 @@ extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
 }
 
 // Side streams of mzk_dp_range, one set per device (created on first use; a device's calls come from one host thread)
-struct DpSide { int ready; hipStream_t s[3]; hipEvent_t fork, join[3]; };
+struct DpSide { int ready; hipStream_t s[4]; hipEvent_t fork, join[4]; };
 static DpSide g_side[16];
 static std::mutex g_side_mu;
 static DpSide *dp_side(void)
@@ -293,7 +294,7 @@ static DpSide *dp_side(void)
     DpSide *S = &g_side[dev];
     std::lock_guard<std::mutex> lock(g_side_mu);
     if (!S->ready) {
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 4; ++i)
             if (hipStreamCreateWithFlags(&S->s[i], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&S->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&S->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -304,12 +305,13 @@ static DpSide *dp_side(void)
 
 extern "C" int mz_dp_hint(int n, const int64_t *totals)
 {
-    const long long failed = totals[3], wf = totals[5], wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
-    const long long row = (long long)n - failed - wf - wide - lag;
-    return MZ_DP_KNOWN | (row > 0 ? MZ_DP_ROW : 0) | (wf > 0 ? MZ_DP_WAVEFRONT : 0) | (wide > 0 ? MZ_DP_WIDE : 0) | (lag > 0 ? MZ_DP_LAG : 0);
+    const long long failed = totals[3], wf = totals[5] & 0xffffffffLL, rowbig = totals[5] >> 32, wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
+    const long long row = (long long)n - failed - wf - wide - lag - rowbig;         // row-parallel pairs of blocks of one to three rows
+    return MZ_DP_KNOWN | (row > 0 ? MZ_DP_ROW : 0) | (rowbig > 0 ? MZ_DP_ROWBIG : 0) | (wf > 0 ? MZ_DP_WAVEFRONT : 0) | (wide > 0 ? MZ_DP_WIDE : 0) |
+           (lag > 0 ? MZ_DP_LAG : 0);
 }
 
-// The DP of pairs [first, first+count): k_dp_row (a block per pair; pairs of other modes leave at once), and the three
+// The DP of pairs [first, first+count): k_dp_row / k_dp_row_big (a block per pair; pairs of other modes leave at once), and the three
 // kernels that take their pairs from a counter (wavefront / strip, blocks of 128..255 rows, lagged row-parallel).
 // Without a hint all four go onto `stream`, one after the other.  With the plan's totals in hand (b->dp_hint) only the
 // kernels that have pairs are launched -- and side by side, on side streams forked from and joined back into `stream`,
@@ -323,24 +325,28 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
     if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
     hipStream_t main_s = (hipStream_t)stream;
-    const int hint = (b->dp_hint & MZ_DP_KNOWN) ? b->dp_hint : (MZ_DP_ROW | MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG);
+    const bool known = (b->dp_hint & MZ_DP_KNOWN) != 0;
+    int hint = known ? b->dp_hint : (MZ_DP_ROW | MZ_DP_ROWBIG | MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG);
+    if (known && (hint & MZ_DP_ROWBIG)) hint &= ~MZ_DP_ROW;      // blocks of four rows or more in the batch: k_dp_row_big takes every row-parallel pair
     // launch order: the kernels whose pairs take longest first (a wavefront pair has twice the steps), the one that
     // fills the GPU last -- on `stream` itself; the others get their CUs before its blocks have taken all the LDS
-    const int kinds[4] = { MZ_DP_WAVEFRONT, MZ_DP_WIDE, MZ_DP_ROW, MZ_DP_LAG };
+    const int kinds[5] = { MZ_DP_WAVEFRONT, MZ_DP_WIDE, MZ_DP_ROWBIG, MZ_DP_ROW, MZ_DP_LAG };
     int nk = 0, last = 0;
-    for (int i = 0; i < 4; ++i) if (hint & kinds[i]) { ++nk; last = i; }
+    for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
         CK(hipMemsetAsync(&b->totals[16], 0, 3 * sizeof(int64_t), main_s), "dp counters");
     DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
     if (S) CK(hipEventRecord(S->fork, main_s), "dp fork");
     int used = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (!(hint & kinds[i])) continue;
         const bool side = S && i != last;
         hipStream_t s = main_s;
         if (side) { s = S->s[used]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
         if (kinds[i] == MZ_DP_ROW)
-            hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 1);
+        else if (kinds[i] == MZ_DP_ROWBIG)
+            hipLaunchKernelGGL(k_dp_row_big, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 2);
         else if (kinds[i] == MZ_DP_WAVEFRONT)
             hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, s, *b, first, count);
         else if (kinds[i] == MZ_DP_WIDE)
