@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # PMC figures of one launch of the dominant kernel on the DEFAULT c2 batch (50 000 pairs), from the separate rocprofv3
 # --pmc passes summarised in profiles/r2_pmc_summary.txt.  Measured, never estimated; reported only for that batch.
 #   FETCH_SIZE 355 227 KB (coalesced reads: x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2 438 500 KB; SQ_INSTS_VALU
-PMC_C2 = {"traffic": (2 * 355227 + 2438500) * 1024, "valu_insts": 2731186455}
+PMC_C2 = {"traffic": (2 * 355176 + 2438497) * 1024, "valu_insts": 2741188179}
 # VALU issue: integer max / dot2 / cndmask / DPP wave-instructions occupy a SIMD for 4 shader cycles on gfx950
 # (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt; v_add/v_sub/v_and: 2-3); 1024 SIMDs.
 VALU_CYCLES = 4.0
@@ -304,6 +304,11 @@ def main():
     roof_achieved = total_bytes / (dp_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes over the DP kernel's time
     default_batch = args.config == "c2" and pairs == 50000 and not args.scatter
     modes = np.bincount(res["mode"], minlength=13)
+    # the DP kernel that took most of the batch's pairs: the row-parallel one (k_dp_row_big when the batch has blocks of four
+    # rows or more), the lagged one, or the wavefront fallbacks
+    big = bool((np.maximum(batch["K"], batch["L"]) >= 4).any())
+    dominant_kernel = max((int(modes[5:9].sum()), "k_dp_row_big" if big else "k_dp_row"), (int(modes[11]), "k_dp_lag"),
+                          (int(modes[:4].sum()), "k_dp"), (int(modes[9:11].sum()), "k_dp_wide"))[1]
 
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",
@@ -322,7 +327,7 @@ def main():
         # batch / its HIP-event time.  The kernel is VALU-issue bound, not HBM bound:
         # measured traffic (profiles/, separate --pmc passes) stays under 1 TB/s; `valu` prices the same launch
         # against the integer VALU issue roof (instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)).
-        "roofline": {"bound": "hbm", "kernel": "k_dp_row", "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": dominant_kernel, "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(roof_achieved / HBM_PEAK_GBS, 5),
                      "traffic": PMC_C2["traffic"] if default_batch else None,
                      "bytes_per_cell": round(total_bytes / cells, 4), "algorithmic_bytes": total_bytes,
