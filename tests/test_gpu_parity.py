@@ -558,6 +558,11 @@ def test_lagged_kernel_random_blocks(mz):
     for i, (A, B, _, _) in enumerate(pairs):
         m_, o0, W = int(res["om"][i]), int(res["offOut"][i]), A.shape[1] + B.shape[1]
         assert m_ == om[i] and _hash(out[o0: o0 + m_ * W], m_) == int(hs[i]), (i, int(res["mode"][i]))
+    # the same pairs from host buffers (mz_yama_batch: chunks in flight, DP kernels of a chunk side by side)
+    lagged = [i for i in range(len(pairs)) if res["mode"][i] == 11][:300]
+    for i, r in zip(lagged, mz.yama_batch([pairs[i] for i in lagged])):
+        W = pairs[i][0].shape[1] + pairs[i][1].shape[1]
+        assert r.status == 0 and r.OM == om[i] and _hash(np.ascontiguousarray(r.cols).reshape(-1), r.OM) == int(hs[i]), i
 
 
 def test_pipelined_form_from_a_cold_start():
