@@ -98,7 +98,8 @@ def cpu_leg(spec_path):
     from multiz_amd import synth
     from oracle import mzoracle as mo
     cfg, pairs, cores = synth.CONFIGS[spec["config"]], spec["pairs"], len(cpus)
-    batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=spec["first_pair"])
+    batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=spec["first_pair"],
+                             indel=cfg.get("indel", 0))
     use_ref = mo.have_reference()
     run_cpu = (lambda bt: mo.ref_batch(bt, threads=cores)) if use_ref else (lambda bt: mo.yama_batch(bt, variant=0, threads=cores))
     rng = np.random.default_rng(12345)
@@ -145,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # (a c2 step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -220,7 +221,7 @@ def main():
     if args.scatter and world > 1:
         # the list exists on rank 0 only: partition by band cells, one grouped RCCL send per peer, the shard's
         # tensors become the device batch where they land; the aligned shard goes back the same way (checked below)
-        whole = synth.make_batch(pairs * world, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"]) if rank == 0 else None
+        whole = synth.make_batch(pairs * world, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], indel=cfg.get("indel", 0)) if rank == 0 else None
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         tens, my_idx = shard.scatter_batch(whole, 0, red)
@@ -244,7 +245,7 @@ def main():
         del whole
         pairs_here = int(len(my_idx))
     else:
-        batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=rank * pairs)
+        batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], first_pair=rank * pairs, indel=cfg.get("indel", 0))
         db = mz.DevBatch(batch, device=dev)                      # inputs now resident in HBM
         pairs_here = pairs
     # rotating workspaces for the pipelined form: three, or one more than the batches whose DPs the library runs side by
@@ -262,6 +263,7 @@ def main():
     # each, on the stream the kernels are launched on (outside the timed region; doubles as extra warm-up)
     kern_ms = np.zeros(4)
     kreps = max(3, min(args.steps, 20))
+    db.run()                                                     # (first use creates the library's helper streams)
     for _ in range(kreps):
         kern_ms += np.array(db.run(timed=True))
     kern_ms /= kreps

@@ -525,7 +525,14 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
      * go two abreast (the second fills the first's tail). */
     {
         hipStream_t sd = s;
-        const int depth = mz_dev_pipeline_depth(b->n);
+        int depth = mz_dev_pipeline_depth(b->n);
+        /* a large batch whose pairs went to several DP kernels runs those side by side (mzk_dp_range) and fills its own
+         * tails; a second such batch beside it only adds waves that cannot become resident (the indel mix of 20 000
+         * pairs: 390 GCUPS back to back, 360 two abreast) */
+        if (b->n > 16384 && !getenv("MZ_DP_STREAMS") && (b->dp_hint & MZ_DP_KNOWN)) {
+            const int kinds = b->dp_hint & (MZ_DP_ROW | MZ_DP_ROWBIG | MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG);
+            if (kinds & (kinds - 1)) depth = 1;
+        }
         if (depth > 1) {
             const unsigned turn = G.dp_turn++ % (unsigned)depth;
             if (turn > 0) {

@@ -152,6 +152,66 @@ void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius,
     }
 }
 
+/* Bands as pre_yama derives them from blocks with indels against the shared reference row (mz_preyama.c:240-258, then
+ * smooth): the band's centre walks down the diagonal, stands still over a run of columns only the first block has
+ * and jumps over a run only the second block has -- `events` such runs per 1 000 columns, half of each kind, lengths
+ * geometric with mean 3.  The pair's own stream decides, so shapes (N = where the walk ends) and bands agree. */
+static int indel_run(rng_t *r) { int g = 1; while (below(r, 3) != 0) ++g; return g; }
+static int indel_walk(rng_t *r, int M, int events, int32_t *centre)      /* centre: M+1 entries or NULL; returns N */
+{
+    int i = 1, c = 0;
+    if (centre) centre[0] = 0;
+    while (i <= M) {
+        const int u = (int)below(r, 1000);
+        if (2 * u < events && i > 1) {
+            int g = indel_run(r);
+            for (; g > 0 && i <= M; --g, ++i) if (centre) centre[i] = c;
+            continue;
+        }
+        if (u < events) c += indel_run(r);
+        ++c;
+        if (centre) centre[i] = c;
+        ++i;
+    }
+    return c > 11 ? c : 11;
+}
+void mz_synth_shapes_indel(int n, uint64_t seed, int64_t first_pair, int K, int L, int mlo, int mhi, int events,
+                           int32_t *aK, int32_t *aL, int32_t *aM, int32_t *aN,
+                           int64_t *offA, int64_t *offB, int64_t *offBand, int64_t totals[3])
+{
+    int64_t oa = 0, ob = 0, oband = 0;
+    int p;
+    for (p = 0; p < n; ++p) {
+        rng_t r, w;
+        rng_seed(&r, seed, (uint64_t)(first_pair + p));
+        rng_seed(&w, seed ^ 0x1D1D1D1DULL, (uint64_t)(first_pair + p));
+        aK[p] = K; aL[p] = L;
+        aM[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        aN[p] = indel_walk(&w, aM[p], events, NULL);
+        offA[p] = oa; offB[p] = ob; offBand[p] = oband;
+        oa += (int64_t)aK[p] * aM[p]; ob += (int64_t)aL[p] * aN[p]; oband += aM[p] + 1;
+    }
+    totals[0] = oa; totals[1] = ob; totals[2] = oband;
+}
+/* the bands of such a batch (after mz_synth_fill, whose diagonal bands they replace) */
+void mz_synth_bands_indel(int n, uint64_t seed, int64_t first_pair, int radius, int events, const int32_t *aM, const int32_t *aN,
+                          const int64_t *offBand, int32_t *poolLB, int32_t *poolRB)
+{
+    int p;
+#pragma omp parallel for schedule(dynamic, 64) if (n > 256)
+    for (p = 0; p < n; ++p) {
+        const int M = aM[p], N = aN[p];
+        int32_t *LB = poolLB + offBand[p], *RB = poolRB + offBand[p];
+        rng_t w;
+        int i;
+        rng_seed(&w, seed ^ 0x1D1D1D1DULL, (uint64_t)(first_pair + p));
+        indel_walk(&w, M, events, LB);
+        for (i = 0; i <= M; ++i) { if (LB[i] > N) LB[i] = N; RB[i] = LB[i]; }
+        LB[0] = 0; RB[M] = N;
+        smooth(LB, RB, M, N, radius);
+    }
+}
+
 /* src[off[i] .. off[i]+len[i]) (elements of `elem` bytes) back to back into dst: the re-packing step of sharding a
  * batch (multiz_amd/shard.py) and of sampling one (bench.py), one memcpy per segment on the host threads */
 void mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const void *src, void *dst)

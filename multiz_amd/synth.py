@@ -19,12 +19,18 @@ CONFIGS = {
     # stands for "K, L of a random tree node per pair"; `pairs` is one GPU's share
     "c4": dict(K=0, L=0, mlo=200, mhi=1000, pairs=125000, radius=30),
     "c5": dict(K=2, L=2, mlo=95000, mhi=105000, pairs=1000, radius=30),
+    # not a BASELINE configuration: C2's blocks with the bands pre_yama derives when the blocks have indels against the
+    # shared reference row, 10 runs of unshared columns per 1 000 (mean length 3) -- rows wider than 64 columns
+    "c2i": dict(K=2, L=2, mlo=900, mhi=1100, pairs=20000, radius=30, indel=10),
 }
 
 
 def describe(name: str, pairs: int) -> str:
     c = CONFIGS[name]
     rows = "K,L from a 30-leaf caterpillar+balanced guide tree (1..29 rows)" if c["K"] == 0 else f"{c['K']}+{c['L']} rows"
+    if c.get("indel"):
+        return (f"{name}: {pairs} block pairs/GPU, {rows}, M~U[{c['mlo']},{c['mhi']}], bands of blocks with {c['indel']} indel runs "
+                f"per 1000 columns (mean length 3), R={c['radius']}")
     return f"{name}: {pairs} block pairs/GPU, {rows}, M,N~U[{c['mlo']},{c['mhi']}], diag band R={c['radius']}"
 
 
@@ -38,7 +44,7 @@ def tree_nodes():
 
 
 def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, seed: int = BASE_SEED,
-               first_pair: int = 0) -> dict:
+               first_pair: int = 0, indel: int = 0) -> dict:
     l = lib()
     aK, aL, aM, aN = (np.zeros(n, dtype=np.int32) for _ in range(4))
     oA, oB, oBand = (np.zeros(n, dtype=np.int64) for _ in range(3))
@@ -47,6 +53,10 @@ def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, see
         l.mz_synth_shapes_tree.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
         l.mz_synth_shapes_tree(n, seed, first_pair, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
                                oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
+    elif indel:
+        l.mz_synth_shapes_indel.argtypes = [C.c_int, C.c_uint64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p] * 7 + [C.c_void_p]
+        l.mz_synth_shapes_indel(n, seed, first_pair, K, L, mlo, mhi, indel, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data,
+                                aN.ctypes.data, oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
     else:
         l.mz_synth_shapes.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
         l.mz_synth_shapes(n, seed, first_pair, K, L, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
@@ -59,6 +69,10 @@ def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, see
     l.mz_synth_fill(n, seed, first_pair, radius, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
                     oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data,
                     poolA.ctypes.data, poolB.ctypes.data, poolLB.ctypes.data, poolRB.ctypes.data)
+    if indel:
+        l.mz_synth_bands_indel.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 5
+        l.mz_synth_bands_indel(n, seed, first_pair, radius, indel, aM.ctypes.data, aN.ctypes.data, oBand.ctypes.data,
+                               poolLB.ctypes.data, poolRB.ctypes.data)
     return dict(K=aK, L=aL, M=aM, N=aN, offA=oA, offB=oB, offBand=oBand,
                 poolA=poolA, poolB=poolB, poolLB=poolLB, poolRB=poolRB)
 
