@@ -120,7 +120,8 @@ typedef struct mz_dev_batch {
 enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
 /* the choice the device would make, from the plan's totals (host copy) of an n-pair batch */
 int mz_walk_choice(int n, const int64_t *totals);
-/* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint), from the plan's totals (host copy) */
+/* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint; bits 8..15: the one with the most), from the plan's
+ * totals (host copy) */
 enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32 };
 int mz_dp_hint(int n, const int64_t *totals);
 
