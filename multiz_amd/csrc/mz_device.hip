@@ -284,7 +284,7 @@ extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
 }
 
 // Side streams of mzk_dp_range, one set per device (created on first use; a device's calls come from one host thread)
-struct DpSide { int ready; hipStream_t s[4]; hipEvent_t fork, join[4]; };
+struct DpSide { int ready; hipStream_t s[4]; hipEvent_t fork, join[4]; std::mutex mu; };
 static DpSide g_side[16];
 static std::mutex g_side_mu;
 static DpSide *dp_side(void)
@@ -349,6 +349,10 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
         CK(hipMemsetAsync(&b->totals[16], 0, 3 * sizeof(int64_t), main_s), "dp counters");
     DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
+    // (one set of side streams and events per DEVICE: two host threads on one device -- the tests' MZ_ALLOW_DUP_DEVICES --
+    // must not interleave their record / wait sequences; what a wait refers to is fixed when it is enqueued)
+    std::unique_lock<std::mutex> side_lock;
+    if (S) side_lock = std::unique_lock<std::mutex>(S->mu);
     if (S) CK(hipEventRecord(S->fork, main_s), "dp fork");
     int used = 0;
     for (int i = 0; i < 5; ++i) {

@@ -50,6 +50,17 @@ for rep in range(2):
         assert mo.fnv1a_np(got, mo.fnv1a_np(np.array([om[i]], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
     api.free_outs(outs)
 assert lib.mz_device_count() == (2 if mode == "dup" else 1)
+# bands of blocks with indels: row-parallel, lagged and wavefront pairs in every chunk, their DP kernels side by side -- on
+# both contexts at once in "dup" mode (one device, two host threads: the device's side streams are shared)
+batch = synth.make_batch(n, 2, 2, 300, 600, 30, first_pair=3, indel=10)
+jobs, outs = api.host_jobs(batch)
+assert api.yama_batch_records(jobs, outs) == 0
+om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=16)
+assert bad == 0 and (outs["status"] == 0).all() and np.array_equal(outs["OM"], om)
+for i in range(0, n, 3):
+    got = np.frombuffer(C.string_at(int(outs["cols"][i]), int(om[i]) * 4), dtype=np.uint8)
+    assert mo.fnv1a_np(got, mo.fnv1a_np(np.array([om[i]], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
+api.free_outs(outs)
 if mode == "dup":
     # block text in / block text out over both contexts (mz_preyama_batch): 60 distinct block pairs, 4 800 jobs
     import inputs
