@@ -400,7 +400,7 @@ size_t mz_dev_plan_bytes(int n)
     s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
     s += 9 * al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
     s += al256(8 * 32);                    /* totals */
-    s += al256(4 * N) + al256(8 * 8 * (N / 256 + 2));   /* packList, scanAux */
+    s += al256(4 * N) + al256(8 * 8 * (N / 64 + 2));    /* packList, scanAux */
     s += al256(4 * N) + al256(12 * N);     /* om, final3 */
     return s;
 }
@@ -416,7 +416,7 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N); TAKE(szPrep, int64_t *, 8 * N);
     TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N); TAKE(offPrep, int64_t *, 8 * N);
     TAKE(totals, int64_t *, 8 * 32);
-    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 8 * (N / 256 + 2));
+    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, 8 * 8 * (N / 64 + 2));
     TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
 #undef TAKE
 }
