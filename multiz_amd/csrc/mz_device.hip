@@ -171,6 +171,31 @@ __device__ __forceinline__ int t_hi(const int *LB, int M, int c)        // last 
     return lo;
 }
 
+// The kernels that take their pairs from a shared counter (k_dp, k_dp_wide, k_dp_lag).  The plan's prefix sums leave, in
+// b.packList, the indices of the pairs of each of these kernels one list after the other (wavefront / strip, blocks of
+// 128+ rows, lagged; k_scan3): a wave's atomic increment IS its next pair -- no walking through the batch's indices
+// (a handful of wavefront pairs in 50 000 would cost a few waves 50 000 atomics), and the launch needs no more waves
+// than the list has pairs (mz_dp_grid) while the pairs still go to whichever wave is free.  A launch over a PART of
+// the batch (first, count) walks the indices of its range one by one instead.
+template <class Pred, class Body>
+__device__ __forceinline__ void for_my_pairs(const mz_dev_batch &b, unsigned long long *next, int list_first, int list_count,
+                                             int first, int count, int lane, Pred mine_is, Body run)
+{
+    const bool whole = first == 0 && count == b.n;
+    const int limit = whole ? list_count : count;
+    for (;;) {
+        int k = 0;
+        if (lane == 0) k = (int)atomicAdd(next, 1ULL);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= limit) break;
+        int p;
+        if (whole) { p = __builtin_amdgcn_readfirstlane(b.packList[list_first + k]); if (b.status[p] != MZ_OK) continue; }   // (k_fit may have failed it since)
+        else { p = first + k; if (!mine_is(p)) continue; }
+        run(p);
+        __syncthreads();                               // the next pair restages the same LDS
+    }
+}
+
 #include "kernels/plan.inc"
 #include "kernels/wavefront_exact.inc"
 #include "kernels/wavefront_fast.inc"
@@ -317,12 +342,28 @@ extern "C" int mz_dp_hint(int n, const int64_t *totals)
            (lag > 0 ? MZ_DP_LAG : 0) | (bit[most] << 8);
 }
 
+extern "C" int mz_dp_grid(int n, const int64_t *totals)
+{
+    const long long wf = totals[5] & 0xffffffffLL, wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
+    auto f = [](long long c) { const long long g = (c + 7) / 8; return (int)(g > 1023 ? 1023 : g); };
+    return f(wf) | (f(wide) << 10) | (f(lag) << 20);
+}
+
 // The DP of pairs [first, first+count): k_dp_row / k_dp_row_big (a block per pair; pairs of other modes leave at once), and the three
 // kernels that take their pairs from a counter (wavefront / strip, blocks of 128..255 rows, lagged row-parallel).
 // Without a hint all four go onto `stream`, one after the other.  With the plan's totals in hand (b->dp_hint) only the
 // kernels that have pairs are launched -- and side by side, on side streams forked from and joined back into `stream`,
 // when several do: a kernel that got a few hundred pairs takes as long as its longest pair, and back to back those
 // tails cost a mixed batch a quarter of its DP time (20 000 pairs with indels: 0.29 + 0.95 + 3.0 ms).
+static int grid_of(int count, int most, int field)       // waves for a counter kernel: pairs (8 x field, when known), at most `most`
+{
+    static int use = -1;                          // MZ_DP_GRID=0: the full grids (measurements)
+    if (use < 0) { const char *e = getenv("MZ_DP_GRID"); use = !(e && e[0] == '0'); }
+    if (!use) field = 0;
+    int g = count < most ? count : most;
+    if (field > 0 && 8 * field < g) g = 8 * field;
+    return g < 1 ? 1 : g;
+}
 extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
@@ -364,12 +405,14 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
             hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 1);
         else if (kinds[i] == MZ_DP_ROWBIG)
             hipLaunchKernelGGL(k_dp_row_big, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 2);
+        // (the counter kernels: no more waves than pairs -- a wave that finds the counter exhausted still had to wait for
+        //  its 9-13 KB of LDS beside the other kernels' waves, and the launch is over only when the last one has)
         else if (kinds[i] == MZ_DP_WAVEFRONT)
-            hipLaunchKernelGGL(k_dp, dim3(count < 6144 ? count : 6144), dim3(WAVE), dyn_lds, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp, dim3(grid_of(count, 6144, b->dp_grid & 1023)), dim3(WAVE), dyn_lds, s, *b, first, count);
         else if (kinds[i] == MZ_DP_WIDE)
-            hipLaunchKernelGGL(k_dp_wide, dim3(count < 2048 ? count : 2048), dim3(WAVE), 0, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
         else
-            hipLaunchKernelGGL(k_dp_lag, dim3(count < 4096 ? count : 4096), dim3(WAVE), 0, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), 0, s, *b, first, count);
         if (side) { CK(hipEventRecord(S->join[used], s), "dp join"); ++used; }
     }
     for (int i = 0; i < used; ++i) CK(hipStreamWaitEvent(main_s, S->join[i], 0), "dp join wait");

@@ -518,10 +518,11 @@ def test_lagged_schedule(mz):
         m_, o0 = int(res["om"][i]), int(res["offOut"][i])
         assert m_ == w.OM and np.array_equal(db.out[o0: o0 + m_ * 5].cpu().numpy().reshape(m_, 5), w.cols), (i, int(res["mode"][i]))
     assert nlag > 50, nlag
-    # the same batch without the caller's hints (mz_dev_batch.dp_hint = walk_hint = 0: every DP kernel launched, one
+    # the same batch without the caller's hints (mz_dev_batch.dp_hint = dp_grid = walk_hint = 0: every DP kernel launched, one
     # after the other, the device choosing the walk) gives the same bytes
     db2 = mz.DevBatch(batch)
     db2.c.dp_hint = 0
+    db2.c.dp_grid = 0
     db2.c.walk_hint = 0
     db2.run()
     res2 = db2.results()
