@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # (a c2 step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i", "c4i"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")

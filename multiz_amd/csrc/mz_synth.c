@@ -185,8 +185,11 @@ void mz_synth_shapes_indel(int n, uint64_t seed, int64_t first_pair, int K, int 
         rng_t r, w;
         rng_seed(&r, seed, (uint64_t)(first_pair + p));
         rng_seed(&w, seed ^ 0x1D1D1D1DULL, (uint64_t)(first_pair + p));
-        aK[p] = K; aL[p] = L;
         aM[p] = mlo + (int)below(&r, (unsigned)(mhi - mlo + 1));
+        if (K == 0 && L == 0) {                          /* (K, L) of a random node of the C4 guide tree */
+            const unsigned node = below(&r, 29);
+            aK[p] = tree30[node][0]; aL[p] = tree30[node][1];
+        } else { aK[p] = K; aL[p] = L; }
         aN[p] = indel_walk(&w, aM[p], events, NULL);
         offA[p] = oa; offB[p] = ob; offBand[p] = oband;
         oa += (int64_t)aK[p] * aM[p]; ob += (int64_t)aL[p] * aN[p]; oband += aM[p] + 1;

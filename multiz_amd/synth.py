@@ -22,6 +22,8 @@ CONFIGS = {
     # not a BASELINE configuration: C2's blocks with the bands pre_yama derives when the blocks have indels against the
     # shared reference row, 10 runs of unshared columns per 1 000 (mean length 3) -- rows wider than 64 columns
     "c2i": dict(K=2, L=2, mlo=900, mhi=1100, pairs=20000, radius=30, indel=10),
+    # ... and the guide-tree workload's blocks (1..29 rows) with such bands
+    "c4i": dict(K=0, L=0, mlo=200, mhi=1000, pairs=50000, radius=30, indel=10),
 }
 
 
@@ -49,7 +51,7 @@ def make_batch(n: int, K: int, L: int, mlo: int, mhi: int, radius: int = 30, see
     aK, aL, aM, aN = (np.zeros(n, dtype=np.int32) for _ in range(4))
     oA, oB, oBand = (np.zeros(n, dtype=np.int64) for _ in range(3))
     tot = (C.c_int64 * 3)()
-    if K == 0 and L == 0:                # the tree workload (configs[3])
+    if K == 0 and L == 0 and not indel:  # the tree workload (configs[3])
         l.mz_synth_shapes_tree.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p]
         l.mz_synth_shapes_tree(n, seed, first_pair, mlo, mhi, aK.ctypes.data, aL.ctypes.data, aM.ctypes.data, aN.ctypes.data,
                                oA.ctypes.data, oB.ctypes.data, oBand.ctypes.data, C.cast(tot, C.c_void_p))
