@@ -86,6 +86,9 @@ typedef struct mz_dev_batch {
                               only the kernels that have pairs are launched, side by side when there are several */
     int32_t dp_grid;       /* 0: unknown; else mz_dp_grid() of the plan's totals: how many waves the DP kernels that take their pairs from a
                               counter need (three 10-bit fields, pairs / 8 rounded up: wavefront, blocks of 128+ rows, lagged) */
+    int32_t dp_rows;       /* 0: unknown; else mz_dp_rows() of the plan's totals: the batch's row-parallel pairs (k_dp_row then launches
+                              that many blocks, each taking its pair from the plan's list, instead of one per pair of the batch) */
+    int32_t pad_;
     int32_t walk_hint;     /* 0: let the device choose the traceback-walk kernel of a batch that runs beside another batch's
                               DP (both kernels are launched, one returns at once); MZ_WALK_RUNS / MZ_WALK_CHASE: the caller
                               has read the plan's totals and chosen (mz_walk_choice()) -- one launch */
@@ -106,7 +109,7 @@ typedef struct mz_dev_batch {
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
                               [11] rows (K+L) of all valid pairs, [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
-    int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows and of the lagged kernel, one list after the other */
+    int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */
     uint32_t *tbw;
@@ -126,6 +129,7 @@ int mz_walk_choice(int n, const int64_t *totals);
 enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32 };
 int mz_dp_hint(int n, const int64_t *totals);
 int mz_dp_grid(int n, const int64_t *totals);
+int mz_dp_rows(int n, const int64_t *totals);
 
 typedef struct mz_score_model {
     int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */

@@ -342,6 +342,11 @@ extern "C" int mz_dp_hint(int n, const int64_t *totals)
            (lag > 0 ? MZ_DP_LAG : 0) | (bit[most] << 8);
 }
 
+extern "C" int mz_dp_rows(int n, const int64_t *totals)
+{
+    const long long row = (long long)n - totals[3] - (totals[5] & 0xffffffffLL) - (totals[8] & 0xffffffffLL) - (totals[8] >> 32);
+    return row > 0 ? (int)row : 0;
+}
 extern "C" int mz_dp_grid(int n, const int64_t *totals)
 {
     const long long wf = totals[5] & 0xffffffffLL, wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
@@ -385,6 +390,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         for (int i = 0; known && i < 4; ++i)                         // move it to the end, the rest keep their order
             if (kinds[i] == most) { for (int j = i; j < 4; ++j) kinds[j] = kinds[j + 1]; kinds[4] = most; break; }
     }
+    const bool rows_listed = known && b->dp_rows > 0 && b->dp_rows < count && first == 0 && count == b->n;
     int nk = 0, last = 0;
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
@@ -401,10 +407,11 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         const bool side = S && i != last;
         hipStream_t s = main_s;
         if (side) { s = S->s[used]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
+        // (the row kernels: a block per pair of the batch, or -- whole batch, counts known -- per entry of the plan's list)
         if (kinds[i] == MZ_DP_ROW)
-            hipLaunchKernelGGL(k_dp_row, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 1);
+            hipLaunchKernelGGL(k_dp_row, dim3(rows_listed ? b->dp_rows : count), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
         else if (kinds[i] == MZ_DP_ROWBIG)
-            hipLaunchKernelGGL(k_dp_row_big, dim3(count), dim3(WAVE), dyn_lds, s, *b, first, count, known ? 0 : 2);
+            hipLaunchKernelGGL(k_dp_row_big, dim3(rows_listed ? b->dp_rows : count), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 2);
         // (the counter kernels: no more waves than pairs -- a wave that finds the counter exhausted still had to wait for
         //  its 9-13 KB of LDS beside the other kernels' waves, and the launch is over only when the last one has)
         else if (kinds[i] == MZ_DP_WAVEFRONT)

@@ -731,7 +731,7 @@ static int chunk_launch(chunk *c)
     b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
     b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
     b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
-    b.dp_grid = mz_dp_grid(n, totals);
+    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals);
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
 
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit(&b, st))
@@ -1046,7 +1046,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
     b.prep = (uint32_t *)X->d_prep[0].p; b.capPrep = (int64_t)(X->d_prep[0].cap / 4);
     b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = (int64_t)X->d_out[0].cap;
     r.rows = (uint8_t *)X->d_pre[5].p;
-    b.dp_hint = mz_dp_hint(n, totals); b.dp_grid = mz_dp_grid(n, totals);
+    b.dp_hint = mz_dp_hint(n, totals); b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals);
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 0) || mzk_emit(&b, st) || mzk_post(&r, &b, st))
         return set_err("%s", mzk_last_error());
 

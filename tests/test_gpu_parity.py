@@ -523,6 +523,7 @@ def test_lagged_schedule(mz):
     db2 = mz.DevBatch(batch)
     db2.c.dp_hint = 0
     db2.c.dp_grid = 0
+    db2.c.dp_rows = 0
     db2.c.walk_hint = 0
     db2.run()
     res2 = db2.results()
