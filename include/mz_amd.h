@@ -108,7 +108,7 @@ typedef struct mz_dev_batch {
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
-                              [11] rows (K+L) of all valid pairs, [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
+                              [11] rows (K+L) of all valid pairs, [12] bytes of the packed outputs (host path), [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
     int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
     /* workspaces + results (device) */

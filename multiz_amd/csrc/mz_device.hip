@@ -457,9 +457,24 @@ extern "C" int mz_walk_choice(int n, const int64_t *totals)
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
-    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, 0);
+    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, 0);
     CK(hipGetLastError(), "emit launch");
+    return 0;
+}
+// the emit of a whole batch with the outputs PACKED (after the walk): szScript becomes the pairs' offsets into b.out,
+// totals[12] the bytes they fill
+extern "C" int mzk_emit_packed(const mz_dev_batch *b, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (b->n + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(k_pack1, dim3(nblk), dim3(WAVE), 0, s, *b);
+    hipLaunchKernelGGL(k_pack2, dim3(1), dim3(WAVE), 0, s, *b, nblk);
+    hipLaunchKernelGGL(k_pack3, dim3(nblk), dim3(WAVE), 0, s, *b);
+    hipLaunchKernelGGL(k_emit, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
+    hipLaunchKernelGGL(k_emit_wide, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
+    CK(hipGetLastError(), "packed emit launch");
     return 0;
 }
 extern "C" int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream)

@@ -87,7 +87,7 @@ typedef struct mz_ctx {
     gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS], d_band[MZ_SETS];
     gbuf d_pre[6], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
-    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
+    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bsmall[MZ_SETS];
     struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
     int ws_victim;
 } mz_ctx;
@@ -133,6 +133,7 @@ static int ctx_open(mz_ctx *X, int device)
     for (i = 0; i < MZ_SETS; ++i) {
         HIPCK(hipEventCreateWithFlags(&X->bdone[i], hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&X->bplan[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&X->bsmall[i], hipEventDisableTiming));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&X->evs[i], hipEventDisableTiming));
@@ -157,6 +158,7 @@ static void ctx_close(mz_ctx *X)
         if (s >= 1 && X->bstream[s]) hipStreamDestroy(X->bstream[s]);
         hipEventDestroy(X->bdone[s]);
         hipEventDestroy(X->bplan[s]);
+        hipEventDestroy(X->bsmall[s]);
     }
     for (i = 0; i < 6; ++i) if (X->d_pre[i].p) { hipFree(X->d_pre[i].p); X->d_pre[i].p = NULL; X->d_pre[i].cap = 0; }
     for (i = 0; i < 2; ++i) if (X->h_pre[i].p) { hipHostFree(X->h_pre[i].p); X->h_pre[i].p = NULL; X->h_pre[i].cap = 0; }
@@ -574,8 +576,12 @@ static int g_copy_threads = MZ_COPY_THREADS;   /* per device worker; fewer each 
 /* One chunk of a host batch in flight, on the stream and buffers of set `set`, in three steps:
  *   chunk_upload()  packs the jobs into pinned memory and issues the copy to the device, the plan and the copy of
  *                   the plan's totals back (asynchronous: the host goes on to pack the next chunk);
- *   chunk_launch()  waits for those totals, sizes the workspaces and issues the kernels and the copy of the results;
- *   chunk_collect() waits for the results and fills the caller's outs. */
+ *   chunk_launch()  waits for those totals, sizes the workspaces and issues the kernels and the copy of the per-pair
+ *                   results (status, OM, scores, where each pair's merged columns start in the PACKED output, and how
+ *                   many bytes that is);
+ *   chunk_fetch()   waits for those and issues the copy of the merged columns: what they fill (4.4 KB per C2 pair), not
+ *                   the slices the plan laid out by their upper bound (8.0 KB);
+ *   chunk_collect() waits for the columns and fills the caller's outs. */
 typedef struct chunk {
     mz_ctx *X;
     int set, n;
@@ -584,6 +590,7 @@ typedef struct chunk {
     mz_dev_batch b;
     int64_t out_bytes, in_bytes;
     double t_pack, t_plan;
+    int fetched;
 } chunk;
 
 static int chunk_upload(mz_ctx *X, chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
@@ -734,11 +741,12 @@ static int chunk_launch(chunk *c)
     b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals);
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
 
-    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit(&b, st))
+    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit_packed(&b, st))
         return set_err("%s", mzk_last_error());
 
-    /* results: status, badrow, om (int32 x n), final3 (3n), offOut (int64 x n), then the merged columns */
-    res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + al256((size_t)totals[2]);
+    /* results: status, badrow, om (int32 x n), final3 (3n), packed offsets (int64 x n), packed bytes (one int64), then
+     * the merged columns (chunk_fetch: their size is not known here; the buffer is sized for the unpacked layout) */
+    res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + 256 + al256((size_t)totals[2]);
     if (host_reserve(&X->h_res[set], res_bytes)) return -1;
     {
         char *r = (char *)X->h_res[set].p;
@@ -746,11 +754,27 @@ static int chunk_launch(chunk *c)
         HIPCK(hipMemcpyAsync(r, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
         HIPCK(hipMemcpyAsync(r, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, st));       r += al256(4 * (size_t)n);
         HIPCK(hipMemcpyAsync(r, b.final3, 12 * (size_t)n, hipMemcpyDeviceToHost, st));  r += al256(12 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, b.offOut, 8 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(8 * (size_t)n);
-        if (totals[2] > 0) HIPCK(hipMemcpyAsync(r, b.out, (size_t)totals[2], hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(r, b.szScript, 8 * (size_t)n, hipMemcpyDeviceToHost, st)); r += al256(8 * (size_t)n);
+        HIPCK(hipMemcpyAsync(r, &b.totals[12], 8, hipMemcpyDeviceToHost, st));
     }
+    HIPCK(hipEventRecord(X->bsmall[set], st));
+    c->b = b; c->out_bytes = 0; c->fetched = 0;
+    return 0;
+}
+
+/* the merged columns of a launched chunk: as many bytes as they fill */
+static int chunk_fetch(chunk *c)
+{
+    mz_ctx *X = c->X;
+    const int n = c->n, set = c->set;
+    char *r = (char *)X->h_res[set].p + al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n);
+    hipStream_t st = X->bstream[set];
+    if (c->fetched) return 0;
+    HIPCK(hipEventSynchronize(X->bsmall[set]));
+    c->out_bytes = *(const int64_t *)r;
+    if (c->out_bytes > 0) HIPCK(hipMemcpyAsync(r + 256, c->b.out, (size_t)c->out_bytes, hipMemcpyDeviceToHost, st));
     HIPCK(hipEventRecord(X->bdone[set], st));
-    c->b = b; c->out_bytes = totals[2];
+    c->fetched = 1;
     return 0;
 }
 
@@ -771,7 +795,8 @@ static int chunk_collect(chunk *c)
     r += al256(4 * (size_t)n); ro = (int32_t *)r;
     r += al256(4 * (size_t)n); rf = (int32_t *)r;
     r += al256(12 * (size_t)n); roff = (int64_t *)r;
-    r += al256(8 * (size_t)n); rout = (uint8_t *)r;
+    r += al256(8 * (size_t)n); rout = (uint8_t *)r + 256;
+    if (chunk_fetch(c)) return -1;
     HIPCK(hipEventSynchronize(X->bdone[set]));
     t1 = now_s();
 #pragma omp parallel for schedule(static) num_threads(g_copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
@@ -833,6 +858,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
             up += m1;
         }
         STEP(chunk_launch(cur));
+        if (k > 0) STEP(chunk_fetch(&ck[(k - 1) % MZ_SETS]));     /* (its kernels were issued an iteration ago) */
         if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
         done += cur->n;
     }
