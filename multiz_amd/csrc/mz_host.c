@@ -491,7 +491,8 @@ int mz_dev_pipeline_depth(int n)
     if (forced > 0) return forced > 5 ? 5 : forced;
     if (n <= 0) return 1;
     if (n > 16384) return 2;                         /* the next batch's DP fills the tail of this one (C2: 585 -> 603 GCUPS, C4 497 -> 508) */
-    d = (5 * 1024 + n - 1) / n;                      /* waves wanted: five per SIMD, 1024 SIMDs */
+    d = (10 * 1024 + n - 1) / n;                     /* waves wanted: twice five per SIMD, 1024 SIMDs -- a batch that just fills the GPU still
+                                                      * tails off (C3, 5 000 pairs: 506 GCUPS two abreast, 515 three abreast, 459 four) */
     return d < 2 ? 2 : d > 5 ? 5 : d;
 }
 
