@@ -88,7 +88,11 @@ typedef struct mz_dev_batch {
                               counter need (three 10-bit fields, pairs / 8 rounded up: wavefront, blocks of 128+ rows, lagged) */
     int32_t dp_rows;       /* 0: unknown; else mz_dp_rows() of the plan's totals: the batch's row-parallel pairs (k_dp_row then launches
                               that many blocks, each taking its pair from the plan's list, instead of one per pair of the batch) */
-    int32_t pad_;
+    int32_t hint_gen;      /* mz_hint_generation() at the time dp_hint / dp_grid / dp_rows / walk_hint were derived.  The hints describe
+                              the plan made under ONE kernel selection and score model; every run re-plans on the device under the
+                              CURRENT ones (mz_enable_row / mz_enable_fast / mz_set_scores / init_scores85 may have been called since),
+                              so hints stamped with another generation -- or not stamped, 0 -- are ignored: every DP kernel is launched
+                              over the whole batch and the device chooses the walk, as if dp_hint were 0 */
     int32_t walk_hint;     /* 0: let the device choose the traceback-walk kernel of a batch that runs beside another batch's
                               DP (both kernels are launched, one returns at once); MZ_WALK_RUNS / MZ_WALK_CHASE: the caller
                               has read the plan's totals and chosen (mz_walk_choice()) -- one launch */
@@ -130,6 +134,9 @@ enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_
 int mz_dp_hint(int n, const int64_t *totals);
 int mz_dp_grid(int n, const int64_t *totals);
 int mz_dp_rows(int n, const int64_t *totals);
+/* generation of the kernel selection + score model the devices hold now (>= 1 once initialised; it changes whenever a
+ * new model is uploaded): the stamp for mz_dev_batch.hint_gen */
+int mz_hint_generation(void);
 
 typedef struct mz_score_model {
     int32_t S6[36];        /* 6x6 class matrix {A,C,G,T,-,other}, from ss[][] (mz_scores.c:34-54) */
@@ -147,7 +154,8 @@ typedef struct mz_score_model {
  * mz_last_error() set.  There is NO CPU fallback: without a usable HIP device every entry
  * point fails. */
 int  mz_init(int device);
-/* The same on several GPUs of the node (devices == NULL: GPUs 0..ngpu-1); the first is the primary device, where
+/* The same on several GPUs of the node (devices == NULL: GPUs first..first+ngpu-1, first = MZ_DEVICE in the
+ * environment, default 0 -- the GPUs an environment-driven start opens); the first is the primary device, where
  * the device-resident API (mz_dev_*) runs.  mz_yama_batch() then deals a large batch out over all of them -- one host
  * thread, one set of streams and staging buffers per GPU, contiguous ranges of the job list balanced by band size;
  * block pairs are independent, so there is no exchange between GPUs.  Without an explicit call the first use of the

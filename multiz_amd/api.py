@@ -38,7 +38,7 @@ class Out(C.Structure):
 
 
 class DevBatchC(C.Structure):
-    _fields_ = [("n", C.c_int32), ("dp_hint", C.c_int32), ("dp_grid", C.c_int32), ("dp_rows", C.c_int32), ("pad_", C.c_int32), ("walk_hint", C.c_int32)] + \
+    _fields_ = [("n", C.c_int32), ("dp_hint", C.c_int32), ("dp_grid", C.c_int32), ("dp_rows", C.c_int32), ("hint_gen", C.c_int32), ("walk_hint", C.c_int32)] + \
         [(k, C.c_void_p) for k in ("K", "L", "M", "N", "offA", "offB", "offBand", "poolA", "poolB", "poolLB", "poolRB",
                                    "status", "badrow", "mode", "cells", "edgeLo", "edgeHi", "szTb", "szScript", "szOut", "szPrep",
                                    "offTb", "offScript", "offOut", "offPrep", "totals", "packList", "scanAux",
@@ -254,6 +254,9 @@ class DevBatch:
         self.c.dp_grid = lib().mz_dp_grid(n, tot16.ctypes.data)           # (and no more waves than pairs for the counter kernels)
         lib().mz_dp_rows.argtypes = [C.c_int, C.c_void_p]
         self.c.dp_rows = lib().mz_dp_rows(n, tot16.ctypes.data)           # (nor more blocks than row-parallel pairs)
+        # the hints hold for the kernel selection and scores in force NOW; the library ignores them (every kernel launched,
+        # as with dp_hint = 0) if mz_enable_row / mz_enable_fast / mz_set_scores changed things before run()
+        self.c.hint_gen = lib().mz_hint_generation()
         tb = int(tot[0]) if cap_tb is None else int(cap_tb)
         sc, ou, pr = int(tot[1]), int(tot[2]), int(tot[4])
         self.tbw = torch.empty(tb + 64, dtype=torch.int32, device=self.dev)

@@ -39,6 +39,7 @@ typedef struct mz_post_batch {
 int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
 int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream);
 const char *mzk_last_error(void);
+void mzk_release_device(int dev);      /* destroy the launchers' side streams and events of one GPU (mz_finalize) */
 #ifdef __cplusplus
 }
 #endif

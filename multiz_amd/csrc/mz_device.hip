@@ -328,6 +328,23 @@ static DpSide *dp_side(void)
     return S;
 }
 
+// mz_finalize(): the side streams and events of one device go with its context
+extern "C" void mzk_release_device(int dev)
+{
+    if (dev < 0 || dev >= 16) return;
+    DpSide *S = &g_side[dev];
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    if (!S->ready) return;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(dev) == hipSuccess) {
+        for (int i = 0; i < 4; ++i) { (void)hipStreamSynchronize(S->s[i]); (void)hipStreamDestroy(S->s[i]); (void)hipEventDestroy(S->join[i]); }
+        (void)hipEventDestroy(S->fork);
+    }
+    S->ready = 0;
+    if (have) (void)hipSetDevice(cur);
+}
+
 extern "C" int mz_dp_hint(int n, const int64_t *totals)
 {
     const long long failed = totals[3], wf = totals[5] & 0xffffffffLL, rowbig = totals[5] >> 32, wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;

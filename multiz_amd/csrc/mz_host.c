@@ -209,12 +209,21 @@ int mz_init(int device)
     return init_devices(1, NULL, device);
 }
 
+/* devices == NULL: first, first+1, ... with first = MZ_DEVICE (default 0) -- the same GPUs the environment-driven
+ * start (ensure_init) opens, so an explicit call after one is a no-op instead of a tear-down under running batches */
+static int env_first_device(void)
+{
+    const char *e = getenv("MZ_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
 int mz_init_multi(int ngpu, const int *devices)
 {
+    const int first = env_first_device();
     int i, same = g_ndev == ngpu;
-    for (i = 0; same && i < ngpu; ++i) same = g_dev[i].ready && g_dev[i].device == (devices ? devices[i] : i);
+    for (i = 0; same && i < ngpu; ++i) same = g_dev[i].ready && g_dev[i].device == (devices ? devices[i] : first + i);
     if (same) return 0;
-    return init_devices(ngpu, devices, 0);
+    return init_devices(ngpu, devices, first);
 }
 
 int mz_device_count(void) { return g_ndev; }
@@ -231,7 +240,10 @@ static int lazy_stream(hipStream_t *s)
 void mz_finalize(void)
 {
     int i;
-    for (i = 0; i < g_ndev; ++i) ctx_close(&g_dev[i]);
+    for (i = 0; i < g_ndev; ++i) {
+        ctx_close(&g_dev[i]);
+        mzk_release_device(g_dev[i].device);   /* the launchers' side streams and events on that GPU */
+    }
     g_ndev = 0;
     g_score_have = 0;
 }
@@ -239,14 +251,13 @@ void mz_finalize(void)
 /* first use without mz_init(): MZ_DEVICE = first GPU (default 0), MZ_NGPU = how many (default 1) */
 static int ensure_init(void)
 {
-    const char *e, *n;
+    const char *n;
     int ngpu;
     if (g_ndev) return 0;
-    e = getenv("MZ_DEVICE");
     n = getenv("MZ_NGPU");
     ngpu = n ? atoi(n) : 1;
-    if (ngpu <= 1) return mz_init(e ? atoi(e) : 0);
-    return init_devices(ngpu, NULL, e ? atoi(e) : 0);
+    if (ngpu <= 1) return mz_init(env_first_device());
+    return init_devices(ngpu, NULL, env_first_device());
 }
 
 /* ------------------------------------------------------------------ scores */
@@ -309,9 +320,23 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
 
 /* the model goes to every context's __constant__ copy.  Kernels of earlier calls may still be reading it
  * (mz_dev_run_async, another caller's stream), so each device is drained first; score changes are rare. */
+static int g_hint_gen;                     /* bumped with every upload: hints of a plan made under another model are void */
+int mz_hint_generation(void) { return g_hint_gen; }
+
+/* the batch as the launchers may see it: hints (include/mz_amd.h) only when they were derived under the selection and
+ * scores in force now -- a stale dp_hint would skip the kernels of modes the re-plan assigns */
+static const mz_dev_batch *checked_hints(const mz_dev_batch *b, mz_dev_batch *tmp)
+{
+    if (!(b->dp_hint | b->dp_grid | b->dp_rows | b->walk_hint) || b->hint_gen == g_hint_gen) return b;
+    *tmp = *b;
+    tmp->dp_hint = tmp->dp_grid = tmp->dp_rows = tmp->walk_hint = 0;
+    return tmp;
+}
+
 static int upload_everywhere(const mz_score_model *m)
 {
     int i;
+    g_hint_gen = g_hint_gen >= 0x7ffffff0 ? 1 : g_hint_gen + 1;
     for (i = 0; i < g_ndev; ++i) {
         HIPCK(hipSetDevice(g_dev[i].device));
         HIPCK(hipDeviceSynchronize());
@@ -433,12 +458,16 @@ int mz_dev_plan(const mz_dev_batch *b, void *stream)
 }
 int mz_dev_dp(const mz_dev_batch *b, void *stream)
 {
+    mz_dev_batch tmp;
     if (ensure_init() || sync_global_scores()) return -1;
+    b = checked_hints(b, &tmp);
     return mzk_dp(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_walk(const mz_dev_batch *b, void *stream)
 {
+    mz_dev_batch tmp;
     if (ensure_init()) return -1;
+    b = checked_hints(b, &tmp);
     return mzk_walk(b, pick_stream(stream), 0) ? set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_emit(const mz_dev_batch *b, void *stream)
@@ -450,8 +479,10 @@ int mz_dev_emit(const mz_dev_batch *b, void *stream)
 int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
 {
     hipStream_t s;
+    mz_dev_batch tmp;
     int i;
     if (ensure_init() || sync_global_scores()) return -1;
+    b = checked_hints(b, &tmp);
     s = (hipStream_t)pick_stream(stream);
     if (ms) {                              /* serial, one HIP event pair per phase */
         HIPCK(hipEventRecord(G.ev[0], s));
@@ -499,8 +530,10 @@ int mz_dev_pipeline_depth(int n)
 int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
 {
     hipStream_t s;
+    mz_dev_batch tmp;
     int w, slot = -1;
     if (ensure_init() || sync_global_scores() || lazy_stream(&G.stream2) || lazy_stream(&G.stream3)) return -1;
+    b = checked_hints(b, &tmp);
     s = (hipStream_t)pick_stream(stream);
     for (w = 0; w < MZ_WS_MAX; ++w) if (G.ws[w].used && G.ws[w].key == (const void *)b->tbw) slot = w;
     if (slot < 0) {
@@ -739,7 +772,7 @@ static int chunk_launch(chunk *c)
     b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
     b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
     b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
-    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals);
+    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
 
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit_packed(&b, st))
@@ -1073,7 +1106,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
     b.prep = (uint32_t *)X->d_prep[0].p; b.capPrep = (int64_t)(X->d_prep[0].cap / 4);
     b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = (int64_t)X->d_out[0].cap;
     r.rows = (uint8_t *)X->d_pre[5].p;
-    b.dp_hint = mz_dp_hint(n, totals); b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals);
+    b.dp_hint = mz_dp_hint(n, totals); b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 0) || mzk_emit(&b, st) || mzk_post(&r, &b, st))
         return set_err("%s", mzk_last_error());
 

@@ -8,16 +8,17 @@
  * main).  That four-argument form is what is restated here; the "beautify" pass of the stand-alone tool (used only
  * when no file for the other blocks is named, maf_project.c:367-481) and its from/to and tree arguments are not.
  */
+#include <pthread.h>
 #include "mz_drivers.h"
 
 /* complement of a nucleotide code, case kept; anything that is not a code becomes a blank (the table of
  * reference multi_util.c:34-38) */
 static unsigned char g_compl[256];
-static void compl_init(void)
+static pthread_once_t g_compl_once = PTHREAD_ONCE_INIT;   /* begin_node() projects both sides in parallel sections */
+static void compl_fill(void)
 {
     static const char pairs[] = "ATCGBVDHKMRYSSWWXXNN";
     int i;
-    if (g_compl['A']) return;
     memset(g_compl, ' ', sizeof g_compl);
     g_compl['-'] = '-';
     for (i = 0; pairs[i]; i += 2) {
@@ -31,7 +32,7 @@ static void compl_init(void)
 static void block_revcomp(struct mafAli *a)
 {
     struct mafComp *c;
-    compl_init();
+    pthread_once(&g_compl_once, compl_fill);
     for (c = a->components; c; c = c->next) {
         char *s = c->text, *p = c->text + a->textSize - 1;
         c->start = c->srcSize - (c->start + c->size);

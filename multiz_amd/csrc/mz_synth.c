@@ -215,15 +215,16 @@ void mz_synth_bands_indel(int n, uint64_t seed, int64_t first_pair, int radius, 
     }
 }
 
-/* src[off[i] .. off[i]+len[i]) (elements of `elem` bytes) back to back into dst: the re-packing step of sharding a
- * batch (multiz_amd/shard.py) and of sampling one (bench.py), one memcpy per segment on the host threads */
-void mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const void *src, void *dst)
+/* src[off[i] .. off[i]+len[i]) (elements of `elem` bytes) to dst[pos[i] ..): the re-packing step of sharding a
+ * batch (multiz_amd/shard.py) and of sampling one (bench.py), one memcpy per segment on the host threads.  `pos` is the
+ * caller's exclusive prefix sum of len (no allocation here, nothing that can fail half-way).  Returns 0, -1 on bad
+ * arguments. */
+int mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const int64_t *pos, const void *src, void *dst)
 {
-    int64_t *pos = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof *pos), acc = 0, i;
-    if (!pos) return;
-    for (i = 0; i < n; ++i) { pos[i] = acc; acc += len[i]; }
+    int64_t i;
+    if (n < 0 || elem <= 0 || (n > 0 && (!off || !len || !pos || !src || !dst))) return -1;
 #pragma omp parallel for schedule(static) if (n > 1024)
     for (i = 0; i < n; ++i)
         memcpy((char *)dst + pos[i] * elem, (const char *)src + off[i] * elem, (size_t)(len[i] * elem));
-    free(pos);
+    return 0;
 }

@@ -56,9 +56,13 @@ def _gather(pool: np.ndarray, off: np.ndarray, ln: np.ndarray) -> np.ndarray:
     ln = np.ascontiguousarray(ln, dtype=np.int64)
     out = np.empty(int(ln.sum()), dtype=pool.dtype)
     if len(off):
+        pos = np.ascontiguousarray(np.cumsum(ln) - ln, dtype=np.int64)
+        src = np.ascontiguousarray(pool)
         f = lib().mz_gather_segments
-        f.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        f(len(off), pool.dtype.itemsize, off.ctypes.data, ln.ctypes.data, np.ascontiguousarray(pool).ctypes.data, out.ctypes.data)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        if f(len(off), pool.dtype.itemsize, off.ctypes.data, ln.ctypes.data, pos.ctypes.data, src.ctypes.data, out.ctypes.data) != 0:
+            raise RuntimeError("mz_gather_segments failed (bad arguments)")
     return out
 
 

@@ -74,3 +74,28 @@ int mzo_ref_batch(const char *libref_path, int n, const int *K, const int *L, co
     if (cells_done) *cells_done = total;
     return bad;
 }
+
+/* `threads` threads each run the same register-only integer chain of `iters` steps: wall seconds.  A box that gives
+ * every thread a core takes the same time at any thread count; a CPU quota, SMT sharing or oversubscribed vCPUs show
+ * up here without any memory traffic (tests/tools/cpu_scaling.py, bench.py's cpu_baseline.scaling). */
+#include <time.h>
+double mzo_spin(int threads, int64_t iters)
+{
+    struct timespec t0, t1;
+    uint64_t sink = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel num_threads(threads) reduction(+:sink)
+    {
+        uint64_t x = 88172645463325252ULL + (uint64_t)
+#ifdef _OPENMP
+            omp_get_thread_num();
+#else
+            0;
+#endif
+        int64_t i;
+        for (i = 0; i < iters; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; }
+        sink += x;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) + (sink == 42 ? 1e-12 : 0.0);
+}

@@ -15,13 +15,13 @@ void mz_synth_shapes_tree(int n, uint64_t seed, int64_t first_pair, int mlo, int
 void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius, const int32_t *aK, const int32_t *aL, const int32_t *aM,
                    const int32_t *aN, const int64_t *offA, const int64_t *offB, const int64_t *offBand, uint8_t *poolA, uint8_t *poolB,
                    int32_t *poolLB, int32_t *poolRB);
-void mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const void *src, void *dst);
+int mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const int64_t *pos, const void *src, void *dst);
 
 int main(void)
 {
     enum { n = 300 };
     int32_t K[n], L[n], M[n], N[n];
-    int64_t oa[n], ob[n], od[n], tot[3], off[n], len[n];
+    int64_t oa[n], ob[n], od[n], tot[3], off[n], len[n], pos[n];
     uint8_t *A, *B, *G;
     int32_t *LB, *RB;
     long long sum = 0;
@@ -33,7 +33,8 @@ int main(void)
         mz_synth_fill(n, 7, t ? 100 : 0, 30, K, L, M, N, oa, ob, od, A, B, LB, RB);
         for (p = 0; p < n; ++p) { off[p] = oa[n - 1 - p]; len[p] = (int64_t)K[n - 1 - p] * M[n - 1 - p]; sum += LB[od[p] + M[p]] + RB[od[p]]; }
         G = malloc((size_t)tot[0]);
-        mz_gather_segments(n, 1, off, len, A, G);
+        { int64_t acc = 0; for (p = 0; p < n; ++p) { pos[p] = acc; acc += len[p]; } }
+        if (mz_gather_segments(n, 1, off, len, pos, A, G) != 0) { fprintf(stderr, "gather refused\n"); return 1; }
         if (memcmp(G, A + oa[n - 1], (size_t)len[0]) != 0) { fprintf(stderr, "gather mismatch\n"); return 1; }
         /* rmColDash + mapping on a pair's columns (1-based pointer arrays over a private copy, one spare byte) */
         for (p = 0; p < n; p += 37) {
