@@ -194,14 +194,24 @@ typedef struct mz_out {
     int badrow;               /* row named by the reference's message for status 2         */
     int OM;                   /* number of merged columns                                  */
     int score[3];             /* C, D, I at grid point (M, N)                              */
-    unsigned char *cols;      /* malloc()ed, OM*(K+L) bytes, caller frees; NULL on error   */
+    unsigned char *cols;      /* OM*(K+L) bytes: the merged columns; NULL on error.  Inside `block` of this or an
+                                 earlier entry -- not a heap pointer of its own, except in a call with n == 1           */
+    void *block;              /* non-NULL on the first pair of each chunk of the call: ONE malloc()ed block holding the
+                                 merged columns of that chunk's pairs.  Release a call's results with mz_free_outs()
+                                 (or, for n == 1: free(outs[0].cols), which is the block -- what yama() hands on)      */
 } mz_out;
 
 /* Align n independent block pairs on the GPU(s).  Returns the number of failed pairs, or -1 on a device error;
  * in either case every outs[i] is defined: status MZ_E_DEVICE and cols == NULL for pairs without a result.
- * Calls are serialised (the library state is process-wide). */
+ * What crosses the PCIe link is the byte CLASSES of the columns (two per byte), the band bounds as steps and, back,
+ * a 32-byte record and a 2-bit edit script per pair; the merged columns (reference mz_yama.c:293-313) are assembled
+ * on the host from the caller's own A and B, which must stay valid until the call returns.
+ * Calls are serialised (the library state is process-wide).  MZ_TIMING=1 in the environment: one JSON line per call on
+ * stderr (pairs, band cells, seconds, GCUPS, bytes over the link each way); MZ_TIMING=2: and one per chunk. */
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
-/* free() every outs[i].cols of a finished call and reset them to NULL */
+/* bytes the last mz_yama_batch() call moved over the PCIe link: to the device(s), and back */
+void mz_link_bytes(int64_t *up, int64_t *down);
+/* free the result blocks of a finished call (all n entries of it) and reset cols / block to NULL */
 void mz_free_outs(int n, mz_out *outs);
 
 /* ---------------------------------------------------------------- pre_yama() batches: block text in, block text out

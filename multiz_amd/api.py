@@ -34,7 +34,7 @@ class Job(C.Structure):
 
 class Out(C.Structure):
     _fields_ = [("status", C.c_int), ("badrow", C.c_int), ("OM", C.c_int), ("score", C.c_int * 3),
-                ("cols", C.c_void_p)]
+                ("cols", C.c_void_p), ("block", C.c_void_p)]
 
 
 class DevBatchC(C.Structure):
@@ -130,13 +130,15 @@ def yama_batch(pairs: Sequence[tuple]) -> List[Result]:
         if o.status == 0:
             w = jobs[i].K + jobs[i].L
             cols = np.frombuffer(C.string_at(o.cols, o.OM * w), dtype=np.uint8).reshape(o.OM, w).copy()
-            lib().free_cols(o.cols)
         res.append(Result(o.status, o.badrow, o.OM, np.array(list(o.score), dtype=np.int32), cols))
+    f = lib().mz_free_outs
+    f.argtypes = [C.c_int, C.c_void_p]
+    f(n, C.cast(outs, C.c_void_p))                   # the call's result blocks (one per chunk: mz_out.block)
     return res
 
 
 JOB_DT = np.dtype([("K", "<i4"), ("L", "<i4"), ("M", "<i4"), ("N", "<i4"), ("A", "<u8"), ("B", "<u8"), ("LB", "<u8"), ("RB", "<u8")])
-OUT_DT = np.dtype([("status", "<i4"), ("badrow", "<i4"), ("OM", "<i4"), ("score", "<i4", (3,)), ("cols", "<u8")])
+OUT_DT = np.dtype([("status", "<i4"), ("badrow", "<i4"), ("OM", "<i4"), ("score", "<i4", (3,)), ("cols", "<u8"), ("block", "<u8")])
 
 
 def host_jobs(batch: dict):
@@ -161,6 +163,14 @@ def yama_batch_records(jobs: np.ndarray, outs: np.ndarray) -> int:
     rc = lib().mz_yama_batch(len(jobs), jobs.ctypes.data_as(C.POINTER(Job)), outs.ctypes.data_as(C.POINTER(Out)))
     _check(rc, "mz_yama_batch")
     return rc
+
+
+def link_bytes(jobs: np.ndarray):
+    """(bytes to the device, bytes back) of one mz_yama_batch() call over these jobs: the library's own accounting
+    (mz_link_bytes: staging block sizes of the last call)"""
+    up, down = C.c_int64(0), C.c_int64(0)
+    lib().mz_link_bytes(C.byref(up), C.byref(down))
+    return up.value, down.value
 
 
 def free_outs(outs: np.ndarray):

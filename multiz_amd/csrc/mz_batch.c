@@ -1,0 +1,742 @@
+/* mz_batch.c -- mz_yama_batch(): N independent yama() calls (reference mz_yama.h:22, mz_yama.c:50-320) from host
+ * buffers to host buffers.
+ *
+ * What bounds this path is the PCIe link (57 GB/s in sum of both directions on this platform) and the host's own
+ * memory traffic, not the kernels, so the link carries only what the device needs (mz_pack.c): byte classes of the
+ * columns, band bounds as steps, and -- back -- a 32-byte record and a 2-bit edit script per pair.  The merged columns
+ * (reference mz_yama.c:293-313) are assembled on the host from the caller's own A and B.
+ *
+ * A call is cut into chunks that go through a three-stage pipeline on MZ_SETS rotating sets of buffers and streams:
+ *
+ *   packer     (the calling thread)  classes + band steps into pinned memory on all host threads; issues the copy to the
+ *                                    device, the expansion kernels, the plan and the copy of the plan's totals;
+ *   launcher   (helper thread)       waits for the totals, sizes the workspaces, issues DP / walk / script packing and
+ *                                    the copy of the results;
+ *   collector  (helper thread)       waits for the results, allocates ONE block for the chunk's merged columns and
+ *                                    assembles them on all host threads.
+ *
+ * No stage waits for a copy or a kernel another stage could work beside; the chunks' kernels overlap on the GPU
+ * through their streams.  A call of one chunk (the drop-in yama(): a batch of one) runs the three steps inline.
+ */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <xmmintrin.h>
+
+#include "mz_ctx.h"
+#include "mz_pack.h"
+
+/* ------------------------------------------------------------------------------------------------ one chunk */
+
+typedef struct chunk {
+    mz_ctx *X;
+    int set, n, index;
+    const mz_job *jobs;
+    mz_out *outs;
+    mz_dev_batch b;
+    int64_t in_bytes, exc_bytes, res_bytes, cells;
+    double t_pack0, t_pack1, t_launch0, t_launch1, t_launch2, t_col0, t_col1, t_col2;
+} chunk;
+
+static int job_ok(const mz_job *j) { return j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1 && j->K <= 255 && j->L <= 255; }
+/* (K, L > 255: the plan refuses the pair (MZ_E_ROWS) from K and L alone; its columns do not travel) */
+
+/* expanded bytes of a block's columns on the device: whole 64-byte groups, so that the class nibbles of a pair fill
+ * whole 32-byte lines of the staging block (streaming stores, mz_pack.c) */
+static size_t cols_padded(int rows, int cols) { return ((size_t)rows * (size_t)cols + 63) & ~(size_t)63; }
+static size_t band_slot(int M) { return ((size_t)M + 31) & ~(size_t)31; }      /* a byte per row 1..M; LB[0], RB[0] travel in the header */
+
+/* pairs per piece of the pack / assemble loops: about four pieces per host thread, at most 64 pairs (a chunk of 84
+ * long pairs -- BASELINE config 5 -- in pieces of 64 kept two threads busy and took 13 ms to assemble) */
+static int pack_grain(int n)
+{
+    const int g = n / (4 * mzi_pool_threads());
+    return g < 1 ? 1 : g > 64 ? 64 : g;
+}
+
+typedef struct pack_ctx {
+    const mz_job *jobs;
+    const int64_t *hoA, *hoB;
+    int64_t *hoC;
+    uint8_t *hA, *hB, *hC, *hFmt, *hE;
+    uint32_t *esz;
+} pack_ctx;
+
+static void pack_range(void *ctx, int lo, int hi)
+{
+    const pack_ctx *q = (const pack_ctx *)ctx;
+    int p;
+    for (p = lo; p < hi; ++p) {
+        const mz_job *j = &q->jobs[p];
+        q->esz[p] = 0;
+        q->hFmt[p] = 2;
+        if (job_ok(j)) {
+            uint32_t steps;
+            mz_pack_classes_stream(j->A, (size_t)j->K * j->M, q->hA + q->hoA[p] / 2, cols_padded(j->K, j->M) / 2);
+            mz_pack_classes_stream(j->B, (size_t)j->L * j->N, q->hB + q->hoB[p] / 2, cols_padded(j->L, j->N) / 2);
+            steps = mz_pack_band_nib_stream(j->LB, j->RB, j->M, q->hC + q->hoC[p], band_slot(j->M));
+            if (steps >= 16u) {                              /* two bytes per row, or raw: through the exception block */
+                q->hFmt[p] = steps < 256u ? 1 : 0;
+                q->esz[p] = steps < 256u ? (uint32_t)((8 + 2 * (size_t)j->M + 3) & ~(size_t)3) : (uint32_t)(8 * ((size_t)j->M + 1));
+            }
+        }
+    }
+    _mm_sfence();                                            /* the streaming stores are out before the piece is reported done */
+}
+
+static void pack_exceptions(void *ctx, int lo, int hi)
+{
+    const pack_ctx *q = (const pack_ctx *)ctx;
+    int p;
+    for (p = lo; p < hi; ++p) {
+        const mz_job *j = &q->jobs[p];
+        if (!q->esz[p]) continue;
+        if (q->hFmt[p] == 1) mz_pack_band_bytes(j->LB, j->RB, j->M, q->hE + q->hoC[p]);
+        else {
+            memcpy(q->hE + q->hoC[p], j->LB, 4 * ((size_t)j->M + 1));
+            memcpy(q->hE + q->hoC[p] + 4 * ((size_t)j->M + 1), j->RB, 4 * ((size_t)j->M + 1));
+        }
+    }
+}
+
+static int g_timing = -1;                  /* MZ_TIMING: 1 = one JSON line per call, 2 = and one per chunk (stderr) */
+#define TSTAMP(X, set, k, st) do { if (g_timing >= 2 && (X)->btime_ready) HIPCK(hipEventRecord((X)->btime[set][k], st)); } while (0)
+
+static int up_prio(void)                   /* MZ_UP_PRIO=1: upload + expansion + plan on a high-priority stream per set.  Off by default: measured
+                                            * on C2 it gains nothing -- a kernel of any priority waits for a DP wave to retire before it gets a slot */
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MZ_UP_PRIO"); v = e && e[0] == '1'; }
+    return v;
+}
+
+static int chunk_parts(void)               /* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides) */
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 12; }
+    return v;
+}
+
+static int chunk_upload(mz_ctx *X, chunk *c, int index, int set, int n, const mz_job *jobs, mz_out *outs)
+{
+    hipStream_t st;
+    mz_dev_batch b;
+    size_t eA = 0, eB = 0, nband = 0, bytesC = 0, hdr, in_bytes, nexc = 0, bytesE = 0;
+    char *h, *d;
+    int32_t *hK, *hL, *hM, *hN, *hLen, *hLB0, *hRB0;
+    const int32_t *dLen, *dLB0, *dRB0;
+    int64_t *hoA, *hoB, *hoBand, *hoC;
+    const int64_t *doC;
+    uint8_t *hFmt, *hC, *hA, *hB;
+    const uint8_t *dFmt, *dC, *dA;
+    uint32_t *esz;
+    int p;
+
+    c->t_pack0 = mzi_now_s();
+    if (mzi_lazy_stream(&X->bstream[set])) return -1;
+    st = X->bstream[set];
+    if (up_prio()) {
+        if (!X->ustream[set]) {
+            int least = 0, greatest = 0;
+            HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCK(hipStreamCreateWithPriority(&X->ustream[set], hipStreamNonBlocking, greatest));
+        }
+        st = X->ustream[set];
+    }
+    c->X = X; c->set = set; c->index = index; c->n = n; c->jobs = jobs; c->outs = outs;
+
+    for (p = 0; p < n; ++p) {
+        const mz_job *j = &jobs[p];
+        if (job_ok(j)) { eA += cols_padded(j->K, j->M); eB += cols_padded(j->L, j->N); nband += (size_t)j->M + 1; bytesC += band_slot(j->M); }
+        else { nband += 1; }
+    }
+    /* one pinned staging block: [K L M N bandLen LB0 RB0](int32 x n) [offA offB offBand offC](int64 x n) fmt(n) band steps,
+     * class nibbles of A, class nibbles of B */
+    hdr = mzi_al256(4 * (size_t)n) * 7 + mzi_al256(8 * (size_t)n) * 4 + mzi_al256((size_t)n);
+    in_bytes = hdr + mzi_al256(bytesC) + mzi_al256(eA / 2) + mzi_al256(eB / 2);
+    esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *esz);
+    if (!esz) return mzi_set_err("out of memory");
+    if (mzi_host_reserve(&X->h_in[set], in_bytes) || mzi_dev_reserve(&X->d_in[set], in_bytes) ||
+        mzi_dev_reserve(&X->d_cols[set], 2 * (mzi_al256(eA / 2) + mzi_al256(eB / 2)) + 256) ||
+        mzi_dev_reserve(&X->d_band[set], 2 * mzi_al256(4 * nband))) { free(esz); return -1; }
+    h = (char *)X->h_in[set].p; d = (char *)X->d_in[set].p;
+
+    memset(&b, 0, sizeof b);
+    b.n = n;
+#define SLICE(hptr, type, field, bytes) do { hptr = (type *)h; b.field = (const type *)d; \
+        h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
+#define SLICE2(hptr, dptr, type, bytes) do { hptr = (type *)h; dptr = (const type *)d; \
+        h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
+    SLICE(hK, int32_t, K, 4 * (size_t)n); SLICE(hL, int32_t, L, 4 * (size_t)n);
+    SLICE(hM, int32_t, M, 4 * (size_t)n); SLICE(hN, int32_t, N, 4 * (size_t)n);
+    SLICE(hoA, int64_t, offA, 8 * (size_t)n); SLICE(hoB, int64_t, offB, 8 * (size_t)n);
+    SLICE(hoBand, int64_t, offBand, 8 * (size_t)n);
+    SLICE2(hLen, dLen, int32_t, 4 * (size_t)n);
+    SLICE2(hLB0, dLB0, int32_t, 4 * (size_t)n); SLICE2(hRB0, dRB0, int32_t, 4 * (size_t)n);
+    SLICE2(hoC, doC, int64_t, 8 * (size_t)n);
+    SLICE2(hFmt, dFmt, uint8_t, (size_t)n);
+    SLICE2(hC, dC, uint8_t, bytesC);
+    SLICE2(hA, dA, uint8_t, eA / 2);
+    hB = (uint8_t *)h;
+#undef SLICE
+#undef SLICE2
+    /* the pools the kernels read: A and B expanded to a byte per class, exactly twice the nibble layout */
+    b.poolA = (const uint8_t *)X->d_cols[set].p;
+    b.poolB = b.poolA + 2 * mzi_al256(eA / 2);
+    b.poolLB = (const int32_t *)X->d_band[set].p;
+    b.poolRB = (const int32_t *)((char *)X->d_band[set].p + mzi_al256(4 * nband));
+    {
+        size_t oa = 0, ob = 0, oband = 0, oc = 0;
+        for (p = 0; p < n; ++p) {                            /* offsets first ... */
+            const mz_job *j = &jobs[p];
+            const int ok = job_ok(j);
+            hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
+            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
+            hLen[p] = ok ? j->M + 1 : 1;
+            hLB0[p] = ok ? j->LB[0] : 0; hRB0[p] = ok ? j->RB[0] : 0;         /* (an invalid job: one dummy entry, LB[0] = RB[0] = 0) */
+            if (ok) { oa += cols_padded(j->K, j->M); ob += cols_padded(j->L, j->N); oband += (size_t)j->M + 1; oc += band_slot(j->M); }
+            else { oband += 1; }
+        }
+    }
+    /* ... then the packing, on the host threads: byte classes two per byte (mz_pack_classes), band bounds a byte per row
+     * where every step is below 16 (the others are noted and sent apart, below) */
+    {
+        pack_ctx pc;
+        pc.jobs = jobs; pc.hoA = hoA; pc.hoB = hoB; pc.hoC = hoC; pc.hA = hA; pc.hB = hB; pc.hC = hC; pc.hFmt = hFmt; pc.esz = esz; pc.hE = NULL;
+        mzi_parallel_for(n, pack_grain(n), pack_range, &pc);
+    }
+    for (p = 0; p < n; ++p) if (esz[p]) { ++nexc; bytesE += esz[p]; }
+    if (nexc) {
+        size_t oe = 0;
+        uint8_t *hE;
+        if (mzi_host_reserve(&X->h_exc[set], bytesE) || mzi_dev_reserve(&X->d_exc[set], bytesE)) { free(esz); return -1; }
+        hE = (uint8_t *)X->h_exc[set].p;
+        for (p = 0; p < n; ++p) if (esz[p]) { hoC[p] = (int64_t)oe; oe += esz[p]; }
+        {
+            pack_ctx pc;
+            pc.jobs = jobs; pc.hoC = hoC; pc.hFmt = hFmt; pc.esz = esz; pc.hE = hE;
+            pc.hoA = pc.hoB = NULL; pc.hA = pc.hB = pc.hC = NULL;
+            mzi_parallel_for(n, pack_grain(n), pack_exceptions, &pc);
+        }
+    }
+    free(esz);
+    c->t_pack1 = mzi_now_s();
+    c->in_bytes = (int64_t)in_bytes; c->exc_bytes = (int64_t)bytesE;
+    TSTAMP(X, set, 0, st);
+    HIPCK(hipMemcpyAsync(X->d_in[set].p, X->h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
+    if (nexc) HIPCK(hipMemcpyAsync(X->d_exc[set].p, X->h_exc[set].p, bytesE, hipMemcpyHostToDevice, st));
+    if (mzk_unband(n, dLen, dLB0, dRB0, b.offBand, doC, dFmt, dC, (const uint8_t *)X->d_exc[set].p, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st) ||
+        mzk_unnib(dA, (void *)b.poolA, (long long)(2 * (mzi_al256(eA / 2) + mzi_al256(eB / 2))), st))
+        return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 1, st);
+
+    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
+    mz_dev_carve(&b, X->d_plan[set].p);
+    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
+    if (mzk_plan(&b, st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(X->h_tot[set].p, b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    TSTAMP(X, set, 2, st);
+    HIPCK(hipEventRecord(X->bplan[set], st));
+    c->b = b;
+    return 0;
+}
+
+static int chunk_launch(chunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set, n = c->n;
+    hipStream_t st = X->bstream[set];
+    mz_dev_batch b = c->b;
+    const int64_t *totals = (const int64_t *)X->h_tot[set].p;
+    size_t res_bytes;
+    char *dres;
+
+    c->t_launch0 = mzi_now_s();
+    HIPCK(hipEventSynchronize(X->bplan[set]));
+    if (up_prio()) HIPCK(hipStreamWaitEvent(st, X->bplan[set], 0));     /* (this stream's kernels read what the upload stream produced) */
+    c->t_launch1 = mzi_now_s();
+
+    /* results: 64-byte header, a record per pair, the scripts at a quarter of the plan's script slices */
+    res_bytes = 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n) + (size_t)totals[1] / 4 + 64;
+    if (mzi_dev_reserve(&X->d_tb[set], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[set], (size_t)totals[1] + 256) ||
+        mzi_dev_reserve(&X->d_prep[set], 4 * (size_t)totals[4] + 256) || mzi_dev_reserve(&X->d_res[set], res_bytes) ||
+        mzi_host_reserve(&X->h_res[set], res_bytes))
+        return -1;
+    b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = NULL;     /* (no merged columns on the device) */
+    b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
+    b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
+    b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
+    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
+    b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
+
+    dres = (char *)X->d_res[set].p;
+    HIPCK(hipMemsetAsync(dres, 0, 64, st));
+    if (mzk_prep(&b, st) || mzk_dp(&b, st)) return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 3, st);
+    if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
+        return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 4, st);
+    HIPCK(hipMemcpyAsync(X->h_res[set].p, dres, res_bytes, hipMemcpyDeviceToHost, st));
+    TSTAMP(X, set, 5, st);
+    HIPCK(hipEventRecord(X->bdone[set], st));
+    c->b = b; c->res_bytes = (int64_t)res_bytes;
+    c->t_launch2 = mzi_now_s();
+    return 0;
+}
+
+typedef struct asm_ctx {
+    const mz_job *jobs;
+    mz_out *outs;
+    const mz_res_rec *rec;
+    const uint8_t *packed;
+    const size_t *where;
+    uint8_t *block;
+    int failed;
+} asm_ctx;
+
+static void assemble_range(void *ctx, int lo, int hi)
+{
+    asm_ctx *q = (asm_ctx *)ctx;
+    int p, failed = 0;
+    for (p = lo; p < hi; ++p) {
+        mz_out *o = &q->outs[p];
+        const mz_res_rec *r = &q->rec[p];
+        const mz_job *j = &q->jobs[p];
+        o->status = r->status; o->badrow = r->badrow; o->OM = 0; o->cols = NULL; o->block = NULL;
+        o->score[0] = o->score[1] = o->score[2] = 0;
+        if (r->status == MZ_E_EMIT) { o->OM = r->om; o->score[0] = r->f[0]; o->score[1] = r->f[1]; }   /* i, j of the reference's message */
+        if (r->status != MZ_OK) { failed++; continue; }
+        o->OM = r->om;
+        o->score[0] = r->f[0]; o->score[1] = r->f[1]; o->score[2] = r->f[2];
+        o->cols = q->block + q->where[p];
+        mz_assemble_cols(j->K, j->L, j->M, j->N, j->A, j->B, q->packed + r->off, r->om, o->cols);
+    }
+    if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
+    _mm_sfence();
+}
+
+static int chunk_collect(chunk *c)
+{
+    mz_ctx *X = c->X;
+    const int n = c->n, set = c->set;
+    const mz_job *jobs = c->jobs;
+    mz_out *outs = c->outs;
+    const char *r = (const char *)X->h_res[set].p;
+    const mz_res_rec *rec = (const mz_res_rec *)(r + 64);
+    const uint8_t *packed = (const uint8_t *)r + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n);
+    size_t *where, total = 0;
+    uint8_t *block = NULL;
+    int p, failed = 0;
+
+    c->t_col0 = mzi_now_s();
+    HIPCK(hipEventSynchronize(X->bdone[set]));
+    c->t_col1 = mzi_now_s();
+    c->cells = *(const int64_t *)r;
+    where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
+    if (!where) return mzi_set_err("out of memory");
+    /* ONE allocation for the chunk's merged columns; outs[first].block owns it (mz_free_outs).  Every pair's columns
+     * start on a 64-byte line of their own (no line shared between two host threads; whole-line streaming stores) --
+     * except the first pair's, which start the block: for a call of one pair cols IS the block, as yama() hands it on. */
+    for (p = 0; p < n; ++p)
+        if (rec[p].status == MZ_OK) total += (((size_t)rec[p].om * (size_t)(jobs[p].K + jobs[p].L)) + 63) & ~(size_t)63;
+    if (total) {
+        size_t at = 0, mis;
+        block = (uint8_t *)mzi_block_get(total + 128);
+        if (!block) { free(where); return mzi_set_err("out of memory for the output columns (%zu bytes)", total); }
+        mis = (size_t)((uintptr_t)block & 63);
+        for (p = 0; p < n; ++p) {
+            where[p] = at;
+            if (rec[p].status != MZ_OK) continue;
+            at += (size_t)rec[p].om * (size_t)(jobs[p].K + jobs[p].L);
+            at = ((at + mis + 63) & ~(size_t)63) - mis;      /* the next pair's first byte at a multiple of 64 */
+        }
+    }
+    {
+        asm_ctx ac;
+        ac.jobs = jobs; ac.outs = outs; ac.rec = rec; ac.packed = packed; ac.where = where; ac.block = block; ac.failed = 0;
+        mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
+        failed = ac.failed;
+    }
+    outs[0].block = block;
+    free(where);
+    c->t_col2 = mzi_now_s();
+    return failed;
+}
+
+/* ------------------------------------------------------------------------------------------------ the pipeline */
+
+typedef struct mz_pipe {
+    mz_ctx *X;
+    int n, max_pairs;
+    const mz_job *jobs;
+    mz_out *outs;
+    chunk ck[MZ_SETS];
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int uploaded, launched, collected;     /* chunks through each stage */
+    int total;                             /* chunks in all; -1 until the packer has cut the last one */
+    int failed, rc, done;
+    int64_t cells, bytes_up, bytes_down;   /* of the chunks collected so far */
+    double t0;
+    hipEvent_t ev0;                        /* MZ_TIMING=2: recorded on the first set's stream when the call starts */
+    char err[600];
+} mz_pipe;
+
+typedef struct batch_stats { int64_t cells, bytes_up, bytes_down; } batch_stats;
+
+static void pipe_abort(mz_pipe *P)
+{
+    pthread_mutex_lock(&P->mu);
+    if (P->rc >= 0) { P->rc = -1; snprintf(P->err, sizeof P->err, "%s", mz_last_error()); }
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+
+static void pipe_count(mz_pipe *P, const chunk *c)
+{
+    P->cells += c->cells; P->bytes_up += c->in_bytes + c->exc_bytes; P->bytes_down += c->res_bytes;
+}
+
+static void chunk_report(const mz_pipe *P, const chunk *c)
+{
+    float g[5] = { 0, 0, 0, 0, 0 }, since0 = 0;
+    int k;
+    if (g_timing < 2) return;
+    if (c->X->btime_ready) {
+        /* GPU time stamps of this chunk's stream: H2D + expansion, plan, (wait for the host) prep + DP, walk + script packing, D2H;
+         * `gpu_start_ms` is the chunk's first stamp against chunk 0's of set 0 (the same clock only roughly: sets differ) */
+        for (k = 0; k < 5; ++k) hipEventElapsedTime(&g[k], c->X->btime[c->set][k], c->X->btime[c->set][k + 1]);
+        hipEventElapsedTime(&since0, P->ev0, c->X->btime[c->set][0]);
+    }
+    fprintf(stderr, "{\"mz_yama_batch_chunk\": %d, \"pairs\": %d, \"cells\": %lld, \"bytes_up\": %lld, \"bytes_down\": %lld, "
+                    "\"pack_ms\": [%.3f, %.3f], \"plan_wait_ms\": [%.3f, %.3f], \"launched_ms\": %.3f, \"result_wait_ms\": [%.3f, %.3f], \"assembled_ms\": %.3f, "
+                    "\"gpu_start_ms\": %.3f, \"gpu_ms\": {\"h2d_expand\": %.3f, \"plan\": %.3f, \"host_gap_dp\": %.3f, \"walk_pack\": %.3f, \"d2h\": %.3f}}\n",
+            c->index, c->n, (long long)c->cells, (long long)(c->in_bytes + c->exc_bytes), (long long)c->res_bytes,
+            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_launch0 - P->t0), 1e3 * (c->t_launch1 - P->t0),
+            1e3 * (c->t_launch2 - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0),
+            since0, g[0], g[1], g[2], g[3], g[4]);
+}
+
+/* stage 2: for chunk k = 0, 1, ...: wait until it is uploaded, wait for its plan, issue its kernels */
+static void launcher_main(mz_pipe *P)
+{
+    int k;
+    hipSetDevice(P->X->device);
+    for (k = 0;; ++k) {
+        pthread_mutex_lock(&P->mu);
+        while (P->rc >= 0 && P->uploaded <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
+        pthread_mutex_unlock(&P->mu);
+        if (chunk_launch(&P->ck[k % MZ_SETS]) < 0) { pipe_abort(P); break; }
+        pthread_mutex_lock(&P->mu);
+        P->launched = k + 1;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+/* stage 3: wait for the results of chunk k, assemble its merged columns, free its buffer set */
+static void collector_main(mz_pipe *P)
+{
+    int k;
+    hipSetDevice(P->X->device);
+    for (k = 0;; ++k) {
+        int rc;
+        pthread_mutex_lock(&P->mu);
+        while (P->rc >= 0 && P->launched <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
+        pthread_mutex_unlock(&P->mu);
+        rc = chunk_collect(&P->ck[k % MZ_SETS]);
+        if (rc < 0) { pipe_abort(P); break; }
+        chunk_report(P, &P->ck[k % MZ_SETS]);
+        pthread_mutex_lock(&P->mu);
+        P->failed += rc;
+        pipe_count(P, &P->ck[k % MZ_SETS]);
+        P->collected = k + 1;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+}
+
+/* persistent helper threads: their OpenMP teams are built once, not once per call */
+static void *worker_main(void *arg)
+{
+    mz_worker *w = (mz_worker *)arg;
+    for (;;) {
+        mz_pipe *P;
+        pthread_mutex_lock(&w->mu);
+        while (!w->quit && !w->job) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->quit) { pthread_mutex_unlock(&w->mu); break; }
+        P = w->job;
+        pthread_mutex_unlock(&w->mu);
+        w->fn(P);
+        pthread_mutex_lock(&w->mu);
+        w->job = NULL;                                   /* free for the next call BEFORE this one is told: it may return at once */
+        pthread_mutex_unlock(&w->mu);
+        pthread_mutex_lock(&P->mu);
+        P->done++;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+    return NULL;
+}
+
+static int workers_start(mz_ctx *X)
+{
+    int i;
+    for (i = 0; i < 2; ++i) {
+        mz_worker *w = &X->worker[i];
+        if (w->started) continue;
+        pthread_mutex_init(&w->mu, NULL);
+        pthread_cond_init(&w->cv, NULL);
+        w->quit = 0; w->job = NULL;
+        if (pthread_create(&w->th, NULL, worker_main, w) != 0) { pthread_mutex_destroy(&w->mu); pthread_cond_destroy(&w->cv); return -1; }
+        w->started = 1;
+    }
+    return 0;
+}
+
+static void worker_give(mz_worker *w, void (*fn)(mz_pipe *), mz_pipe *P)
+{
+    pthread_mutex_lock(&w->mu);
+    w->fn = fn; w->job = P;
+    pthread_cond_signal(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+}
+
+void mzi_workers_stop(mz_ctx *X)
+{
+    int i;
+    for (i = 0; i < 2; ++i) {
+        mz_worker *w = &X->worker[i];
+        if (!w->started) continue;
+        pthread_mutex_lock(&w->mu);
+        w->quit = 1;
+        pthread_cond_signal(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pthread_join(w->th, NULL);
+        pthread_mutex_destroy(&w->mu);
+        pthread_cond_destroy(&w->cv);
+        w->started = 0;
+    }
+}
+
+/* what a pair weighs in the cutting of chunks: its input bytes as the caller holds them */
+static size_t job_bytes(const mz_job *j)
+{
+    return job_ok(j) ? (size_t)j->K * j->M + (size_t)j->L * j->N + 8 * ((size_t)j->M + 1) : 0;
+}
+
+/* the next chunk: at most `limit` pairs and `max_bytes` of input */
+static int next_chunk(const mz_job *jobs, int n, int first, int limit, size_t max_bytes)
+{
+    size_t bytes = 0;
+    int m = 0;
+    while (first + m < n && m < limit && bytes < max_bytes) { bytes += job_bytes(&jobs[first + m]); ++m; }
+    return m;
+}
+
+/* A batch of any size on ONE context.  A guide-tree level with a million merges (BASELINE config 4) needs a bounded
+ * amount of pinned host memory and HBM: MZ_SETS chunks at most are in flight.  On a device error everything in flight
+ * is drained and every pair not yet collected is left marked MZ_E_DEVICE with cols == NULL (mz_yama_batch() pre-marks
+ * all of them), so a caller may clean up outs. */
+static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int max_pairs, batch_stats *stats)
+{
+    mz_pipe *P;
+    size_t max_bytes = 0;
+    int k = 0, up = 0, rc = 0, s, threaded;
+
+    if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
+    P = (mz_pipe *)calloc(1, sizeof *P);
+    if (!P) return mzi_set_err("out of memory");
+    P->X = X; P->n = n; P->jobs = jobs; P->outs = outs; P->max_pairs = max_pairs; P->total = -1; P->t0 = mzi_now_s();
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+
+    if (g_timing >= 2) {
+        if (!X->btime_ready) {
+            int a, e, ok = 1;
+            for (a = 0; a < MZ_SETS && ok; ++a) for (e = 0; e < 6 && ok; ++e) ok = hipEventCreate(&X->btime[a][e]) == hipSuccess;
+            X->btime_ready = ok;
+        }
+        if (X->btime_ready && hipEventCreate(&P->ev0) == hipSuccess) hipEventRecord(P->ev0, X->stream);
+        else X->btime_ready = 0;
+    }
+    /* chunks by pairs AND by bytes: a call of few long pairs (BASELINE config 5: 1 000 pairs, 1.2 GB) is cut into as many
+     * pieces as one of many short ones, at least 8 MB each and at most 1 GB */
+    for (s = 0; s < n; ++s) max_bytes += job_bytes(&jobs[s]);
+    max_bytes = max_bytes / (size_t)chunk_parts() + 1;
+    if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
+    if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
+    /* one chunk: the three steps inline (no thread is woken for a single yama() call); also when no thread can be had */
+    threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n && workers_start(X) == 0;
+    if (!threaded) {
+        while (up < n) {
+            chunk *c = &P->ck[0];
+            const int m = next_chunk(jobs, n, up, max_pairs, max_bytes);
+            int f;
+            if (chunk_upload(X, c, k, 0, m, jobs + up, outs + up) < 0 || chunk_launch(c) < 0 || (f = chunk_collect(c)) < 0) { rc = -1; break; }
+            chunk_report(P, c);
+            pipe_count(P, c);
+            P->failed += f; up += m; ++k;
+        }
+        if (rc >= 0) rc = P->failed;
+    } else {
+        worker_give(&X->worker[0], launcher_main, P);
+        worker_give(&X->worker[1], collector_main, P);
+        /* stage 1 here: cut, pack, upload, plan.  The first chunk is a half-size one: the GPU starts that much earlier. */
+        while (up < n) {
+            const int first_half = k == 0 && (max_pairs >= 2048 || max_bytes >= ((size_t)32 << 20));
+            const int limit = first_half ? (max_pairs + 1) / 2 : max_pairs;
+            int m, bad;
+            pthread_mutex_lock(&P->mu);
+            while (P->rc >= 0 && k - P->collected >= MZ_SETS) pthread_cond_wait(&P->cv, &P->mu);    /* its buffer set is still in use */
+            bad = P->rc < 0;
+            pthread_mutex_unlock(&P->mu);
+            if (bad) break;
+            m = next_chunk(jobs, n, up, limit, first_half ? max_bytes / 2 : max_bytes);
+            if (chunk_upload(X, &P->ck[k % MZ_SETS], k, k % MZ_SETS, m, jobs + up, outs + up) < 0) { pipe_abort(P); break; }
+            up += m; ++k;
+            pthread_mutex_lock(&P->mu);
+            P->uploaded = k;
+            pthread_cond_broadcast(&P->cv);
+            pthread_mutex_unlock(&P->mu);
+        }
+        pthread_mutex_lock(&P->mu);
+        P->total = k;
+        pthread_cond_broadcast(&P->cv);
+        while (P->done < 2) pthread_cond_wait(&P->cv, &P->mu);
+        rc = P->rc < 0 ? -1 : P->failed;
+        pthread_mutex_unlock(&P->mu);
+        if (rc < 0) mzi_set_err("%s", P->err);
+    }
+    if (rc < 0) for (s = 0; s < MZ_SETS; ++s) { if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]); if (X->ustream[s]) hipStreamSynchronize(X->ustream[s]); }
+    if (g_timing >= 2 && X->btime_ready) hipEventDestroy(P->ev0);
+    if (stats) { stats->cells = P->cells; stats->bytes_up = P->bytes_up; stats->bytes_down = P->bytes_down; }
+    pthread_mutex_destroy(&P->mu);
+    pthread_cond_destroy(&P->cv);
+    free(P);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ several GPUs */
+
+/* host thread of one further GPU (mz_yama_batch with several contexts) */
+typedef struct dev_task { mz_ctx *X; int n, max_pairs, rc; const mz_job *jobs; mz_out *outs; batch_stats st; char err[600]; } dev_task;
+static void *dev_worker(void *arg)
+{
+    dev_task *t = (dev_task *)arg;
+    t->rc = batch_on_ctx(t->X, t->n, t->jobs, t->outs, t->max_pairs, &t->st);
+    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, mz_last_error());
+    return NULL;
+}
+
+/* what a pair costs the GPU, roughly: band rows x the band's width in the middle (no pass over the bounds) */
+static double job_weight(const mz_job *j)
+{
+    if (j->K < 1 || j->L < 1 || j->M < 1 || j->N < 1 || !j->LB || !j->RB) return 1.0;
+    return ((double)j->M + 1.0) * (double)(j->RB[j->M / 2] - j->LB[j->M / 2] + 1) + 64.0 * (j->K + j->L);
+}
+
+/* bytes the last mz_yama_batch() call moved over the link, each way */
+static int64_t g_last_up, g_last_down;
+
+int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
+{
+    static int env_pairs = -1;
+    int failed = 0, max_pairs, use, p, rc;
+    batch_stats st = { 0, 0, 0 };
+    double t_call = mzi_now_s();
+    if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (g_timing < 0) { const char *e = getenv("MZ_TIMING"); g_timing = e ? (atoi(e) > 0 ? atoi(e) : 1) : 0; }
+    if (n <= 0) return 0;
+    for (p = 0; outs && p < n; ++p) {                    /* "not computed" until a chunk says otherwise */
+        outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL;
+        outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
+    }
+    pthread_mutex_lock(&g_big);
+    {
+        const int first = !g_ndev && g_timing;
+        double t0 = mzi_now_s(), t1;
+        if (mzi_ensure_init()) { pthread_mutex_unlock(&g_big); return -1; }
+        t1 = mzi_now_s();
+        if (mzi_sync_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+        if (!jobs || !outs) { pthread_mutex_unlock(&g_big); return mzi_set_err("mz_yama_batch: NULL jobs or outs"); }
+        if (first) fprintf(stderr, "{\"mz_start_up\": {\"hip_runtime_and_streams_ms\": %.1f, \"gpus\": %d, \"score_upload_and_code_object_ms\": %.1f}}\n",
+                           1e3 * (t1 - t0), g_ndev, 1e3 * (mzi_now_s() - t1));
+    }
+    /* GPUs to use: all of them once every one gets a worthwhile share */
+    use = g_ndev;
+    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
+    {
+        /* chunk size: a twelfth of a GPU's share (MZ_CHUNKS overrides the divisor; 4 / 6 / 8 / 12 / 16 pieces measured on the
+         * 50 000-pair C2 call: 11.2 / 12.0 / 11.3 / 10.0 / 10.9 ms), so that the copies, the kernels and the host's packing
+         * and assembling of different chunks overlap and the first kernels start early -- but at least 1 Ki pairs (a wave
+         * per SIMD; chunks in flight share the GPU) and at most 16 Ki */
+        const int share = (n + use - 1) / use, parts = chunk_parts(), per = (share + parts - 1) / parts;
+        max_pairs = env_pairs ? env_pairs : per < 1024 ? 1024 : per > 16384 ? 16384 : per;
+    }
+    if (use == 1) {
+        G.copy_threads = MZ_COPY_THREADS;
+        rc = batch_on_ctx(&G, n, jobs, outs, max_pairs, &st);
+    } else {
+        /* Contiguous ranges of about equal weight, one per GPU, each driven by its own host thread through its own
+         * context (streams, staging buffers, helper threads); results land in outs[] at the jobs' own positions, so there
+         * is nothing to gather.  No data-path collective: the work list lives in host memory and every GPU pulls its
+         * share over its own PCIe link. */
+        dev_task task[MZ_MAX_DEV];
+        pthread_t th[MZ_MAX_DEV];
+        double total = 0.0, acc = 0.0;
+        int d = 0, start = 0, started[MZ_MAX_DEV];
+        for (p = 0; p < n; ++p) total += job_weight(&jobs[p]);
+        for (p = 0; p < n && d < use; ++p) {
+            acc += job_weight(&jobs[p]);
+            if (d == use - 1) { p = n - 1; acc = total; }
+            if (acc >= total * (d + 1) / use || p == n - 1) {
+                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
+                task[d].n = p + 1 - start; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0; memset(&task[d].st, 0, sizeof task[d].st);
+                g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
+                start = p + 1;
+                ++d;
+            }
+        }
+        use = d;
+        for (d = 1; d < use; ++d) {
+            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, dev_worker, &task[d]) == 0;
+            if (!started[d] && task[d].n > 0) dev_worker(&task[d]);         /* no thread: do it here, after the others started */
+        }
+        if (task[0].n > 0) dev_worker(&task[0]);
+        rc = 0;
+        for (d = 0; d < use; ++d) {
+            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
+            if (task[d].n <= 0) continue;
+            if (task[d].rc < 0) { rc = -1; mzi_set_err("%s", task[d].err); }
+            else failed += task[d].rc;
+            st.cells += task[d].st.cells; st.bytes_up += task[d].st.bytes_up; st.bytes_down += task[d].st.bytes_down;
+            g_dev[d].copy_threads = MZ_COPY_THREADS;
+        }
+        hipSetDevice(G.device);
+        if (rc >= 0) rc = failed;
+    }
+    g_last_up = st.bytes_up; g_last_down = st.bytes_down;
+    pthread_mutex_unlock(&g_big);
+    if (g_timing && rc >= 0) {
+        /* one JSON line per call: pairs, band cells, seconds, GCUPS, bytes over the link each way */
+        const double dt = mzi_now_s() - t_call;
+        fprintf(stderr, "{\"mz_yama_batch\": {\"pairs\": %d, \"failed\": %d, \"cells\": %lld, \"seconds\": %.6f, \"gcups\": %.2f, \"bytes_up\": %lld, \"bytes_down\": %lld, "
+                        "\"gpus\": %d, \"chunk_pairs\": %d}}\n", n, rc, (long long)st.cells, dt, (double)st.cells / dt / 1e9, (long long)st.bytes_up, (long long)st.bytes_down, use, max_pairs);
+    }
+    return rc;
+}
+
+void mz_link_bytes(int64_t *up, int64_t *down) { if (up) *up = g_last_up; if (down) *down = g_last_down; }
+
+/* release the merged columns of a finished mz_yama_batch() call: the blocks the chunks allocated (outs[i].block).
+ * Large blocks are parked for the next calls instead of going back to the system (mz_pool.c). */
+void mz_free_outs(int n, mz_out *outs)
+{
+    int p;
+    for (p = 0; p < n; ++p) { mzi_block_put(outs[p].block); outs[p].block = NULL; outs[p].cols = NULL; }
+}

@@ -9,8 +9,14 @@ extern "C" {
 int mzk_upload_scores(const mz_score_model *m, void *stream);
 int mzk_plan(const mz_dev_batch *b, void *stream);
 /* expand the host path's delta-coded band bounds into the int32 pools (see k_unband) */
-int mzk_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
-               const uint8_t *packed, int32_t *poolLB, int32_t *poolRB, void *stream);
+int mzk_unband(int n, const int32_t *bandLen, const int32_t *lb0, const int32_t *rb0, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
+               const uint8_t *packed, const uint8_t *exceptions, int32_t *poolLB, int32_t *poolRB, void *stream);
+/* class nibbles (mz_pack.c) -> one canonical byte per class; nbytes_out a multiple of 8 */
+int mzk_unnib(const void *nibbles, void *bytes, long long nbytes_out, void *stream);
+/* what mz_yama_batch() copies back: hdr (64 B: [0] = band cells of the valid pairs, zeroed by the caller), one record
+ * per pair, the edit scripts at two bits per merged column (pair p at byte recs[p].off of `packed`) */
+typedef struct mz_res_rec { int32_t status, badrow, om, f[3]; int64_t off; } mz_res_rec;
+int mzk_script_pack(const mz_dev_batch *b, void *hdr, void *recs, void *packed, void *stream);
 int mzk_prep(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
 int mzk_walk(const mz_dev_batch *b, void *stream, int beside_dp);   /* beside_dp: another batch's DP runs at the same time */

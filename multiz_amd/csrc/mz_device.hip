@@ -238,31 +238,41 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
 }
 
 // ------------------------------------------------------------------------------------------
-// Band bounds as the host path ships them (mz_yama_batch): LB and RB are monotone and move by a column or two per
-// row, so instead of 8 bytes per row (two thirds of a C2 pair's input) the staging block carries, per pair,
+// What the host path (mz_yama_batch, mz_host.c / mz_pack.c) sends instead of the pools themselves.
+//
+// Band bounds: LB and RB are monotone and move by a column or two per row, so instead of 8 bytes per row (two thirds
+// of a C2 pair's input) the staging block carries, per pair,
+//   format 2:  M bytes  (LB[i]-LB[i-1]) | (RB[i]-RB[i-1]) << 4; LB[0], RB[0] in the header     (all steps 0..15)
 //   format 1:  LB[0], RB[0] (int32), then M bytes LB[i]-LB[i-1], then M bytes RB[i]-RB[i-1]   (all steps 0..255)
 //   format 0:  LB[0..M], RB[0..M] as int32                                                    (anything else)
-// at byte offset offC[p] (4-byte aligned).  One wave per pair turns that back into the int32 pools every kernel reads.
+// at byte offset offC[p] (4-byte aligned) -- format 2 in the staging block itself (every pair has its slot there), the
+// other two in the exception block.  One wave per pair turns that back into the int32 pools every kernel reads.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC,
-                                                 const uint8_t *fmt, const uint8_t *packed, int32_t *poolLB, int32_t *poolRB)
+__global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, const int32_t *lb0, const int32_t *rb0, const int64_t *offBand, const int64_t *offC,
+                                                 const uint8_t *fmt, const uint8_t *packed, const uint8_t *exceptions,
+                                                 int32_t *poolLB, int32_t *poolRB)
 {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
     const int M = bandLen[p] - 1;                       // entries 0..M (an invalid job carries one dummy entry)
     int32_t *LB = poolLB + offBand[p], *RB = poolRB + offBand[p];
-    const uint8_t *src = packed + offC[p];
-    if (fmt[p] == 0) {
+    const int f = fmt[p];
+    const uint8_t *src = (f == 2 ? packed : exceptions) + offC[p];
+    if (f == 0) {
         const int32_t *s = (const int32_t *)src;
         for (int i = lane; i <= M; i += WAVE) { LB[i] = s[i]; RB[i] = s[M + 1 + i]; }
         return;
     }
-    int baseL = ((const int32_t *)src)[0], baseR = ((const int32_t *)src)[1];
-    const uint8_t *dL = src + 8, *dR = src + 8 + M;
+    int baseL = f == 2 ? lb0[p] : ((const int32_t *)src)[0], baseR = f == 2 ? rb0[p] : ((const int32_t *)src)[1];
+    const uint8_t *dL = f == 2 ? src : src + 8, *dR = src + 8 + M;
     if (lane == 0) { LB[0] = baseL; RB[0] = baseR; }
     for (int i0 = 1; i0 <= M; i0 += WAVE) {
         const int i = i0 + lane;
-        int x = i <= M ? dL[i - 1] : 0, y = i <= M ? dR[i - 1] : 0;
+        int x = 0, y = 0;
+        if (i <= M) {
+            if (f == 2) { const int v = dL[i - 1]; x = v & 15; y = v >> 4; }
+            else { x = dL[i - 1]; y = dR[i - 1]; }
+        }
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
             const int a = __shfl_up(x, o), c = __shfl_up(y, o);
@@ -274,12 +284,40 @@ __global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, 
     }
 }
 
-extern "C" int mzk_unband(int n, const int32_t *bandLen, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
-                          const uint8_t *packed, int32_t *poolLB, int32_t *poolRB, void *stream)
+// Columns: class nibbles (mz_pack.c) back to one canonical byte per class -- A, C, G, T, '-', N: the six classes the
+// score tables distinguish (mz_scores.c:39-54), so the DP sees what it would see on the caller's own bytes; the merged
+// columns are assembled on the host from the caller's bytes and the edit script.  A thread per dword: 8 nibbles in,
+// 8 bytes out; pair boundaries do not matter (every pair's slice is a whole number of 32-byte lines).
+__global__ __launch_bounds__(256) void k_unnib(const uint32_t *src, uint2 *dst, long long ndw)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ndw) return;
+    const unsigned long long tab = 0x00004e2d54474341ULL;           // "ACGT-N", a byte per class
+    const uint32_t w = src[i];
+    uint2 o;
+    o.x = (uint32_t)((tab >> (8 * (w & 15))) & 0xff) | (uint32_t)((tab >> (8 * ((w >> 4) & 15))) & 0xff) << 8 |
+          (uint32_t)((tab >> (8 * ((w >> 8) & 15))) & 0xff) << 16 | (uint32_t)((tab >> (8 * ((w >> 12) & 15))) & 0xff) << 24;
+    o.y = (uint32_t)((tab >> (8 * ((w >> 16) & 15))) & 0xff) | (uint32_t)((tab >> (8 * ((w >> 20) & 15))) & 0xff) << 8 |
+          (uint32_t)((tab >> (8 * ((w >> 24) & 15))) & 0xff) << 16 | (uint32_t)((tab >> (8 * (w >> 28))) & 0xff) << 24;
+    dst[i] = o;
+}
+
+extern "C" int mzk_unband(int n, const int32_t *bandLen, const int32_t *lb0, const int32_t *rb0, const int64_t *offBand, const int64_t *offC, const uint8_t *fmt,
+                          const uint8_t *packed, const uint8_t *exceptions, int32_t *poolLB, int32_t *poolRB, void *stream)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_unband, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, bandLen, offBand, offC, fmt, packed, poolLB, poolRB);
+    hipLaunchKernelGGL(k_unband, dim3(n), dim3(WAVE), 0, (hipStream_t)stream, n, bandLen, lb0, rb0, offBand, offC, fmt, packed, exceptions, poolLB, poolRB);
     CK(hipGetLastError(), "unband launch");
+    return 0;
+}
+
+extern "C" int mzk_unnib(const void *nibbles, void *bytes, long long nbytes_out, void *stream)
+{
+    const long long ndw = nbytes_out / 8;               // (the caller pads every slice to 8 bytes)
+    if (ndw <= 0) return 0;
+    hipLaunchKernelGGL(k_unnib, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t *)nibbles, (uint2 *)bytes, ndw);
+    CK(hipGetLastError(), "unnib launch");
     return 0;
 }
 
@@ -492,6 +530,16 @@ extern "C" int mzk_emit_packed(const mz_dev_batch *b, void *stream)
     hipLaunchKernelGGL(k_emit, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
     hipLaunchKernelGGL(k_emit_wide, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
     CK(hipGetLastError(), "packed emit launch");
+    return 0;
+}
+// The host path's result: per pair a 32-byte record and the edit script at two bits per merged column, in column order
+// (the walk leaves a byte per column, last column first).  Also the reference's closing check of the emit
+// (mz_yama.c:310-312): the script must take exactly M columns of A and N of B.  hdr[0] += band cells of the pair.
+extern "C" int mzk_script_pack(const mz_dev_batch *b, void *hdr, void *recs, void *packed, void *stream)
+{
+    if (b->n <= 0) return 0;
+    hipLaunchKernelGGL(k_script_pack, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b, (long long *)hdr, (mz_res_rec *)recs, (uint8_t *)packed);
+    CK(hipGetLastError(), "script pack launch");
     return 0;
 }
 extern "C" int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream)

@@ -35,6 +35,16 @@ struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct m
 int mz_multic_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int minw, int cate,
                     FILE *out, FILE *out1, FILE *out2);
 void *mz_xmalloc(size_t n);
+/* append a result block of mz_yama_batch() (mz_out.block) to a list that is freed after the last wave of yama() calls */
+static inline void **mz_hold(void **list, int *n, void *block)
+{
+    if ((*n & (*n + 1)) == 0) {                          /* 0, 1, 3, 7, ...: room for twice as many and one */
+        list = (void **)realloc(list, (size_t)(2 * *n + 2) * sizeof *list);
+        if (!list) mz_fatalf("Ran out of memory trying to allocate %lu.", (unsigned long)((2 * *n + 2) * sizeof *list));
+    }
+    list[(*n)++] = block;
+    return list;
+}
 char *mz_xstrdup(const char *s);
 struct mafAli *mz_pop_first(struct mafAli **head);
 void mz_take_chr(struct mafAli **from, struct mafAli **to, const char *chr);   /* blocks on contig chr, order kept */

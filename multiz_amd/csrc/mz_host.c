@@ -6,8 +6,6 @@
  * no HIP device is usable every entry point fails (yama(): prints and exit(1)s, like any other
  * fatal condition of the reference, util.c:21-30).
  */
-#define __HIP_PLATFORM_AMD__ 1
-#include <hip/hip_runtime_api.h>
 #include <limits.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -17,7 +15,7 @@
 #include <string.h>
 #include <time.h>
 
-#include "mz_device.h"
+#include "mz_ctx.h"
 #include "../../include/mz_scores.h"
 #include "../../include/mz_yama.h"
 
@@ -28,7 +26,7 @@ char *argv0;                               /* reference util.c:4; drivers set it
 
 const char *mz_last_error(void) { return g_err; }
 
-static int set_err(const char *fmt, ...)
+int mzi_set_err(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -37,8 +35,6 @@ static int set_err(const char *fmt, ...)
     return -1;
 }
 
-#define HIPCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
-    return set_err("%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
 /* same shape as the reference's fatalf(): "<argv0 basename>: message\n", exit(1) */
 int mz_scores_explicit;                  /* set by mz_set_scores(), cleared by init_scores70/85() */
@@ -58,49 +54,15 @@ __attribute__((noreturn)) void mz_fatalf(const char *fmt, ...)
     exit(1);
 }
 
-/* ------------------------------------------------------------------ context */
+/* ------------------------------------------------------------------ context (struct and helpers: mz_ctx.h) */
 
-typedef struct gbuf { void *p; size_t cap; } gbuf;
-
-#define MZ_SLICES 4                        /* (number of helper events) */
-
-#define MZ_SETS 4                          /* buffer sets of the chunk pipeline: uploading, computing, copying back, being unpacked */
-
-#define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
-
-/* Everything the library holds on ONE GPU.  g_dev[0] is the primary context: the device-resident API (mz_dev_*)
- * and single-GPU runs live there.  mz_init_multi() / MZ_NGPU add contexts on further GPUs, each driven by its own
- * host thread when mz_yama_batch() deals a large batch out over them (block pairs are
- * independent, so the shards never talk to each other). */
-typedef struct mz_ctx {
-    int ready;
-    int device;
-    hipStream_t stream;
-    hipStream_t stream2;                   /* pipelined form: traceback walk + emit of batch k beside the DP of batch k+1 */
-    hipStream_t stream3;                   /* pipelined form: plan of batch k+1 beside the DP of batch k */
-    hipStream_t stream_dp[4];              /* pipelined form, small batches: the DPs of consecutive batches side by side */
-    unsigned dp_turn;
-    hipEvent_t ev[5];
-    hipEvent_t evs[MZ_SLICES + 1];
-    int scores_ok;                         /* the device's copy of the score model is current */
-    /* grow-only buffers of the host-buffer path */
-    gbuf h_in[MZ_SETS], d_in[MZ_SETS], d_plan[MZ_SETS], d_tb[MZ_SETS], d_script[MZ_SETS], d_out[MZ_SETS], d_prep[MZ_SETS], h_res[MZ_SETS], h_tot[MZ_SETS], d_band[MZ_SETS];
-    gbuf d_pre[6], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
-    hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
-    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bsmall[MZ_SETS];
-    struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
-    int ws_victim;
-} mz_ctx;
-
-#define MZ_MAX_DEV 16
-static mz_ctx g_dev[MZ_MAX_DEV];
-static int g_ndev;                         /* contexts in use (0 before mz_init) */
-#define G (g_dev[0])
+mz_ctx g_dev[MZ_MAX_DEV];
+int g_ndev;                                /* contexts in use (0 before mz_init) */
 static unsigned long long g_score_sum;     /* checksum of the score tables last handed to the devices */
 static int g_score_have;
-static pthread_mutex_t g_big = PTHREAD_MUTEX_INITIALIZER;   /* one host-path call at a time (the library state is process-wide) */
+pthread_mutex_t g_big = PTHREAD_MUTEX_INITIALIZER;   /* one host-path call at a time (the library state is process-wide) */
 
-static int dev_reserve(gbuf *b, size_t need)
+int mzi_dev_reserve(gbuf *b, size_t need)
 {
     if (need <= b->cap) return 0;
     if (b->p) { HIPCK(hipFree(b->p)); b->p = NULL; b->cap = 0; }
@@ -109,7 +71,7 @@ static int dev_reserve(gbuf *b, size_t need)
     b->cap = need;
     return 0;
 }
-static int host_reserve(gbuf *b, size_t need)
+int mzi_host_reserve(gbuf *b, size_t need)
 {
     if (need <= b->cap) return 0;
     if (b->p) { HIPCK(hipHostFree(b->p)); b->p = NULL; b->cap = 0; }
@@ -133,11 +95,11 @@ static int ctx_open(mz_ctx *X, int device)
     for (i = 0; i < MZ_SETS; ++i) {
         HIPCK(hipEventCreateWithFlags(&X->bdone[i], hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&X->bplan[i], hipEventDisableTiming));
-        HIPCK(hipEventCreateWithFlags(&X->bsmall[i], hipEventDisableTiming));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&X->evs[i], hipEventDisableTiming));
     X->device = device;
+    X->copy_threads = MZ_COPY_THREADS;
     X->ready = 1;
     return 0;
 }
@@ -146,20 +108,22 @@ static void ctx_close(mz_ctx *X)
 {
     int i, s;
     if (!X->ready) return;
+    mzi_workers_stop(X);
     hipSetDevice(X->device);
     hipStreamSynchronize(X->stream);
     for (s = 0; s < MZ_SETS; ++s) {
-        gbuf *d[] = { &X->d_in[s], &X->d_plan[s], &X->d_tb[s], &X->d_script[s], &X->d_out[s], &X->d_prep[s], &X->d_band[s] };
+        gbuf *d[] = { &X->d_in[s], &X->d_exc[s], &X->d_cols[s], &X->d_band[s], &X->d_plan[s], &X->d_tb[s], &X->d_script[s], &X->d_prep[s], &X->d_res[s] };
+        gbuf *h[] = { &X->h_in[s], &X->h_exc[s], &X->h_tot[s], &X->h_res[s] };
         if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
-        for (i = 0; i < 7; ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
-        if (X->h_in[s].p)  { hipHostFree(X->h_in[s].p);  X->h_in[s].p = NULL;  X->h_in[s].cap = 0; }
-        if (X->h_res[s].p) { hipHostFree(X->h_res[s].p); X->h_res[s].p = NULL; X->h_res[s].cap = 0; }
-        if (X->h_tot[s].p) { hipHostFree(X->h_tot[s].p); X->h_tot[s].p = NULL; X->h_tot[s].cap = 0; }
+        for (i = 0; i < (int)(sizeof d / sizeof d[0]); ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
+        for (i = 0; i < (int)(sizeof h / sizeof h[0]); ++i) if (h[i]->p) { hipHostFree(h[i]->p); h[i]->p = NULL; h[i]->cap = 0; }
         if (s >= 1 && X->bstream[s]) hipStreamDestroy(X->bstream[s]);
+        if (X->ustream[s]) { hipStreamSynchronize(X->ustream[s]); hipStreamDestroy(X->ustream[s]); X->ustream[s] = NULL; }
+        if (X->btime_ready) for (i = 0; i < 6; ++i) hipEventDestroy(X->btime[s][i]);
         hipEventDestroy(X->bdone[s]);
         hipEventDestroy(X->bplan[s]);
-        hipEventDestroy(X->bsmall[s]);
     }
+    if (X->d_out0.p) { hipFree(X->d_out0.p); X->d_out0.p = NULL; X->d_out0.cap = 0; }
     for (i = 0; i < 6; ++i) if (X->d_pre[i].p) { hipFree(X->d_pre[i].p); X->d_pre[i].p = NULL; X->d_pre[i].cap = 0; }
     for (i = 0; i < 2; ++i) if (X->h_pre[i].p) { hipHostFree(X->h_pre[i].p); X->h_pre[i].p = NULL; X->h_pre[i].cap = 0; }
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
@@ -182,14 +146,14 @@ static int init_devices(int ngpu, const int *devices, int first)
      * Effective only if the runtime is not up yet; an application that starts it first sets the variable itself. */
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        return set_err("no HIP device available (this library has no CPU path)");
-    if (ngpu < 1 || ngpu > MZ_MAX_DEV) return set_err("mz_init_multi: %d GPUs requested (1..%d supported)", ngpu, MZ_MAX_DEV);
+        return mzi_set_err("no HIP device available (this library has no CPU path)");
+    if (ngpu < 1 || ngpu > MZ_MAX_DEV) return mzi_set_err("mz_init_multi: %d GPUs requested (1..%d supported)", ngpu, MZ_MAX_DEV);
     for (i = 0; i < ngpu; ++i) {
         const int d = devices ? devices[i] : first + i;
-        if (d < 0 || d >= count) return set_err("HIP device %d out of range (%d present)", d, count);
+        if (d < 0 || d >= count) return mzi_set_err("HIP device %d out of range (%d present)", d, count);
         for (j = 0; j < i; ++j)       /* (MZ_ALLOW_DUP_DEVICES=1: several contexts on one GPU, to exercise the dealing on a one-GPU box) */
             if ((devices ? devices[j] : first + j) == d && !(getenv("MZ_ALLOW_DUP_DEVICES") && atoi(getenv("MZ_ALLOW_DUP_DEVICES"))))
-                return set_err("mz_init_multi: device %d listed twice", d);
+                return mzi_set_err("mz_init_multi: device %d listed twice", d);
     }
     if (g_ndev) mz_finalize();
     for (i = 0; i < ngpu; ++i)
@@ -230,7 +194,7 @@ int mz_device_count(void) { return g_ndev; }
 
 /* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs 4 % of the
  * pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
-static int lazy_stream(hipStream_t *s)
+int mzi_lazy_stream(hipStream_t *s)
 {
     if (*s) return 0;
     HIPCK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, getenv("MZ_HELPER_PRIO") ? atoi(getenv("MZ_HELPER_PRIO")) : 0));
@@ -246,10 +210,12 @@ void mz_finalize(void)
     }
     g_ndev = 0;
     g_score_have = 0;
+    mzi_pool_stop();
+    mzi_blocks_drop();
 }
 
 /* first use without mz_init(): MZ_DEVICE = first GPU (default 0), MZ_NGPU = how many (default 1) */
-static int ensure_init(void)
+int mzi_ensure_init(void)
 {
     const char *n;
     int ngpu;
@@ -290,14 +256,14 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     for (a = 0; a < 128; ++a)
         for (b = 0; b < 128; ++b)
             if (SSAT(a, b) != m->S6[class_of(a) * 6 + class_of(b)])
-                return set_err("substitution table is not constant on the byte classes {A,C,G,T,-,other} at (%d,%d)", a, b);
+                return mzi_set_err("substitution table is not constant on the byte classes {A,C,G,T,-,other} at (%d,%d)", a, b);
 #undef SSAT
     m->gap_open = g16[1];
     for (x = 0; x < 16; ++x) {
         int s = (x >> 3) & 1, t = (x >> 2) & 1, u = (x >> 1) & 1, v = x & 1;
         int want = (u != v && !(s == u && t == v)) ? m->gap_open : 0;
         if (g16[x] != want)
-            return set_err("gap-open table entry %d is %d, expected %d (quasi-natural structure)", x, g16[x], want);
+            return mzi_set_err("gap-open table entry %d is %d, expected %d (quasi-natural structure)", x, g16[x], want);
     }
     m->gap_extend = ext;
     /* gap_open = g1*g2, both small enough that 127*g fits an int16 dot-product operand; the fast
@@ -312,15 +278,15 @@ static int model_from_tables(int **rows, const int *flat, const int *g16, int ex
     }
     for (a = 0; a < 36; ++a)
         if (m->S6[a] < -258 || m->S6[a] > 258)      /* 127 rows * |score| must fit the int16 dot-product operand */
-            return set_err("substitution score %d too large for the packed int16 row vector", m->S6[a]);
+            return mzi_set_err("substitution score %d too large for the packed int16 row vector", m->S6[a]);
     if (m->gap_open < 0 || m->gap_open >= (1 << 15) || ext < 0 || ext >= (1 << 15))
-        return set_err("gap penalties out of range (open %d, extend %d)", m->gap_open, ext);
+        return mzi_set_err("gap penalties out of range (open %d, extend %d)", m->gap_open, ext);
     return 0;
 }
 
 /* the model goes to every context's __constant__ copy.  Kernels of earlier calls may still be reading it
  * (mz_dev_run_async, another caller's stream), so each device is drained first; score changes are rare. */
-static int g_hint_gen;                     /* bumped with every upload: hints of a plan made under another model are void */
+int g_hint_gen;                     /* bumped with every upload: hints of a plan made under another model are void */
 int mz_hint_generation(void) { return g_hint_gen; }
 
 /* the batch as the launchers may see it: hints (include/mz_amd.h) only when they were derived under the selection and
@@ -340,7 +306,7 @@ static int upload_everywhere(const mz_score_model *m)
     for (i = 0; i < g_ndev; ++i) {
         HIPCK(hipSetDevice(g_dev[i].device));
         HIPCK(hipDeviceSynchronize());
-        if (mzk_upload_scores(m, g_dev[i].stream)) return set_err("%s", mzk_last_error());
+        if (mzk_upload_scores(m, g_dev[i].stream)) return mzi_set_err("%s", mzk_last_error());
         g_dev[i].scores_ok = 1;
     }
     HIPCK(hipSetDevice(G.device));
@@ -350,7 +316,7 @@ static int upload_everywhere(const mz_score_model *m)
 int mz_set_scores(const int *ss_flat, const int *gop16, int ext)
 {
     mz_score_model m;
-    if (ensure_init()) return -1;
+    if (mzi_ensure_init()) return -1;
     if (model_from_tables(NULL, ss_flat, gop16, ext, &m)) return -1;
     if (upload_everywhere(&m)) return -1;
     g_score_have = 0;
@@ -400,7 +366,7 @@ static unsigned long long score_checksum(void)
 }
 
 /* hand the reference-style globals (ss, gop, gap_extend) to the devices if they changed */
-static int sync_global_scores(void)
+int mzi_sync_scores(void)
 {
     mz_score_model m;
     unsigned long long sum;
@@ -419,16 +385,15 @@ static int sync_global_scores(void)
 
 /* ------------------------------------------------------------------ device-resident API */
 
-static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t mz_dev_plan_bytes(int n)
 {
     size_t s = 0, N = (size_t)(n > 0 ? n : 1);
-    s += 5 * al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
-    s += 9 * al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
-    s += al256(8 * 32);                    /* totals */
-    s += al256(4 * N) + al256(8 * 8 * (N / 64 + 2));    /* packList, scanAux */
-    s += al256(4 * N) + al256(12 * N);     /* om, final3 */
+    s += 5 * mzi_al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
+    s += 9 * mzi_al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
+    s += mzi_al256(8 * 32);                    /* totals */
+    s += mzi_al256(4 * N) + mzi_al256(8 * 8 * (N / 64 + 2));    /* packList, scanAux */
+    s += mzi_al256(4 * N) + mzi_al256(12 * N);     /* om, final3 */
     return s;
 }
 
@@ -436,7 +401,7 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
 {
     char *p = (char *)mem;
     size_t N = (size_t)(b->n > 0 ? b->n : 1);
-#define TAKE(field, type, bytes) do { b->field = (type)p; p += al256(bytes); } while (0)
+#define TAKE(field, type, bytes) do { b->field = (type)p; p += mzi_al256(bytes); } while (0)
     TAKE(status, int32_t *, 4 * N); TAKE(badrow, int32_t *, 4 * N); TAKE(mode, int32_t *, 4 * N);
     TAKE(edgeLo, int32_t *, 4 * N); TAKE(edgeHi, int32_t *, 4 * N);
     TAKE(cells, int64_t *, 8 * N);
@@ -452,28 +417,28 @@ static void *pick_stream(void *s) { return s ? s : (void *)G.stream; }
 
 int mz_dev_plan(const mz_dev_batch *b, void *stream)
 {
-    if (ensure_init() || sync_global_scores()) return -1;
+    if (mzi_ensure_init() || mzi_sync_scores()) return -1;
     /* prep == NULL: a sizing pass (validity, modes, sizes, offsets, totals) before the workspaces exist */
-    return (mzk_plan(b, pick_stream(stream)) || (b->prep && mzk_prep(b, pick_stream(stream)))) ? set_err("%s", mzk_last_error()) : 0;
+    return (mzk_plan(b, pick_stream(stream)) || (b->prep && mzk_prep(b, pick_stream(stream)))) ? mzi_set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_dp(const mz_dev_batch *b, void *stream)
 {
     mz_dev_batch tmp;
-    if (ensure_init() || sync_global_scores()) return -1;
+    if (mzi_ensure_init() || mzi_sync_scores()) return -1;
     b = checked_hints(b, &tmp);
-    return mzk_dp(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+    return mzk_dp(b, pick_stream(stream)) ? mzi_set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_walk(const mz_dev_batch *b, void *stream)
 {
     mz_dev_batch tmp;
-    if (ensure_init()) return -1;
+    if (mzi_ensure_init()) return -1;
     b = checked_hints(b, &tmp);
-    return mzk_walk(b, pick_stream(stream), 0) ? set_err("%s", mzk_last_error()) : 0;
+    return mzk_walk(b, pick_stream(stream), 0) ? mzi_set_err("%s", mzk_last_error()) : 0;
 }
 int mz_dev_emit(const mz_dev_batch *b, void *stream)
 {
-    if (ensure_init()) return -1;
-    return mzk_emit(b, pick_stream(stream)) ? set_err("%s", mzk_last_error()) : 0;
+    if (mzi_ensure_init()) return -1;
+    return mzk_emit(b, pick_stream(stream)) ? mzi_set_err("%s", mzk_last_error()) : 0;
 }
 
 int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
@@ -481,24 +446,24 @@ int mz_dev_run(const mz_dev_batch *b, void *stream, float ms[4])
     hipStream_t s;
     mz_dev_batch tmp;
     int i;
-    if (ensure_init() || sync_global_scores()) return -1;
+    if (mzi_ensure_init() || mzi_sync_scores()) return -1;
     b = checked_hints(b, &tmp);
     s = (hipStream_t)pick_stream(stream);
     if (ms) {                              /* serial, one HIP event pair per phase */
         HIPCK(hipEventRecord(G.ev[0], s));
-        if (mzk_plan(b, s) || mzk_prep(b, s)) return set_err("%s", mzk_last_error());
+        if (mzk_plan(b, s) || mzk_prep(b, s)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[1], s));
-        if (mzk_dp(b, s)) return set_err("%s", mzk_last_error());
+        if (mzk_dp(b, s)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[2], s));
-        if (mzk_walk(b, s, 0)) return set_err("%s", mzk_last_error());
+        if (mzk_walk(b, s, 0)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[3], s));
-        if (mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+        if (mzk_emit(b, s)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.ev[4], s));
         HIPCK(hipEventSynchronize(G.ev[4]));
         for (i = 0; i < 4; ++i) HIPCK(hipEventElapsedTime(&ms[i], G.ev[i], G.ev[i + 1]));
         return 0;
     }
-    if (mzk_plan(b, s) || mzk_prep(b, s) || mzk_dp(b, s) || mzk_walk(b, s, 0) || mzk_emit(b, s)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(b, s) || mzk_prep(b, s) || mzk_dp(b, s) || mzk_walk(b, s, 0) || mzk_emit(b, s)) return mzi_set_err("%s", mzk_last_error());
     return 0;
 }
 
@@ -532,7 +497,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
     hipStream_t s;
     mz_dev_batch tmp;
     int w, slot = -1;
-    if (ensure_init() || sync_global_scores() || lazy_stream(&G.stream2) || lazy_stream(&G.stream3)) return -1;
+    if (mzi_ensure_init() || mzi_sync_scores() || mzi_lazy_stream(&G.stream2) || mzi_lazy_stream(&G.stream3)) return -1;
     b = checked_hints(b, &tmp);
     s = (hipStream_t)pick_stream(stream);
     for (w = 0; w < MZ_WS_MAX; ++w) if (G.ws[w].used && G.ws[w].key == (const void *)b->tbw) slot = w;
@@ -551,7 +516,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
         HIPCK(hipStreamWaitEvent(G.stream3, G.ws[slot].done, 0));      /* its previous batch has been walked and emitted */
     }
     if (ready_event) HIPCK(hipStreamWaitEvent(G.stream3, (hipEvent_t)ready_event, 0));
-    if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(b, G.stream3) || mzk_prep(b, G.stream3)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.evs[3], G.stream3));
     /* Small batches -- at most a few waves per SIMD: the 1 000 long pairs of C5, the 5 000 of C3 -- leave the GPU
      * half empty while their last waves finish, and a lone wave per SIMD is latency-bound throughout (section 4.1 of
@@ -572,16 +537,16 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
         if (depth > 1) {
             const unsigned turn = G.dp_turn++ % (unsigned)depth;
             if (turn > 0) {
-                if (lazy_stream(&G.stream_dp[turn - 1])) return -1;
+                if (mzi_lazy_stream(&G.stream_dp[turn - 1])) return -1;
                 sd = G.stream_dp[turn - 1];
             }
         }
         HIPCK(hipStreamWaitEvent(sd, G.evs[3], 0));
-        if (mzk_dp(b, sd)) return set_err("%s", mzk_last_error());
+        if (mzk_dp(b, sd)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.evs[2], sd));
     }
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
-    if (mzk_walk(b, G.stream2, 1) || mzk_emit(b, G.stream2)) return set_err("%s", mzk_last_error());
+    if (mzk_walk(b, G.stream2, 1) || mzk_emit(b, G.stream2)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(G.ws[slot].done, G.stream2));
     return 0;
 }
@@ -590,426 +555,11 @@ int mz_dev_wait(void *stream)
 {
     hipStream_t s;
     int w;
-    if (ensure_init()) return -1;
+    if (mzi_ensure_init()) return -1;
     s = (hipStream_t)pick_stream(stream);
     for (w = 0; w < MZ_WS_MAX; ++w)
         if (G.ws[w].used) HIPCK(hipStreamWaitEvent(s, G.ws[w].done, 0));
     return 0;
-}
-
-/* ------------------------------------------------------------------ host-buffer batch */
-
-#include <time.h>
-static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
-
-/* host threads of the pack / unpack loops: enough to saturate memory bandwidth; waking a whole 256-thread pool
- * for a 2 ms loop costs more than it saves (and was seen to stall for 70-100 ms now and then) */
-#define MZ_COPY_THREADS 24
-static int g_copy_threads = MZ_COPY_THREADS;   /* per device worker; fewer each when several GPUs work side by side */
-
-/* One chunk of a host batch in flight, on the stream and buffers of set `set`, in three steps:
- *   chunk_upload()  packs the jobs into pinned memory and issues the copy to the device, the plan and the copy of
- *                   the plan's totals back (asynchronous: the host goes on to pack the next chunk);
- *   chunk_launch()  waits for those totals, sizes the workspaces and issues the kernels and the copy of the per-pair
- *                   results (status, OM, scores, where each pair's merged columns start in the PACKED output, and how
- *                   many bytes that is);
- *   chunk_fetch()   waits for those and issues the copy of the merged columns: what they fill (4.4 KB per C2 pair), not
- *                   the slices the plan laid out by their upper bound (8.0 KB);
- *   chunk_collect() waits for the columns and fills the caller's outs. */
-typedef struct chunk {
-    mz_ctx *X;
-    int set, n;
-    const mz_job *jobs;
-    mz_out *outs;
-    mz_dev_batch b;
-    int64_t out_bytes, in_bytes;
-    double t_pack, t_plan;
-    int fetched;
-} chunk;
-
-static int chunk_upload(mz_ctx *X, chunk *c, int set, int n, const mz_job *jobs, mz_out *outs)
-{
-    double t0 = now_s();
-    hipStream_t st;
-    mz_dev_batch b;
-    size_t bytesA = 0, bytesB = 0, nband = 0, hdr, in_bytes;
-    char *h, *d;
-    int32_t *hK, *hL, *hM, *hN, *hLen;
-    const int32_t *dLen;
-    int64_t *hoA, *hoB, *hoBand, *hoC;
-    const int64_t *doC;
-    uint8_t *hA, *hB, *hFmt, *hC;
-    const uint8_t *dFmt, *dC;
-    size_t bytesC = 0;
-    uint32_t *csz;
-    int p;
-
-    if (lazy_stream(&X->bstream[set])) return -1;
-    st = X->bstream[set];
-    c->X = X; c->set = set; c->n = n; c->jobs = jobs; c->outs = outs;
-
-    for (p = 0; p < n; ++p) {
-        const mz_job *j = &jobs[p];
-        int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
-        bytesA += ok ? (size_t)j->K * j->M : 0;
-        bytesB += ok ? (size_t)j->L * j->N : 0;
-        nband += ok ? (size_t)j->M + 1 : 1;
-    }
-    /* how each pair's band bounds will travel (see below): decided first, in parallel, so that the staging block has
-     * their real size and the copy to the device moves no slack */
-    csz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *csz);
-    if (!csz) return set_err("out of memory");
-#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
-    for (p = 0; p < n; ++p) {
-        const mz_job *j = &jobs[p];
-        if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
-            const int M = j->M;
-            int i, small = 1;
-            for (i = 1; i <= M && small; ++i)
-                small = (unsigned)(j->LB[i] - j->LB[i - 1]) < 256u && (unsigned)(j->RB[i] - j->RB[i - 1]) < 256u;
-            /* bit 31: byte steps; low bits: bytes in the staging block, a multiple of 4 */
-            csz[p] = small ? (0x80000000u | (uint32_t)((8 + 2 * (size_t)M + 3) & ~(size_t)3)) : (uint32_t)(8 * ((size_t)M + 1));
-        } else csz[p] = 8;
-    }
-    for (p = 0; p < n; ++p) bytesC += csz[p] & 0x7fffffffu;
-    /* one pinned staging block: [K L M N bandLen](int32 x n) [offA offB offBand offC](int64 x n) fmt(n) bands A B.
-     * The band bounds travel delta-coded where they can (k_unband, mz_device.hip) and are expanded on the device
-     * into poolLB / poolRB, which live in a device-only buffer: they were two thirds of the input of a C2 pair. */
-    hdr = al256(4 * (size_t)n) * 5 + al256(8 * (size_t)n) * 4 + al256((size_t)n);
-    in_bytes = hdr + al256(bytesC) + al256(bytesA) + al256(bytesB);
-    if (host_reserve(&X->h_in[set], in_bytes) || dev_reserve(&X->d_in[set], in_bytes) ||
-        dev_reserve(&X->d_band[set], 2 * al256(4 * nband))) { free(csz); return -1; }
-    h = (char *)X->h_in[set].p; d = (char *)X->d_in[set].p;
-
-    memset(&b, 0, sizeof b);
-    b.n = n;
-#define SLICE(hptr, type, field, bytes) do { hptr = (type *)h; b.field = (const type *)d; \
-        h += al256(bytes); d += al256(bytes); } while (0)
-    SLICE(hK, int32_t, K, 4 * (size_t)n); SLICE(hL, int32_t, L, 4 * (size_t)n);
-    SLICE(hM, int32_t, M, 4 * (size_t)n); SLICE(hN, int32_t, N, 4 * (size_t)n);
-    SLICE(hoA, int64_t, offA, 8 * (size_t)n); SLICE(hoB, int64_t, offB, 8 * (size_t)n);
-    SLICE(hoBand, int64_t, offBand, 8 * (size_t)n);
-    hLen = (int32_t *)h; dLen = (const int32_t *)d; h += al256(4 * (size_t)n); d += al256(4 * (size_t)n);
-    hoC = (int64_t *)h; doC = (const int64_t *)d; h += al256(8 * (size_t)n); d += al256(8 * (size_t)n);
-    hFmt = (uint8_t *)h; dFmt = (const uint8_t *)d; h += al256((size_t)n); d += al256((size_t)n);
-    hC = (uint8_t *)h; dC = (const uint8_t *)d; h += al256(bytesC); d += al256(bytesC);
-    SLICE(hA, uint8_t, poolA, bytesA); SLICE(hB, uint8_t, poolB, bytesB);
-#undef SLICE
-    b.poolLB = (const int32_t *)X->d_band[set].p;
-    b.poolRB = (const int32_t *)((char *)X->d_band[set].p + al256(4 * nband));
-    {
-        size_t oa = 0, ob = 0, oband = 0, oc = 0;
-        for (p = 0; p < n; ++p) {                            /* offsets first ... */
-            const mz_job *j = &jobs[p];
-            int ok = j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1;
-            hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
-            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
-            hLen[p] = ok ? j->M + 1 : 1;
-            if (ok) { oa += (size_t)j->K * j->M; ob += (size_t)j->L * j->N; oband += (size_t)j->M + 1; }
-            else oband += 1;
-            oc += csz[p] & 0x7fffffffu;
-        }
-        /* ... then the copies into the pinned staging block, on all host threads (a single thread moves
-         * ~14 GB/s: 18 ms for the 240 MB of a 20 000-pair C2 batch, three times the GPU work) */
-#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
-        for (p = 0; p < n; ++p) {
-            const mz_job *j = &jobs[p];
-            if (j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1) {
-                memcpy(hA + hoA[p], j->A, (size_t)j->K * j->M);
-                memcpy(hB + hoB[p], j->B, (size_t)j->L * j->N);
-                {   /* band bounds: byte steps when every step of LB and RB is 0..255, raw otherwise */
-                    const int M = j->M, small = (csz[p] >> 31) != 0;
-                    uint8_t *c8 = hC + hoC[p];
-                    int i;
-                    hFmt[p] = (uint8_t)small;
-                    if (small) {
-                        ((int32_t *)c8)[0] = j->LB[0]; ((int32_t *)c8)[1] = j->RB[0];
-                        for (i = 1; i <= M; ++i) { c8[8 + i - 1] = (uint8_t)(j->LB[i] - j->LB[i - 1]); c8[8 + M + i - 1] = (uint8_t)(j->RB[i] - j->RB[i - 1]); }
-                    } else {
-                        memcpy(c8, j->LB, 4 * ((size_t)M + 1));
-                        memcpy(c8 + 4 * ((size_t)M + 1), j->RB, 4 * ((size_t)M + 1));
-                    }
-                }
-            } else {
-                hFmt[p] = 0;
-                memset(hC + hoC[p], 0, 8);
-            }
-        }
-    }
-    free(csz);
-    c->t_pack = now_s() - t0;
-    c->in_bytes = (int64_t)in_bytes;
-    HIPCK(hipMemcpyAsync(X->d_in[set].p, X->h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
-    if (mzk_unband(n, dLen, b.offBand, doC, dFmt, dC, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st)) return set_err("%s", mzk_last_error());
-
-    if (dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
-    mz_dev_carve(&b, X->d_plan[set].p);
-    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
-    if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(X->h_tot[set].p, b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCK(hipEventRecord(X->bplan[set], st));
-    c->b = b;
-    return 0;
-}
-
-static int chunk_launch(chunk *c)
-{
-    mz_ctx *X = c->X;
-    const int set = c->set, n = c->n;
-    const double t0 = now_s();
-    hipStream_t st = X->bstream[set];
-    mz_dev_batch b = c->b;
-    const int64_t *totals = (const int64_t *)X->h_tot[set].p;
-    size_t res_bytes;
-
-    HIPCK(hipEventSynchronize(X->bplan[set]));
-    c->t_plan = now_s() - t0;
-
-    if (dev_reserve(&X->d_tb[set], 4 * (size_t)totals[0] + 256) || dev_reserve(&X->d_script[set], (size_t)totals[1] + 256) ||
-        dev_reserve(&X->d_out[set], (size_t)totals[2] + 256) || dev_reserve(&X->d_prep[set], 4 * (size_t)totals[4] + 256))
-        return -1;
-    b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = (uint8_t *)X->d_out[set].p;
-    b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
-    b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
-    b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
-    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
-    b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = (int64_t)X->d_out[set].cap;
-
-    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 1) || mzk_emit_packed(&b, st))
-        return set_err("%s", mzk_last_error());
-
-    /* results: status, badrow, om (int32 x n), final3 (3n), packed offsets (int64 x n), packed bytes (one int64), then
-     * the merged columns (chunk_fetch: their size is not known here; the buffer is sized for the unpacked layout) */
-    res_bytes = al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n) + 256 + al256((size_t)totals[2]);
-    if (host_reserve(&X->h_res[set], res_bytes)) return -1;
-    {
-        char *r = (char *)X->h_res[set].p;
-        HIPCK(hipMemcpyAsync(r, b.status, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, b.badrow, 4 * (size_t)n, hipMemcpyDeviceToHost, st));   r += al256(4 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, b.om, 4 * (size_t)n, hipMemcpyDeviceToHost, st));       r += al256(4 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, b.final3, 12 * (size_t)n, hipMemcpyDeviceToHost, st));  r += al256(12 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, b.szScript, 8 * (size_t)n, hipMemcpyDeviceToHost, st)); r += al256(8 * (size_t)n);
-        HIPCK(hipMemcpyAsync(r, &b.totals[12], 8, hipMemcpyDeviceToHost, st));
-    }
-    HIPCK(hipEventRecord(X->bsmall[set], st));
-    c->b = b; c->out_bytes = 0; c->fetched = 0;
-    return 0;
-}
-
-/* the merged columns of a launched chunk: as many bytes as they fill */
-static int chunk_fetch(chunk *c)
-{
-    mz_ctx *X = c->X;
-    const int n = c->n, set = c->set;
-    char *r = (char *)X->h_res[set].p + al256(4 * (size_t)n) * 3 + al256(12 * (size_t)n) + al256(8 * (size_t)n);
-    hipStream_t st = X->bstream[set];
-    if (c->fetched) return 0;
-    HIPCK(hipEventSynchronize(X->bsmall[set]));
-    c->out_bytes = *(const int64_t *)r;
-    if (c->out_bytes > 0) HIPCK(hipMemcpyAsync(r + 256, c->b.out, (size_t)c->out_bytes, hipMemcpyDeviceToHost, st));
-    HIPCK(hipEventRecord(X->bdone[set], st));
-    c->fetched = 1;
-    return 0;
-}
-
-static int chunk_collect(chunk *c)
-{
-    mz_ctx *X = c->X;
-    const int n = c->n, set = c->set;
-    const mz_job *jobs = c->jobs;
-    mz_out *outs = c->outs;
-    char *r = (char *)X->h_res[set].p;
-    int32_t *rs = (int32_t *)r, *rb, *ro, *rf;
-    int64_t *roff;
-    uint8_t *rout;
-    int p, failed = 0, oom = 0;
-    double t0 = now_s(), t1;
-
-    r += al256(4 * (size_t)n); rb = (int32_t *)r;
-    r += al256(4 * (size_t)n); ro = (int32_t *)r;
-    r += al256(4 * (size_t)n); rf = (int32_t *)r;
-    r += al256(12 * (size_t)n); roff = (int64_t *)r;
-    r += al256(8 * (size_t)n); rout = (uint8_t *)r + 256;
-    if (chunk_fetch(c)) return -1;
-    HIPCK(hipEventSynchronize(X->bdone[set]));
-    t1 = now_s();
-#pragma omp parallel for schedule(static) num_threads(g_copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
-    for (p = 0; p < n; ++p) {
-        mz_out *o = &outs[p];
-        o->status = rs[p]; o->badrow = rb[p]; o->OM = 0; o->cols = NULL;
-        o->score[0] = o->score[1] = o->score[2] = 0;
-        if (rs[p] == MZ_E_EMIT) { o->OM = ro[p]; o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; }   /* i, j of the reference's message */
-        if (rs[p] != MZ_OK) { failed++; continue; }
-        o->OM = ro[p];
-        o->score[0] = rf[3 * p]; o->score[1] = rf[3 * p + 1]; o->score[2] = rf[3 * p + 2];
-        {
-            size_t nb = (size_t)ro[p] * (size_t)(jobs[p].K + jobs[p].L);
-            o->cols = (unsigned char *)malloc(nb ? nb : 1);
-            if (!o->cols) { oom = 1; o->status = MZ_E_DEVICE; o->OM = 0; continue; }
-            memcpy(o->cols, rout + roff[p], nb);
-        }
-    }
-    if (oom) return set_err("out of memory for the output columns");
-    if (getenv("MZ_TIMING"))
-        fprintf(stderr, "mz_yama_batch chunk(%d): pack %.2f ms, wait for H2D + plan %.2f ms, wait for kernels + D2H %.2f ms, unpack %.2f ms; %.0f B per pair to the device, %.0f B back\n",
-                n, 1e3 * c->t_pack, 1e3 * c->t_plan, 1e3 * (t1 - t0), 1e3 * (now_s() - t1), (double)c->in_bytes / n,
-                (double)(c->out_bytes + 32 * (int64_t)n) / n);
-    return failed;
-}
-
-/* A batch of any size on ONE context: chunks of 1 Ki - 16 Ki pairs / at most ~1 GB of input columns go through four
- * rotating sets of staging buffers, so that a guide-tree level with a million merges (BASELINE config 4) needs a
- * bounded amount of pinned host memory and HBM.  MZ_CHUNK_PAIRS overrides the pair limit.
- * Up to four chunks are in flight on four buffer sets and streams: while chunk k is uploaded and planned the host
- * packs chunk k+1; when the plan's totals of chunk k are in, its kernels and the copy of its results are issued;
- * chunk k-1 is computing or copying back; chunk k-2 is unpacked.  The host does not wait for a copy or a kernel it
- * could work beside.  On a device error everything in flight is drained and every pair not yet collected is left
- * marked MZ_E_DEVICE with cols == NULL (mz_yama_batch() pre-marks all of them), so a caller may clean up outs. */
-static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int max_pairs)
-{
-    chunk ck[MZ_SETS];
-    int k = 0, up = 0, done = 0, failed = 0, rc = 0, s;
-#define NEXT_CHUNK(first, count) do { size_t bytes_ = 0; int m_ = 0; \
-        while ((first) + m_ < n && m_ < max_pairs && bytes_ < ((size_t)1 << 30)) { \
-            const mz_job *j_ = &jobs[(first) + m_]; \
-            if (j_->K >= 1 && j_->L >= 1 && j_->M >= 1 && j_->N >= 1) \
-                bytes_ += (size_t)j_->K * j_->M + (size_t)j_->L * j_->N + 8 * ((size_t)j_->M + 1); \
-            ++m_; } (count) = m_; } while (0)
-#define STEP(call) do { rc = (call); if (rc < 0) goto fail; } while (0)
-    if (hipSetDevice(X->device) != hipSuccess) return set_err("hipSetDevice(%d) failed", X->device);
-    {
-        int m0;
-        NEXT_CHUNK(0, m0);
-        STEP(chunk_upload(X, &ck[0], 0, m0, jobs, outs));
-        up = m0;
-    }
-    for (k = 0; done < n; ++k) {
-        chunk *cur = &ck[k % MZ_SETS];
-        if (up < n) {                                    /* pack + upload the next chunk beside this one's copy */
-            int m1;
-            NEXT_CHUNK(up, m1);
-            STEP(chunk_upload(X, &ck[(k + 1) % MZ_SETS], (k + 1) % MZ_SETS, m1, jobs + up, outs + up));
-            up += m1;
-        }
-        STEP(chunk_launch(cur));
-        if (k > 0) STEP(chunk_fetch(&ck[(k - 1) % MZ_SETS]));     /* (its kernels were issued an iteration ago) */
-        if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
-        done += cur->n;
-    }
-    if (k > 1) { STEP(chunk_collect(&ck[(k - 2) % MZ_SETS])); failed += rc; }
-    STEP(chunk_collect(&ck[(k - 1) % MZ_SETS])); failed += rc;
-    return failed;
-fail:
-    for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
-    return -1;
-#undef NEXT_CHUNK
-#undef STEP
-}
-
-/* host thread of one further GPU (mz_yama_batch with several contexts) */
-typedef struct dev_task { mz_ctx *X; int n, max_pairs, rc; const mz_job *jobs; mz_out *outs; char err[600]; } dev_task;
-static void *dev_worker(void *arg)
-{
-    dev_task *t = (dev_task *)arg;
-    t->rc = batch_on_ctx(t->X, t->n, t->jobs, t->outs, t->max_pairs);
-    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, g_err);
-    return NULL;
-}
-
-/* what a pair costs the GPU, roughly: band rows x the band's width in the middle (no pass over the bounds) */
-static double job_weight(const mz_job *j)
-{
-    if (j->K < 1 || j->L < 1 || j->M < 1 || j->N < 1 || !j->LB || !j->RB) return 1.0;
-    return ((double)j->M + 1.0) * (double)(j->RB[j->M / 2] - j->LB[j->M / 2] + 1) + 64.0 * (j->K + j->L);
-}
-
-#define MZ_MULTI_MIN 2048                  /* pairs per GPU below which dealing a batch out is not worth a thread */
-
-int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
-{
-    static int env_pairs = -1;
-    int failed = 0, max_pairs, use, p, rc;
-    if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
-    if (n <= 0) return 0;
-    for (p = 0; outs && p < n; ++p) {                    /* "not computed" until a chunk says otherwise */
-        outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL;
-        outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
-    }
-    pthread_mutex_lock(&g_big);
-    {
-        const int first = !g_ndev && getenv("MZ_TIMING") != NULL;
-        struct timespec t0, t1, t2;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        if (ensure_init()) { pthread_mutex_unlock(&g_big); return -1; }
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        if (sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
-        if (!jobs || !outs) { pthread_mutex_unlock(&g_big); return set_err("mz_yama_batch: NULL jobs or outs"); }
-        clock_gettime(CLOCK_MONOTONIC, &t2);
-        if (first) fprintf(stderr, "mz_yama_batch: GPU start-up %.1f ms (HIP runtime, streams; %d GPU%s), score upload incl. code object load %.1f ms\n",
-                           1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), g_ndev, g_ndev > 1 ? "s" : "",
-                           1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec));
-    }
-    /* GPUs to use: all of them once every one gets a worthwhile share */
-    use = g_ndev;
-    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
-    {
-        /* chunk size: about a quarter of a GPU's share, so that even a few thousand pairs overlap their copies with
-         * their kernels, but at least 1 Ki pairs (a wave per SIMD; chunks in flight share the GPU) and at most 16 Ki */
-        const int share = (n + use - 1) / use;
-        max_pairs = env_pairs ? env_pairs : (share + 3) / 4 < 1024 ? 1024 : (share + 3) / 4 > 16384 ? 16384 : (share + 3) / 4;
-    }
-    if (use == 1) {
-        g_copy_threads = MZ_COPY_THREADS;
-        rc = batch_on_ctx(&G, n, jobs, outs, max_pairs);
-        pthread_mutex_unlock(&g_big);
-        return rc;
-    }
-    {
-        /* Contiguous ranges of about equal weight, one per GPU, each driven by its own host thread through its own
-         * context (streams, staging buffers); results land in outs[] at the jobs' own positions, so there is nothing
-         * to gather.  No data-path collective: the work list lives in host memory and every GPU pulls its share over
-         * its own PCIe link. */
-        dev_task task[MZ_MAX_DEV];
-        pthread_t th[MZ_MAX_DEV];
-        double total = 0.0, acc = 0.0;
-        int d = 0, start = 0, started[MZ_MAX_DEV];
-        for (p = 0; p < n; ++p) total += job_weight(&jobs[p]);
-        g_copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
-        for (p = 0; p < n && d < use; ++p) {
-            acc += job_weight(&jobs[p]);
-            if (d == use - 1) { p = n - 1; acc = total; }
-            if (acc >= total * (d + 1) / use || p == n - 1) {
-                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
-                task[d].n = p + 1 - start; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0;
-                start = p + 1;
-                ++d;
-            }
-        }
-        use = d;
-        for (d = 1; d < use; ++d) {
-            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, dev_worker, &task[d]) == 0;
-            if (!started[d] && task[d].n > 0) dev_worker(&task[d]);         /* no thread: do it here, after the others started */
-        }
-        if (task[0].n > 0) dev_worker(&task[0]);
-        rc = 0;
-        for (d = 0; d < use; ++d) {
-            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
-            if (task[d].n <= 0) continue;
-            if (task[d].rc < 0) { rc = -1; set_err("%s", task[d].err); }
-            else failed += task[d].rc;
-        }
-        hipSetDevice(G.device);
-        g_copy_threads = MZ_COPY_THREADS;
-        pthread_mutex_unlock(&g_big);
-        return rc < 0 ? -1 : failed;
-    }
-}
-
-/* free the merged columns of a finished mz_yama_batch() call (every cols pointer; NULLs are skipped) */
-void mz_free_outs(int n, mz_out *outs)
-{
-    int p;
-    for (p = 0; p < n; ++p) { free(outs[p].cols); outs[p].cols = NULL; }
 }
 
 /* ------------------------------------------------------------------ pre_yama() batches */
@@ -1033,22 +583,22 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
 
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
-        if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1) return set_err("mz_preyama_batch: job %d has an empty block or slice", p);
+        if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1) return mzi_set_err("mz_preyama_batch: job %d has an empty block or slice", p);
         txt += (size_t)j->K * j->M_all + (size_t)j->L1 * j->N_all;
         szA += (size_t)j->K * j->M_all; szB += (size_t)(j->L1 - 1) * j->N_all;
         nband += (size_t)j->M_all + 1; nscr += 2 * ((size_t)j->N_all + 2) + 2 * ((size_t)j->M_all + 2);
         nrow += (size_t)j->K + j->L1 - 1;
     }
     /* pinned staging: K L Ma Na rad (int32 x n), offT1 offT2 offA offB offBand offScr offRow (int64 x n), text */
-    hdr = 5 * al256(4 * (size_t)n) + 7 * al256(8 * (size_t)n);
-    in_bytes = hdr + al256(txt);
-    if (host_reserve(&X->h_pre[0], in_bytes) || dev_reserve(&X->d_pre[0], in_bytes) ||
-        dev_reserve(&X->d_pre[1], al256(szA) + al256(szB) + 256) || dev_reserve(&X->d_pre[2], 2 * al256(4 * nband)) ||
-        dev_reserve(&X->d_pre[3], 4 * nscr + 256)) return -1;
+    hdr = 5 * mzi_al256(4 * (size_t)n) + 7 * mzi_al256(8 * (size_t)n);
+    in_bytes = hdr + mzi_al256(txt);
+    if (mzi_host_reserve(&X->h_pre[0], in_bytes) || mzi_dev_reserve(&X->d_pre[0], in_bytes) ||
+        mzi_dev_reserve(&X->d_pre[1], mzi_al256(szA) + mzi_al256(szB) + 256) || mzi_dev_reserve(&X->d_pre[2], 2 * mzi_al256(4 * nband)) ||
+        mzi_dev_reserve(&X->d_pre[3], 4 * nscr + 256)) return -1;
     h = (char *)X->h_pre[0].p; d = (char *)X->d_pre[0].p;
     memset(&b, 0, sizeof b); memset(&q, 0, sizeof q); memset(&r, 0, sizeof r);
     b.n = q.n = n;
-#define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += al256(bytes); d += al256(bytes); } while (0)
+#define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
     SL(hK, int32_t, q.K, 4 * (size_t)n); SL(hL, int32_t, q.L, 4 * (size_t)n); SL(hMa, int32_t, q.Ma, 4 * (size_t)n);
     SL(hNa, int32_t, q.Na, 4 * (size_t)n); SL(hRad, int32_t, q.rad, 4 * (size_t)n);
     SL(hT1, int64_t, q.offT1, 8 * (size_t)n); SL(hT2, int64_t, q.offT2, 8 * (size_t)n);
@@ -1069,7 +619,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
             hoScr[p] = (int64_t)os; os += 2 * ((size_t)j->N_all + 2) + 2 * ((size_t)j->M_all + 2);
             hoRow[p] = (int64_t)orow; orow += (size_t)j->K + j->L1 - 1;
         }
-#pragma omp parallel for schedule(static) num_threads(g_copy_threads) if (n > 256)
+#pragma omp parallel for schedule(static) num_threads(X->copy_threads) if (n > 256)
         for (p = 0; p < n; ++p) {
             const mz_prejob *j = &jobs[p];
             int k;
@@ -1078,45 +628,45 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
         }
     }
     HIPCK(hipMemcpyAsync(X->d_pre[0].p, X->h_pre[0].p, in_bytes, hipMemcpyHostToDevice, st));
-    b.poolA = (const uint8_t *)X->d_pre[1].p; b.poolB = (const uint8_t *)X->d_pre[1].p + al256(szA);
-    b.poolLB = (const int32_t *)X->d_pre[2].p; b.poolRB = (const int32_t *)((char *)X->d_pre[2].p + al256(4 * nband));
+    b.poolA = (const uint8_t *)X->d_pre[1].p; b.poolB = (const uint8_t *)X->d_pre[1].p + mzi_al256(szA);
+    b.poolLB = (const int32_t *)X->d_pre[2].p; b.poolRB = (const int32_t *)((char *)X->d_pre[2].p + mzi_al256(4 * nband));
     q.scr = (int32_t *)X->d_pre[3].p;
     /* K L M N of the device batch, the NULL flags, sizes, scores: one more device block */
-    if (dev_reserve(&X->d_pre[4], 5 * al256(4 * (size_t)n) + al256(4 * nrow) + al256(8 * (size_t)n))) return -1;
+    if (mzi_dev_reserve(&X->d_pre[4], 5 * mzi_al256(4 * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256(8 * (size_t)n))) return -1;
     {
         char *e = (char *)X->d_pre[4].p;
-        b.K = (const int32_t *)e; e += al256(4 * (size_t)n); b.L = (const int32_t *)e; e += al256(4 * (size_t)n);
-        b.M = (const int32_t *)e; e += al256(4 * (size_t)n); b.N = (const int32_t *)e; e += al256(4 * (size_t)n);
-        q.nullres = (int32_t *)e; e += al256(4 * (size_t)n);
-        r.size = (int32_t *)e; e += al256(4 * nrow);
+        b.K = (const int32_t *)e; e += mzi_al256(4 * (size_t)n); b.L = (const int32_t *)e; e += mzi_al256(4 * (size_t)n);
+        b.M = (const int32_t *)e; e += mzi_al256(4 * (size_t)n); b.N = (const int32_t *)e; e += mzi_al256(4 * (size_t)n);
+        q.nullres = (int32_t *)e; e += mzi_al256(4 * (size_t)n);
+        r.size = (int32_t *)e; e += mzi_al256(4 * nrow);
         r.score = (int64_t *)e;
     }
-    if (mzk_pre(&q, &b, st)) return set_err("%s", mzk_last_error());
+    if (mzk_pre(&q, &b, st)) return mzi_set_err("%s", mzk_last_error());
 
-    if (dev_reserve(&X->d_plan[0], mz_dev_plan_bytes(n))) return -1;
+    if (mzi_dev_reserve(&X->d_plan[0], mz_dev_plan_bytes(n))) return -1;
     mz_dev_carve(&b, X->d_plan[0].p);
     b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;
-    if (mzk_plan(&b, st)) return set_err("%s", mzk_last_error());
+    if (mzk_plan(&b, st)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipMemcpyAsync(totals, b.totals, sizeof totals, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
-    if (dev_reserve(&X->d_tb[0], 4 * (size_t)totals[0] + 256) || dev_reserve(&X->d_script[0], (size_t)totals[1] + 256) ||
-        dev_reserve(&X->d_out[0], (size_t)totals[2] + 256) || dev_reserve(&X->d_prep[0], 4 * (size_t)totals[4] + 256) ||
-        dev_reserve(&X->d_pre[5], (size_t)totals[2] + 256)) return -1;
-    b.tbw = (uint32_t *)X->d_tb[0].p; b.script = (uint8_t *)X->d_script[0].p; b.out = (uint8_t *)X->d_out[0].p;
+    if (mzi_dev_reserve(&X->d_tb[0], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[0], (size_t)totals[1] + 256) ||
+        mzi_dev_reserve(&X->d_out0, (size_t)totals[2] + 256) || mzi_dev_reserve(&X->d_prep[0], 4 * (size_t)totals[4] + 256) ||
+        mzi_dev_reserve(&X->d_pre[5], (size_t)totals[2] + 256)) return -1;
+    b.tbw = (uint32_t *)X->d_tb[0].p; b.script = (uint8_t *)X->d_script[0].p; b.out = (uint8_t *)X->d_out0.p;
     b.prep = (uint32_t *)X->d_prep[0].p; b.capPrep = (int64_t)(X->d_prep[0].cap / 4);
-    b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = (int64_t)X->d_out[0].cap;
+    b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = (int64_t)X->d_out0.cap;
     r.rows = (uint8_t *)X->d_pre[5].p;
     b.dp_hint = mz_dp_hint(n, totals); b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 0) || mzk_emit(&b, st) || mzk_post(&r, &b, st))
-        return set_err("%s", mzk_last_error());
+        return mzi_set_err("%s", mzk_last_error());
 
     /* results: status badrow om M N nullres (int32 x n), offOut score (int64 x n), sizes (int32 x rows), the rows */
-    res_bytes = 6 * al256(4 * (size_t)n) + 2 * al256(8 * (size_t)n) + al256(4 * nrow) + al256((size_t)totals[2]);
-    if (host_reserve(&X->h_pre[1], res_bytes)) return -1;
+    res_bytes = 6 * mzi_al256(4 * (size_t)n) + 2 * mzi_al256(8 * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256((size_t)totals[2]);
+    if (mzi_host_reserve(&X->h_pre[1], res_bytes)) return -1;
     hres = (char *)X->h_pre[1].p;
     {
         char *o = hres;
-#define DOWN(src, bytes) do { HIPCK(hipMemcpyAsync(o, src, bytes, hipMemcpyDeviceToHost, st)); o += al256(bytes); } while (0)
+#define DOWN(src, bytes) do { HIPCK(hipMemcpyAsync(o, src, bytes, hipMemcpyDeviceToHost, st)); o += mzi_al256(bytes); } while (0)
         DOWN(b.status, 4 * (size_t)n); DOWN(b.badrow, 4 * (size_t)n); DOWN(b.om, 4 * (size_t)n);
         DOWN(b.M, 4 * (size_t)n); DOWN(b.N, 4 * (size_t)n); DOWN(q.nullres, 4 * (size_t)n);
         DOWN(b.offOut, 8 * (size_t)n); DOWN(r.score, 8 * (size_t)n); DOWN(r.size, 4 * nrow);
@@ -1125,13 +675,13 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
     }
     HIPCK(hipStreamSynchronize(st));
     {
-        const int32_t *rs = (const int32_t *)hres, *rb = (const int32_t *)(hres + al256(4 * (size_t)n)),
-                      *ro = (const int32_t *)(hres + 2 * al256(4 * (size_t)n)), *rM = (const int32_t *)(hres + 3 * al256(4 * (size_t)n)),
-                      *rN = (const int32_t *)(hres + 4 * al256(4 * (size_t)n)), *rnull = (const int32_t *)(hres + 5 * al256(4 * (size_t)n));
-        const int64_t *roff = (const int64_t *)(hres + 6 * al256(4 * (size_t)n)), *rsc = roff + al256(8 * (size_t)n) / 8;
-        const int32_t *rsz = (const int32_t *)((const char *)rsc + al256(8 * (size_t)n));
-        const uint8_t *rrows = (const uint8_t *)rsz + al256(4 * nrow);
-#pragma omp parallel for schedule(static) num_threads(g_copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
+        const int32_t *rs = (const int32_t *)hres, *rb = (const int32_t *)(hres + mzi_al256(4 * (size_t)n)),
+                      *ro = (const int32_t *)(hres + 2 * mzi_al256(4 * (size_t)n)), *rM = (const int32_t *)(hres + 3 * mzi_al256(4 * (size_t)n)),
+                      *rN = (const int32_t *)(hres + 4 * mzi_al256(4 * (size_t)n)), *rnull = (const int32_t *)(hres + 5 * mzi_al256(4 * (size_t)n));
+        const int64_t *roff = (const int64_t *)(hres + 6 * mzi_al256(4 * (size_t)n)), *rsc = roff + mzi_al256(8 * (size_t)n) / 8;
+        const int32_t *rsz = (const int32_t *)((const char *)rsc + mzi_al256(8 * (size_t)n));
+        const uint8_t *rrows = (const uint8_t *)rsz + mzi_al256(4 * nrow);
+#pragma omp parallel for schedule(static) num_threads(X->copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
         for (p = 0; p < n; ++p) {
             mz_preout *o = &outs[p];
             const int W = jobs[p].K + jobs[p].L1 - 1;
@@ -1151,7 +701,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
             }
         }
     }
-    if (oom) return set_err("out of memory for the merged rows");
+    if (oom) return mzi_set_err("out of memory for the merged rows");
     if (getenv("MZ_TIMING"))
         fprintf(stderr, "mz_preyama_batch pass(%d): %.1f MB to the device (%.0f B per merge), %.1f MB back (%.0f B per merge)\n",
                 n, in_bytes / 1e6, (double)in_bytes / n, res_bytes / 1e6, (double)res_bytes / n);
@@ -1162,7 +712,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
 static int preyama_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs)
 {
     int done = 0, failed = 0;
-    if (hipSetDevice(X->device) != hipSuccess) return set_err("hipSetDevice(%d) failed", X->device);
+    if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
     while (done < n) {
         size_t bytes = 0;
         int m = 0, rc;
@@ -1193,10 +743,10 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
     int failed = 0, a, b, use, rc, p;
     if (n <= 0) return 0;
     pthread_mutex_lock(&g_big);
-    if (ensure_init() || sync_global_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+    if (mzi_ensure_init() || mzi_sync_scores()) { pthread_mutex_unlock(&g_big); return -1; }
     for (a = 0; a < 128; ++a)                              /* k_post's pair sums need ss[x][y] == ss[y][x] */
         for (b = 0; b < a; ++b)
-            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); set_err("score table is not symmetric"); return -2; }
+            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); mzi_set_err("score table is not symmetric"); return -2; }
     for (p = 0; p < n; ++p) { memset(&outs[p], 0, sizeof outs[p]); outs[p].status = MZ_E_DEVICE; }
     use = g_ndev;
     while (use > 1 && n / use < MZ_MULTI_MIN) --use;
@@ -1222,7 +772,7 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
             }
         }
         use = d;
-        g_copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
+        for (d = 0; d < use; ++d) g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
         for (d = 1; d < use; ++d) {
             started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, pre_worker, &task[d]) == 0;
             if (!started[d] && task[d].n > 0) pre_worker(&task[d]);
@@ -1232,11 +782,11 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
         for (d = 0; d < use; ++d) {
             if (d >= 1 && started[d]) pthread_join(th[d], NULL);
             if (task[d].n <= 0) continue;
-            if (task[d].rc < 0) { rc = -1; set_err("%s", task[d].err); }
+            if (task[d].rc < 0) { rc = -1; mzi_set_err("%s", task[d].err); }
             else failed += task[d].rc;
         }
         hipSetDevice(G.device);
-        g_copy_threads = MZ_COPY_THREADS;
+        for (d = 0; d < g_ndev; ++d) g_dev[d].copy_threads = MZ_COPY_THREADS;
         pthread_mutex_unlock(&g_big);
         return rc < 0 ? -1 : failed;
     }

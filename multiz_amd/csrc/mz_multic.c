@@ -131,7 +131,8 @@ static void run_multic(crecord *R, int radius, int v, int minw)
     mz_job *jobs = (mz_job *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mz_job));
     mz_out *outs = (mz_out *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mz_out));
     int *who = (int *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(int));
-    int i;
+    void **held = NULL;
+    int i, nheld = 0;
     mz_score_profile_sync();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)
     for (i = 0; i < nmg; ++i) {
@@ -145,11 +146,13 @@ static void run_multic(crecord *R, int radius, int v, int minw)
         if (n == 0) break;
         rc = mz_yama_batch(n, jobs, outs);
         if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+        for (i = 0; i < n; ++i) if (outs[i].block) held = mz_hold(held, &nheld, outs[i].block);   /* (kept until the last wave: see mz_multiz.c) */
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
         for (i = 0; i < n; ++i) {
             cmerge *g = &R->mg[who[i]];
             struct mafAli *res = NULL;
             if (outs[i].status != MZ_OK) { g->state = MERGE_FAILED; g->bad_job = jobs[i]; g->bad_out = outs[i]; continue; }
+            g->py.borrowed = 1;
             g->state = mz_py_step(&g->py, outs[i].cols, outs[i].OM, &res);
             if (g->state == MZ_PY_JOB || !res) continue;
             colour_top_row(res, g->a->ali, g->b->ali);
@@ -164,6 +167,8 @@ static void run_multic(crecord *R, int radius, int v, int minw)
             mafAliFree(&res);
         }
     }
+    for (i = 0; i < nheld; ++i) free(held[i]);
+    free(held);
     free(jobs); free(outs); free(who);
 }
 

@@ -367,7 +367,8 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
 
 static void run_merges(record **RR, int nrec, int minw)
 {
-    int nmg = 0, i, r;
+    int nmg = 0, i, r, nheld = 0;
+    void **held = NULL;
     mz_job *jobs;
     mz_out *outs;
     int *who;
@@ -414,14 +415,19 @@ static void run_merges(record **RR, int nrec, int minw)
         t0 = mz_now_s();
         rc = mz_yama_batch(n, jobs, outs);
         if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
+        /* the merged columns live in the call's result blocks; a v == 0 merge aligns against them in the next wave, so
+         * the blocks are kept until the last wave is through */
+        for (i = 0; i < n; ++i) if (outs[i].block) held = mz_hold(held, &nheld, outs[i].block);
         t1 = mz_now_s();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (n > 64)
         for (i = 0; i < n; ++i) {
             merge *g = &all[who[i]].R->mg[all[who[i]].i];
             if (outs[i].status != MZ_OK) {                  /* reported at its place in the output order, see replay() */
                 g->state = MERGE_FAILED; g->bad_job = jobs[i]; g->bad_out = outs[i];
-            } else
+            } else {
+                g->py.borrowed = 1;
                 g->state = mz_py_step(&g->py, outs[i].cols, outs[i].OM, &g->result);
+            }
             if (g->state != MZ_PY_JOB && g->state != MERGE_FAILED) {    /* finished: render and release here */
                 if (g->result && g->result->components->size >= minw) {
                     FILE *m = open_memstream(&g->text, &g->len);
@@ -434,6 +440,8 @@ static void run_merges(record **RR, int nrec, int minw)
         }
         if (timing) fprintf(stderr, "mz_multiz: yama batch of %d %.3f s (with GPU start-up in the first), next stage %.3f s\n", n, t1 - t0, mz_now_s() - t1);
     }
+    for (i = 0; i < nheld; ++i) free(held[i]);
+    free(held);
     free(jobs); free(outs); free(who); free(all);
 }
 

@@ -1,0 +1,212 @@
+/* mz_pool.c -- the host threads of the batch pipeline (mz_batch.c): one process-wide pool of sleeping workers and a
+ * parallel-for that several threads may call at once (the packer and the collector of every GPU's pipeline do).
+ *
+ * Why not OpenMP here: a libgomp team spins after every parallel region (GOMP_SPINCOUNT), two or three teams of 24
+ * spinning threads burn a container's CPU quota in tens of milliseconds (the GPU boxes of this project give a job
+ * 16 CPUs' worth of time per 100 ms: cpu.max "1600000 100000"), and the kernel then parks every thread of the process,
+ * the ones feeding the GPU included -- mz_yama_batch() of 50 000 pairs took 14 to 52 ms from call to call.  These
+ * workers sleep on a condition variable between jobs; what they cost is what they copy.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "mz_ctx.h"
+
+typedef struct pjob {
+    mz_pfn fn;
+    void *ctx;
+    int n, grain, next, pending;
+    struct pjob *link;
+} pjob;
+
+#define POOL_MAX 64
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t work, done;
+    pjob *head;
+    int nthreads, started, quit;
+    pthread_t th[POOL_MAX];
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, { 0 } };
+
+/* CPUs this process may use at once: the affinity mask, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs_quota) */
+int mzi_cpu_budget(void)
+{
+    cpu_set_t set;
+    int cpus = 0;
+    FILE *f;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+    if (cpus <= 0) cpus = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (cpus <= 0) cpus = 1;
+    if ((f = fopen("/sys/fs/cgroup/cpu.max", "r")) != NULL) {
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = atol(q);
+            if (quota > 0 && (quota + period - 1) / period < cpus) cpus = (int)((quota + period - 1) / period);
+        }
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) != NULL) {
+        long quota = -1, period = 100000;
+        FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+        if (g) { if (fscanf(g, "%ld", &period) != 1) period = 100000; fclose(g); }
+        fclose(f);
+        if (quota > 0 && period > 0 && (quota + period - 1) / period < cpus) cpus = (int)((quota + period - 1) / period);
+    }
+    return cpus;
+}
+
+static int grab(pjob *j, int *lo, int *hi)
+{
+    if (j->next >= j->n) return 0;
+    *lo = j->next;
+    *hi = j->next + j->grain < j->n ? j->next + j->grain : j->n;
+    j->next = *hi;
+    return 1;
+}
+
+static void *pool_worker(void *arg)
+{
+    (void)arg;
+    pthread_mutex_lock(&g_pool.mu);
+    while (!g_pool.quit) {
+        pjob *j;
+        int lo, hi;
+        for (j = g_pool.head; j && j->next >= j->n; j = j->link) ;
+        if (!j) { pthread_cond_wait(&g_pool.work, &g_pool.mu); continue; }
+        grab(j, &lo, &hi);
+        pthread_mutex_unlock(&g_pool.mu);
+        j->fn(j->ctx, lo, hi);
+        pthread_mutex_lock(&g_pool.mu);
+        j->pending -= hi - lo;
+        if (j->pending == 0) pthread_cond_broadcast(&g_pool.done);
+    }
+    pthread_mutex_unlock(&g_pool.mu);
+    return NULL;
+}
+
+/* workers: MZ_HOST_THREADS, or MZ_COPY_THREADS (fewer on a machine with fewer CPUs) -- more than a CPU quota's worth when
+ * there is one: the calls come in bursts (a quota of 16 CPUs is 1.6 s of CPU time per 100 ms, a 50 000-pair call spends
+ * 0.15 s of it), and measured on such a box 24 threads beat 16 by a fifth */
+static void pool_start_locked(void)
+{
+    const char *e = getenv("MZ_HOST_THREADS");
+    int want = e && atoi(e) > 0 ? atoi(e) : (int)sysconf(_SC_NPROCESSORS_ONLN), i;
+    if (want > MZ_COPY_THREADS && !(e && atoi(e) > 0)) want = MZ_COPY_THREADS;
+    if (want < 1) want = 1;
+    if (want > POOL_MAX) want = POOL_MAX;
+    g_pool.started = 1;
+    g_pool.nthreads = 0;
+    for (i = 0; i < want - 1; ++i) {
+        if (pthread_create(&g_pool.th[g_pool.nthreads], NULL, pool_worker, NULL) != 0) break;
+        ++g_pool.nthreads;
+    }
+}
+
+int mzi_pool_threads(void)
+{
+    int n;
+    pthread_mutex_lock(&g_pool.mu);
+    if (!g_pool.started) pool_start_locked();
+    n = g_pool.nthreads + 1;
+    pthread_mutex_unlock(&g_pool.mu);
+    return n;
+}
+
+/* fn(ctx, lo, hi) over [0, n) in pieces of `grain`, on the pool's workers and the calling thread; returns when every
+ * piece is done.  Small loops run in the caller alone. */
+void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx)
+{
+    pjob job, **pp;
+    int lo, hi;
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    if (n <= grain) { fn(ctx, 0, n); return; }
+    job.fn = fn; job.ctx = ctx; job.n = n; job.grain = grain; job.next = 0; job.pending = n; job.link = NULL;
+    pthread_mutex_lock(&g_pool.mu);
+    if (!g_pool.started) pool_start_locked();
+    for (pp = &g_pool.head; *pp; pp = &(*pp)->link) ;       /* jobs in arrival order: the older chunk first */
+    *pp = &job;
+    pthread_cond_broadcast(&g_pool.work);
+    while (grab(&job, &lo, &hi)) {
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(ctx, lo, hi);
+        pthread_mutex_lock(&g_pool.mu);
+        job.pending -= hi - lo;
+    }
+    while (job.pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    for (pp = &g_pool.head; *pp != &job; pp = &(*pp)->link) ;
+    *pp = job.link;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* mz_finalize(): the workers go (a later call starts new ones) */
+void mzi_pool_stop(void)
+{
+    int i, n;
+    pthread_mutex_lock(&g_pool.mu);
+    if (!g_pool.started || g_pool.head) { pthread_mutex_unlock(&g_pool.mu); return; }
+    g_pool.quit = 1;
+    n = g_pool.nthreads;
+    pthread_cond_broadcast(&g_pool.work);
+    pthread_mutex_unlock(&g_pool.mu);
+    for (i = 0; i < n; ++i) pthread_join(g_pool.th[i], NULL);
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.quit = 0; g_pool.started = 0; g_pool.nthreads = 0;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* ------------------------------------------------------------------------------------------------ result blocks
+ * The merged columns of a chunk are ONE malloc()ed block (mz_out.block).  A 27 MB block is an mmap() of its own
+ * to malloc: fresh zero pages on every call (52 000 page faults per 50 000-pair C2 call, 600 000 for a C4 share) and an
+ * munmap() on free.  mz_free_outs() therefore parks up to BLOCK_KEEP blocks / BLOCK_KEEP_BYTES here and the next calls
+ * take them back, warm; they stay ordinary malloc() pointers (a caller that free()s one itself just does not
+ * return it). */
+#include <malloc.h>
+#define BLOCK_KEEP 32
+#define BLOCK_KEEP_BYTES ((size_t)3 << 30)
+static struct { pthread_mutex_t mu; void *p[BLOCK_KEEP]; size_t cap[BLOCK_KEEP]; size_t bytes; int n; } g_blocks = { PTHREAD_MUTEX_INITIALIZER, { 0 }, { 0 }, 0, 0 };
+
+void *mzi_block_get(size_t need)
+{
+    void *p = NULL;
+    int i, best = -1;
+    pthread_mutex_lock(&g_blocks.mu);
+    for (i = 0; i < g_blocks.n; ++i)                         /* the smallest that fits, if it is not absurdly large for the job */
+        if (g_blocks.cap[i] >= need && (best < 0 || g_blocks.cap[i] < g_blocks.cap[best])) best = i;
+    if (best >= 0 && g_blocks.cap[best] <= 2 * need + (1 << 20)) {
+        p = g_blocks.p[best];
+        g_blocks.bytes -= g_blocks.cap[best];
+        g_blocks.p[best] = g_blocks.p[--g_blocks.n]; g_blocks.cap[best] = g_blocks.cap[g_blocks.n];
+    }
+    pthread_mutex_unlock(&g_blocks.mu);
+    return p ? p : malloc(need);
+}
+
+void mzi_block_put(void *p)
+{
+    size_t cap;
+    if (!p) return;
+    cap = malloc_usable_size(p);
+    pthread_mutex_lock(&g_blocks.mu);
+    if (cap >= ((size_t)1 << 20) && g_blocks.n < BLOCK_KEEP && g_blocks.bytes + cap <= BLOCK_KEEP_BYTES) {
+        g_blocks.p[g_blocks.n] = p; g_blocks.cap[g_blocks.n++] = cap; g_blocks.bytes += cap;
+        p = NULL;
+    }
+    pthread_mutex_unlock(&g_blocks.mu);
+    free(p);
+}
+
+void mzi_blocks_drop(void)
+{
+    int i;
+    pthread_mutex_lock(&g_blocks.mu);
+    for (i = 0; i < g_blocks.n; ++i) free(g_blocks.p[i]);
+    g_blocks.n = 0; g_blocks.bytes = 0;
+    pthread_mutex_unlock(&g_blocks.mu);
+}

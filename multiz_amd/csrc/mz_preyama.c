@@ -185,10 +185,10 @@ void mz_py_free(mz_py *p)
 {
     if (p->A) cols_free(p->A);
     if (p->B) cols_free(p->B);
-    if (p->merged) cols_free(p->merged);
+    if (p->merged) { if (p->borrowed) free(p->merged + 1); else cols_free(p->merged); }
     if (p->ref1) cols_free(p->ref1);
     if (p->ref2) cols_free(p->ref2);
-    if (p->merged2) cols_free(p->merged2);
+    if (p->merged2) { if (p->borrowed) free(p->merged2 + 1); else cols_free(p->merged2); }
     free(p->map1); free(p->map2); free(p->LB); free(p->RB);
     py_zero(p);
 }
@@ -270,7 +270,7 @@ int mz_py_begin(mz_py *p, struct mafAli *a1, struct mafAli *a2, int beg, int end
     return MZ_PY_JOB;
 }
 
-/* stage 2 / 3: `flat` = the merged columns of p->job (om columns; ownership passes to p).
+/* stage 2 / 3: `flat` = the merged columns of p->job (om columns; ownership passes to p unless p->borrowed).
  * MZ_PY_DONE: *result is pre_yama()'s return value; MZ_PY_JOB: (v == 0) run p->job once more. */
 int mz_py_step(mz_py *p, uchar *flat, int om, struct mafAli **result)
 {

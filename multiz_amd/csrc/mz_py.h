@@ -11,6 +11,9 @@ enum { MZ_PY_NULL = 0, MZ_PY_JOB = 1, MZ_PY_DONE = 2 };
 typedef struct mz_py {
     struct mafAli *a1, *a2;          /* borrowed: must outlive the last stage */
     int radius, v, stage;
+    int borrowed;                    /* 1: the merged columns handed to mz_py_step() stay the caller's (inside a result block of
+                                        mz_yama_batch(), released with mz_free_outs() after the last stage); 0: they are a
+                                        malloc()ed block of their own and this structure frees it */
     int K, L, M, N, M_all, N_all, cbeg1, cbeg2, cend2;
     unsigned char **A, **B, **merged, **ref1, **ref2, **merged2;
     int *map1, *map2, *LB, *RB;

@@ -160,6 +160,21 @@ def fnv1a_np(arr: np.ndarray, h: int = 0) -> int:
     return int(f(arr.ctypes.data, arr.size, h))
 
 
+def hash_cols(cols_ptr: np.ndarray, om: np.ndarray, width: np.ndarray) -> np.ndarray:
+    """per-pair FNV-1a of (OM, merged columns) for columns given by ADDRESS (uint64; 0 = none) -- the same hash as
+    ref_batch() / yama_batch() return, over the product's mz_out.cols of a host-path call"""
+    n = len(om)
+    ptr = np.ascontiguousarray(cols_ptr, dtype=np.uint64)
+    om = np.ascontiguousarray(om, dtype=np.int32)
+    width = np.ascontiguousarray(width, dtype=np.int32)
+    out = np.zeros(n, dtype=np.uint64)
+    f = lib().mzo_hash_cols
+    f.restype = None
+    f.argtypes = [C.c_int] + [C.c_void_p] * 4
+    f(n, ptr.ctypes.data, om.ctypes.data, width.ctypes.data, out.ctypes.data)
+    return out
+
+
 def _batch_args(batch: dict):
     arrs = [np.ascontiguousarray(batch[k], dtype=np.int32) for k in ("K", "L", "M", "N")]
     offs = [np.ascontiguousarray(batch[k], dtype=np.int64) for k in ("offA", "offB", "offBand")]

@@ -99,3 +99,16 @@ double mzo_spin(int threads, int64_t iters)
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) + (sink == 42 ? 1e-12 : 0.0);
 }
+
+/* per-pair hash of (OM, merged columns) as mzo_ref_batch() / mzo_yama_batch() compute it, over columns that lie
+ * anywhere in memory (the mz_out.cols pointers of the product's host path): bench.py's parity gate */
+void mzo_hash_cols(int n, const uint64_t *cols_ptr, const int32_t *om, const int32_t *width, uint64_t *hash)
+{
+    int p;
+#pragma omp parallel for schedule(static)
+    for (p = 0; p < n; ++p) {
+        const int32_t m = om[p];
+        const uint64_t h = mzo_fnv1a((const uint8_t *)&m, 4, 0);
+        hash[p] = cols_ptr[p] ? mzo_fnv1a((const uint8_t *)(uintptr_t)cols_ptr[p], (int64_t)m * width[p], h) : 0;
+    }
+}

@@ -664,7 +664,7 @@ def test_band_steps_that_do_not_fit_a_byte(mz):
     # pairs in the same call, and give the reference's result
     rng = np.random.default_rng(77)
     pairs = []
-    for M, N, step in ((6, 2000, 300), (9, 3000, 320), (40, 1200, 0)):
+    for M, N, step in ((6, 2000, 300), (9, 3000, 320), (40, 1200, 0), (30, 1500, 40), (64, 2600, 37)):   # raw, raw, nibble, byte, byte steps
         A = inputs.random_block(rng, M, 2, dash=0.05, odd=0.02)
         B = inputs.noisy_copy(rng, A, N, 3, dash=0.05)
         if step:
@@ -676,6 +676,7 @@ def test_band_steps_that_do_not_fit_a_byte(mz):
         assert mo.check(M, N, LB, RB)[0] == 0
         pairs.append((A, B, LB, RB))
     assert max(int(np.diff(p[2]).max()) for p in pairs[:2]) > 255
+    assert all(15 < max(int(np.diff(p[2]).max()), int(np.diff(p[3]).max())) < 256 for p in pairs[3:])
     for kset in (2, 1, 0):
         _kernels(mz, kset)
         res = mz.yama_batch(pairs)
@@ -683,6 +684,38 @@ def test_band_steps_that_do_not_fit_a_byte(mz):
             w = mo.yama(*p)
             assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), (kset, i)
     _kernels(mz, 2)
+
+
+def test_hints_of_another_kernel_selection_are_ignored(mz):
+    # DevBatch derives dp_hint / dp_grid / dp_rows / walk_hint from the plan made when it is built; every run re-plans on
+    # the device under the selection in force THEN.  Built under "wavefront kernels only" and run after the row-parallel
+    # kernels are switched on, the stale hints would launch the wavefront kernels alone while the re-plan hands most
+    # pairs to k_dp_row: traceback never written, status MZ_OK, wrong columns.  The hints carry the selection's
+    # generation (mz_hint_generation) and are dropped when it differs.  (Pairs whose slices no longer fit the
+    # workspaces sized under the old selection -- the transposed pairs need a prep slice -- fail loudly, as before.)
+    from multiz_amd import synth
+    pairs = _random_pairs(4242, 160, kmax=5, mmax=300)
+    batch = synth.pack_pairs(pairs)
+    _kernels(mz, 1)
+    db = mz.DevBatch(batch)                 # workspaces and hints of the wavefront kernels (the larger traceback)
+    stamp = db.c.hint_gen
+    _kernels(mz, 2)
+    db.run()
+    assert mz.lib().mz_hint_generation() != stamp
+    for form in ("serial", "pipelined"):
+        res = db.results()
+        ok = res["status"] == 0
+        assert set(np.unique(res["status"])) <= {0, 19}, np.unique(res["status"])
+        assert int((ok & (res["mode"] == 5)).sum()) >= 20, np.bincount(res["mode"][ok])       # row-parallel pairs that the stale hint would skip
+        host_out = db.out.cpu().numpy()
+        for i, (A, B, LB, RB) in enumerate(pairs):
+            if not ok[i]:
+                continue
+            want = mo.yama(A, B, LB, RB)
+            m_, o0 = int(res["om"][i]), int(res["offOut"][i])
+            assert m_ == want.OM and np.array_equal(host_out[o0: o0 + m_ * (A.shape[1] + B.shape[1])].reshape(m_, -1), want.cols), (form, i, int(res["mode"][i]))
+        db.out.zero_(); db.tbw.zero_()
+        db.run_async(); db.wait()
 
 
 def test_host_batches_are_chunked(tmp_path):
