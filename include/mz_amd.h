@@ -216,24 +216,33 @@ void mz_free_outs(int n, mz_out *outs);
 
 /* ---------------------------------------------------------------- pre_yama() batches: block text in, block text out
  *
- * N independent one-stage merges -- pre_yama(a1, a2, beg, end, radius, v = 1, ...) of reference mz_preyama.c:152-262
- * -- given as the TEXT of the two blocks over their overlap.  Everything between the text and the text happens on
+ * N independent merges -- pre_yama(a1, a2, beg, end, radius, v, ...) of reference mz_preyama.c:152-359: one stage
+ * (v = 1, :152-262) or two (v = 0: the first block's top row sits the first yama() out and is aligned against its
+ * result by a second one whose band comes from mapping(), :265-336, the reference's two defects there included) --
+ * given as the TEXT of the two blocks over their overlap.  Everything between the text and the text happens on
  * the GPU (kernels/prepost.inc around the DP): column packing, removal of all-dash columns (rmColDash), the band from
  * the shared reference row and smooth(), yama() itself, the merged columns back to rows with their base counts and
  * mafScoreRange() of the block that mafBuild() would assemble (rows without a base left out).  The caller keeps
  * what only it knows: names, strands and start coordinates of the rows. */
 typedef struct mz_prejob {
-    int K;                        /* rows of the first block (all of them take part when v = 1)             */
+    int K;                        /* rows of the first block, its top row included (v = 0 needs K >= 2: with
+                                     nothing below the top row pre_yama() returns NULL after writing the second
+                                     block's slice to fpw2, mz_preyama.c:193-196 -- that stays with the caller)    */
     int L1;                       /* rows of the second block INCLUDING its top (reference) row: L = L1 - 1 */
     int M_all, N_all;             /* columns of the two slices (cend - cbeg + 1 of mz_preyama.c:167-172)    */
     int radius;
     const char *const *rows1;     /* K pointers: row r of the first slice is rows1[r][0 .. M_all)           */
     const char *const *rows2;     /* L1 pointers, the reference row first                                   */
+    int v;                        /* 1: one-stage merge; 0: two stages                                      */
 } mz_prejob;
 
 typedef struct mz_preout {
     int status, badrow;           /* as in mz_out (yama()'s own refusals, limits of this build)             */
-    int null_result;              /* 1: pre_yama() returns NULL -- no column of the second block is left    */
+    int null_result;              /* 1: pre_yama() returns NULL -- no column of the second block (v = 0: or of the
+                                     first block's lower rows) is left; 2: v = 0 with K = 1 (see mz_prejob.K);
+                                     3: v = 0 and the two top rows hold different numbers of bases over the
+                                     overlap -- the reference dies of "M3 not equals N3!!" (mz_preyama.c:330)  */
+    int stage;                    /* which yama() call `status` is about (1 or 2)                            */
     int M, N;                     /* yama()'s M and N (after the dash columns went)                         */
     int OM;                       /* columns of the merged block                                            */
     double score;                 /* mafScoreRange(block, 0, OM) over the rows that keep a base             */

@@ -181,25 +181,27 @@ def free_outs(outs: np.ndarray):
 
 class PreJob(C.Structure):
     _fields_ = [("K", C.c_int), ("L1", C.c_int), ("M_all", C.c_int), ("N_all", C.c_int), ("radius", C.c_int),
-                ("rows1", C.POINTER(C.c_char_p)), ("rows2", C.POINTER(C.c_char_p))]
+                ("rows1", C.POINTER(C.c_char_p)), ("rows2", C.POINTER(C.c_char_p)), ("v", C.c_int)]
 
 
 class PreOut(C.Structure):
-    _fields_ = [("status", C.c_int), ("badrow", C.c_int), ("null_result", C.c_int), ("M", C.c_int), ("N", C.c_int),
+    _fields_ = [("status", C.c_int), ("badrow", C.c_int), ("null_result", C.c_int), ("stage", C.c_int), ("M", C.c_int), ("N", C.c_int),
                 ("OM", C.c_int), ("score", C.c_double), ("size", C.POINTER(C.c_int)), ("rows", C.c_void_p)]
 
 
 def preyama_batch(jobs: Sequence[tuple]):
-    """jobs: sequence of (rows1, rows2, radius) -- rows1: the K rows of the first block over the overlap (bytes, equal
-    lengths), rows2: the rows of the second block over the overlap, its top (reference) row first.  One-stage merges
-    (v = 1) through mz_preyama_batch(): text in, text out, everything between on the GPU.  Returns a list of dicts
+    """jobs: sequence of (rows1, rows2, radius[, v]) -- rows1: the K rows of the first block over the overlap (bytes, equal
+    lengths), rows2: the rows of the second block over the overlap, its top (reference) row first; v = 1 (default): one-stage
+    merge, v = 0: two stages.  Through mz_preyama_batch(): text in, text out, everything between on the GPU.  Returns a list of dicts
     (status, null, M, N, OM, score, size, rows) -- rows as a list of bytes."""
     n = len(jobs)
     cj, co, keep = (PreJob * n)(), (PreOut * n)(), []
-    for i, (r1, r2, radius) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        r1, r2, radius = job[:3]
         a1, a2 = (C.c_char_p * len(r1))(*r1), (C.c_char_p * len(r2))(*r2)
         keep += [a1, a2]
         cj[i].K, cj[i].L1, cj[i].M_all, cj[i].N_all, cj[i].radius = len(r1), len(r2), len(r1[0]), len(r2[0]), radius
+        cj[i].v = job[3] if len(job) > 3 else 1
         cj[i].rows1, cj[i].rows2 = a1, a2
     f = lib().mz_preyama_batch
     f.argtypes = [C.c_int, C.POINTER(PreJob), C.POINTER(PreOut)]
@@ -208,7 +210,8 @@ def preyama_batch(jobs: Sequence[tuple]):
     out = []
     for i in range(n):
         o, W = co[i], cj[i].K + cj[i].L1 - 1
-        d = dict(status=o.status, badrow=o.badrow, null=bool(o.null_result), M=o.M, N=o.N, OM=o.OM, score=o.score, size=None, rows=None)
+        d = dict(status=o.status, badrow=o.badrow, null=bool(o.null_result), null_code=o.null_result, stage=o.stage, M=o.M, N=o.N, OM=o.OM,
+                 score=o.score, size=None, rows=None)
         if o.rows:
             d["size"] = [o.size[k] for k in range(W)]
             raw = C.string_at(o.rows, W * o.OM)

@@ -63,7 +63,7 @@ typedef struct mz_ctx {
     gbuf h_in[MZ_SETS], d_in[MZ_SETS], h_exc[MZ_SETS], d_exc[MZ_SETS], d_cols[MZ_SETS], d_band[MZ_SETS], d_plan[MZ_SETS], h_tot[MZ_SETS],
          d_tb[MZ_SETS], d_script[MZ_SETS], d_prep[MZ_SETS], d_res[MZ_SETS], h_res[MZ_SETS];
     gbuf d_out0;                           /* mz_preyama_batch(): merged columns (k_post reads them on the device) */
-    gbuf d_pre[6], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
+    gbuf d_pre[10], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipStream_t ustream[MZ_SETS];          /* and one of high priority for its upload, expansion and plan: a chunk's plan must not queue
                                             * behind the DP waves of the chunks before it (the launcher waits for its totals) */

@@ -29,7 +29,8 @@ int mzk_emit_packed(const mz_dev_batch *b, void *stream);
 /* device side of pre_yama() around the DP (kernels/prepost.inc): all device pointers */
 typedef struct mz_pre_batch {
     int n;
-    const int32_t *K, *L, *Ma, *Na, *rad;
+    const int32_t *K, *L, *Ma, *Na, *rad;      /* K: rows of the first block, its top row included; L: rows of the second below its top row */
+    const int32_t *v;                          /* 1: one-stage merge (all K rows align); 0: two stages (mz_preyama.c:265-336) */
     const int64_t *offT1, *offT2;
     const uint8_t *txt;
     const int64_t *offScr;
@@ -37,12 +38,17 @@ typedef struct mz_pre_batch {
     int32_t *nullres;
 } mz_pre_batch;
 typedef struct mz_post_batch {
+    const int32_t *v;                          /* with only_v1: pairs whose v is 0 are left alone (their block comes from the second stage) */
+    int only_v1;
     uint8_t *rows;
     const int64_t *offRow;
     int32_t *size;
     int64_t *score;
 } mz_post_batch;
 int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
+/* between the two stages of the v == 0 merges: the second yama() job of every such pair of b1 into b2 (same indices;
+ * the other pairs of b2 get M = 0, which the plan refuses) */
+int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream);
 int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream);
 const char *mzk_last_error(void);
 void mzk_release_device(int dev);      /* destroy the launchers' side streams and events of one GPU (mz_finalize) */

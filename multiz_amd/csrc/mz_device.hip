@@ -549,6 +549,13 @@ extern "C" int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *strea
     CK(hipGetLastError(), "pre launch");
     return 0;
 }
+extern "C" int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream)
+{
+    if (q->n <= 0) return 0;
+    hipLaunchKernelGGL(k_mid, dim3(q->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *b1, *b2);
+    CK(hipGetLastError(), "mid launch");
+    return 0;
+}
 extern "C" int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream)
 {
     if (b->n <= 0) return 0;

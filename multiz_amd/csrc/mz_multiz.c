@@ -289,9 +289,16 @@ static struct mafAli *block_from_rows(const mz_preout *o, struct mafAli *a1, int
     return blk;
 }
 
-/* The one-stage merges (v == 1) with everything between block text and block text on the GPU (SURVEY.md 8 f2,
- * mz_preyama_batch()): the host only locates the overlap columns and assembles the result's bookkeeping.  Returns 0
- * when the score tables do not allow it (the caller then takes the host stages for these merges too). */
+/* The merges with everything between block text and block text on the GPU (mz_preyama_batch()): the
+ * one-stage ones (v == 1) and the two-stage ones (v == 0) whose first block has rows below its top row; the host only
+ * locates the overlap columns and assembles the result's bookkeeping.  What the device path does not finish -- a merge
+ * yama() refuses in its second stage, top rows that disagree ("M3 not equals N3!!") -- is left in state 0 for the host
+ * stages, which reproduce the reference's messages.  Returns 0 when the score tables do not allow the device path. */
+static int on_device(const merge *g)
+{
+    return g->v == 1 || (g->v == 0 && g->a1->components->next != NULL);
+}
+
 static int run_merges_device(mref *all, int nmg, int minw, int timing)
 {
     mz_prejob *jobs;
@@ -303,7 +310,7 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
     for (i = 0; i < nmg; ++i) {
         merge *g = &all[i].R->mg[all[i].i];
         struct mafComp *c;
-        if (g->v != 1) continue;
+        if (!on_device(g)) continue;
         ++n;
         for (c = g->a1->components; c; c = c->next) ++nptr;
         for (c = g->a2->components; c; c = c->next) ++nptr;
@@ -319,8 +326,9 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
         struct mafComp *c;
         mz_prejob *j;
         int ce1, ce2;
-        if (g->v != 1) continue;
+        if (!on_device(g)) continue;
         j = &jobs[n];
+        j->v = g->v;
         cb1[n] = mafPos2Col(g->a1->components, g->beg, g->a1->textSize);
         ce1 = mafPos2Col(g->a1->components, g->end, g->a1->textSize);
         cb2[n] = mafPos2Col(g->a2->components, g->beg, g->a2->textSize);
@@ -340,7 +348,8 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
     for (i = 0; i < n; ++i) {
         merge *g = &all[who[i]].R->mg[all[who[i]].i];
         const mz_preout *o = &outs[i];
-        if (o->null_result) { g->state = MZ_PY_DONE; g->result = NULL; continue; }
+        if (o->null_result == 1) { g->state = MZ_PY_DONE; g->result = NULL; continue; }
+        if (o->null_result || (o->status != MZ_OK && g->v == 0)) continue;      /* (state 0: the host stages take it) */
         if (o->status != MZ_OK) {
             /* yama() refused the job: the message names LB / RB entries, so the host builds the job after all (rare) */
             if (mz_py_begin(&g->py, g->a1, g->a2, g->beg, g->end, g->radius, g->v, NULL) != MZ_PY_JOB) { g->state = MZ_PY_DONE; continue; }
@@ -359,7 +368,7 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
         }
         mafAliFree(&g->result);
     }
-    if (timing) fprintf(stderr, "mz_multiz: %d one-stage merges, block text to block text on the GPU %.3f s, blocks assembled and rendered %.3f s\n",
+    if (timing) fprintf(stderr, "mz_multiz: %d merges, block text to block text on the GPU %.3f s, blocks assembled and rendered %.3f s\n",
                         n, t1 - t0, mz_now_s() - t1);
     free(jobs); free(outs); free(who); free(cb1); free(cb2); free(ptrs);
     return 1;
@@ -384,12 +393,11 @@ static void run_merges(record **RR, int nrec, int minw)
         for (i = 0; i < RR[r]->nmg; ++i) { all[nmg].R = RR[r]; all[nmg++].i = i; }
     mz_score_profile_sync();
     for (r = 0; r < nrec; ++r) render_events(RR[r]);
-    /* v == 1: slicing, dash columns, band, yama(), transposition, base counts and score all on the GPU (MZ_HOST_PREP=1
-     * keeps them on the host stages below, as every v == 0 merge is) */
+    /* slicing, dash columns, band, yama() -- both of them when v == 0 --, transposition, base counts and score all on the
+     * GPU (MZ_HOST_PREP=1 keeps every merge on the host stages below) */
     {
         const char *e = getenv("MZ_HOST_PREP");
-        if (!(e && atoi(e) != 0) && run_merges_device(all, nmg, minw, timing))
-            for (i = 0; i < nmg; ++i) { merge *g = &all[i].R->mg[all[i].i]; if (g->v == 1 && g->state == 0) g->state = MZ_PY_DONE; }
+        if (!(e && atoi(e) != 0)) run_merges_device(all, nmg, minw, timing);
     }
     t0 = mz_now_s();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(MZ_STAGE_THREADS) if (nmg > 64)

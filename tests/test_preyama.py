@@ -318,3 +318,77 @@ def test_device_prep_and_post_random_blocks(product):
     j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
     r = m.preyama_batch([j])[0]
     assert r["null"] and r["rows"] is None and mo.pre_yama(a1, a2, beg, end, 30, 1)[0] is None
+
+
+# ------------------------------------------------------------------ two-stage merges (v = 0) on the device
+
+def _v0_job(a1, a2, beg, end, radius):
+    j, cb1, cb2 = _prejob(a1, a2, beg, end, radius)
+    return j + (0,), cb1, cb2
+
+
+@pytest.mark.gpu
+def test_device_two_stage_merges_on_golden_blocks(product):
+    # the 60 reference-generated block pairs as TWO-stage merges (v = 0, mz_preyama.c:265-336): rmColDash of both blocks,
+    # first yama(), mapping() with the reference's two defects, the composed and smoothed band, second yama(), mafBuild
+    # and mafScoreRange -- all on the GPU through mz_preyama_batch().  30 of the golden cases were generated by the
+    # compiled reference with v = 0: those are compared with the reference's own output, all 60 with the oracle.
+    import multiz_amd as m
+    jobs, meta = [], []
+    for g in GOLD:
+        a1, a2 = to_block(g["a1"]), to_block(g["a2"])
+        if len(a1.rows) < 2:
+            continue
+        j, cb1, cb2 = _v0_job(a1, a2, g["beg"], g["end"], g["radius"])
+        jobs.append(j); meta.append((a1, cb1, a2, cb2, g))
+    assert sum(g["v"] == 0 for *_, g in meta) >= 20
+    res = m.preyama_batch(jobs)
+    for r, (a1, cb1, a2, cb2, g) in zip(res, meta):
+        want, _ = mo.pre_yama(a1, a2, g["beg"], g["end"], g["radius"], 0)
+        assert r["status"] == 0 and r["null_code"] in (0, 1)
+        assert same_block(_assemble(r, a1, cb1, a2, cb2), want), g.get("tag")
+        if g["v"] == 0:
+            assert same_block(_assemble(r, a1, cb1, a2, cb2), to_block(g["out"]))       # the reference's own output
+
+
+@pytest.mark.gpu
+def test_device_two_stage_merges_random_blocks(product):
+    # random block pairs as two-stage merges, mixed with one-stage merges in the same call: dash-heavy blocks (columns
+    # removed from EITHER block, which is where the two reference defects of SURVEY appendix A.6 act), rows left without
+    # a base, small radii, long overlaps
+    import multiz_amd as m
+    rng = np.random.default_rng(20)
+    jobs, meta = [], []
+    nv0 = 0
+    while nv0 < 170:
+        n1, n2 = int(rng.integers(2, 9)), int(rng.integers(2, 9))
+        a1, a2, beg, end = inputs.random_block_pair(rng, n1, n2, int(rng.integers(60, 900)))
+        if end - beg < 12:
+            continue
+        R = int(rng.choice([15, 30, 50]))
+        v = 0 if rng.random() < 0.8 else 1
+        try:
+            want, _ = mo.pre_yama(a1, a2, beg, end, R, v)
+        except RuntimeError:
+            continue
+        j, cb1, cb2 = _prejob(a1, a2, beg, end, R)
+        jobs.append(j + (v,)); meta.append((a1, cb1, a2, cb2, want, v))
+        nv0 += v == 0
+    res = m.preyama_batch(jobs)
+    removed_a = 0
+    for r, (a1, cb1, a2, cb2, want, v) in zip(res, meta):
+        assert r["status"] == 0, (r["status"], r["stage"], v)
+        assert same_block(_assemble(r, a1, cb1, a2, cb2), want), v
+        removed_a += v == 0 and r["M"] < len(a1.rows[0].text[cb1:])
+    assert removed_a > 5                                    # rmColDash took columns out of the first block too
+    # the first block has nothing but its top row: pre_yama() returns NULL after writing a2's slice to fpw2 -- code 2, the caller's job
+    a1, a2, beg, end = inputs.random_block_pair(rng, 1, 3, 200)
+    j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
+    r = m.preyama_batch([j + (0,)])[0]
+    assert r["null_code"] == 2 and r["rows"] is None
+    # nothing below the top row of the first block but dashes under the overlap: NULL
+    a1, a2, beg, end = inputs.random_block_pair(rng, 2, 2, 200)
+    a1.rows[1].text = "-" * a1.textSize
+    j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
+    r = m.preyama_batch([j + (0,)])[0]
+    assert r["null_code"] == 1 and mo.pre_yama(a1, a2, beg, end, 30, 0)[0] is None
