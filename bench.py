@@ -35,15 +35,39 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# PMC figures of one launch of the dominant kernel on the DEFAULT c2 batch (50 000 pairs), from the separate rocprofv3
-# --pmc passes summarised in profiles/r2_pmc_summary.txt.  Measured, never estimated; reported only for that batch.
-#   FETCH_SIZE 355 227 KB (coalesced reads: x2 on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE 2 438 500 KB; SQ_INSTS_VALU
-PMC_C2 = {"traffic": (2 * 355176 + 2438497) * 1024, "valu_insts": 2741188179}
 # VALU issue: integer max / dot2 / cndmask / DPP wave-instructions occupy a SIMD for 4 shader cycles on gfx950
 # (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt; v_add/v_sub/v_and: 2-3); 1024 SIMDs.
 VALU_CYCLES = 4.0
 SIMDS = 1024
-CLOCK_GHZ = 2.35          # GRBM_GUI_ACTIVE / 8 / kernel time of the same launch (profiles/r2_pmc_summary.txt)
+
+
+def sources_hash():
+    """what the PMC records are keyed by: the device sources (same function as tests/tools/pmc_collect.py)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "multiz_amd", "csrc")
+    for f in [os.path.join(base, "mz_device.hip")] + sorted(glob.glob(os.path.join(base, "kernels", "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(config, pairs, kernel):
+    """PMC figures of one launch of `kernel` on this config's batch from the newest profiles/r*_pmc.json (collected by
+    tests/tools/pmc_collect.py: separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
+    Measured, never estimated; "stale": the device sources have changed since they were collected."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        r = d.get("records", {}).get(f"{config}:{pairs}", {}).get(kernel)
+        if r and "SQ_INSTS_VALU" in r:
+            return dict(r, source=os.path.relpath(f, ROOT), stale=d.get("sources_hash") != sources_hash())
+    return None
 
 
 def spawn_ranks(args):
@@ -165,6 +189,53 @@ def cpu_leg(spec_path):
                                 f"is {budget} CPUs (cpu.max = {quota_text}): socket_linear extrapolates the measured rate to all {cores} cores"}))
 
 
+# ------------------------------------------------------------------------------------------ one process, N GPUs
+
+def ngpu_mode(args):
+    """`--mode ngpu --gpus N`: ONE process; the library opens N contexts (mz_init_multi) and mz_yama_batch() deals a host
+    list of N x pairs out over them -- contiguous ranges of about equal weight, one host thread and one PCIe link per GPU,
+    no exchange between GPUs (the path mz_multiz / mz_roast take on a node with MZ_NGPU=N).  The rate includes packing,
+    both PCIe directions and the assembly of the merged columns on the host.  MZ_ALLOW_DUP_DEVICES=1 (tests): the N
+    contexts on GPU 0."""
+    import numpy as np
+    from multiz_amd import api, synth
+    cfg = dict(synth.CONFIGS[args.config])
+    pairs = (args.pairs or cfg["pairs"]) * args.gpus
+    dup = os.environ.get("MZ_ALLOW_DUP_DEVICES") == "1"
+    api.init_multi(args.gpus, [0] * args.gpus if dup else None)
+    ngpu = api.lib().mz_device_count()
+    idents = [api.device_identity(i) for i in range(ngpu)]
+    batch = synth.make_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], indel=cfg.get("indel", 0))
+    cells = synth.band_cells(batch)
+    jobs, outs = api.host_jobs(batch)
+    for _ in range(max(1, args.warmup)):
+        api.yama_batch_records(jobs, outs)
+        om = outs["OM"].copy(); ok = bool((outs["status"] == 0).all())
+        api.free_outs(outs)
+    times = []
+    steps = min(args.steps, 10)
+    for _ in range(steps):
+        t = time.perf_counter()
+        api.yama_batch_records(jobs, outs)
+        times.append(time.perf_counter() - t)
+        assert np.array_equal(outs["OM"], om)
+        api.free_outs(outs)
+    if not ok:
+        raise SystemExit("block pairs failed on the device -- number void")
+    link = api.link_bytes(jobs)
+    t_med = float(np.median(times))
+    print(json.dumps({
+        "metric": "GCUPS (DP cell updates/s) on yama block-pair merge", "mode": "ngpu",
+        "value": round(cells / t_med / 1e9, 2), "unit": "GCUPS", "n_gpus": ngpu, "steps": steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(1e3 * t_med, 3), "ms_all": [round(1e3 * x, 2) for x in times], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": synth.describe(args.config, pairs // args.gpus), "pairs_total": pairs, "band_cells_total": cells,
+                   "parallelism": f"one process, mz_init_multi({ngpu}): a host list dealt over {ngpu} GPU contexts, one host thread and "
+                                  f"one PCIe link each (host buffers in, merged columns out: transfers included)"},
+        "devices": idents, "distinct_devices": len(set(idents)),
+        "link_bytes_per_pair": {"up": round(link[0] / pairs, 1), "down": round(link[1] / pairs, 1)}}))
+
+
 # ------------------------------------------------------------------------------------------ main
 
 def algorithmic_bytes(batch, om):
@@ -189,10 +260,15 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) column")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 builds the whole list and deals it out (multiz_amd.shard)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "ngpu"],
+                    help="ranks: one process per GPU (torch.distributed, the scaling measurement); ngpu: ONE process, the C path "
+                         "mz_init_multi(N) + mz_yama_batch() over a host list of N x pairs -- what mz_multiz / mz_roast use on a node")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg:
         return cpu_leg(args.cpu_leg)
+    if args.mode == "ngpu":
+        return ngpu_mode(args)
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -320,6 +396,7 @@ def main():
     db.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     workspaces = ring[:min(nws, args.warmup + args.steps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
@@ -341,7 +418,6 @@ def main():
     gcups = all_cells * args.steps / elapsed / 1e9
     dp_ms = float(kern_ms[1])
     roof_achieved = total_bytes / (dp_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes over the DP kernel's time
-    default_batch = args.config == "c2" and pairs == 50000 and not args.scatter
     modes = np.bincount(res["mode"], minlength=13)
     # the DP kernel that took most of the batch's pairs: the row-parallel one (k_dp_row_big when the batch has blocks of four
     # rows or more), the lagged one, or the wavefront fallbacks
@@ -368,16 +444,39 @@ def main():
         # against the integer VALU issue roof (instructions x 4 cycles / (1024 SIMDs x 2.4 GHz)).
         "roofline": {"bound": "hbm", "kernel": dominant_kernel, "achieved": round(roof_achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(roof_achieved / HBM_PEAK_GBS, 5),
-                     "traffic": PMC_C2["traffic"] if default_batch else None,
+                     "traffic": None,
                      "bytes_per_cell": round(total_bytes / cells, 4), "algorithmic_bytes": total_bytes,
-                     "dp_kernel_gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1),
-                     "valu": ({"insts_per_launch": PMC_C2["valu_insts"], "cycles_per_inst": VALU_CYCLES, "simds": SIMDS,
-                               "clock_ghz": CLOCK_GHZ,
-                               "frac": round(PMC_C2["valu_insts"] * VALU_CYCLES / (SIMDS * CLOCK_GHZ * 1e9 * dp_ms * 1e-3), 4)}
-                              if default_batch else None)},
+                     "dp_kernel_gcups": round(cells / (dp_ms * 1e-3) / 1e9, 1), "valu": None},
     }
+    pmc = pmc_record(args.config, pairs, dominant_kernel) if not args.scatter else None
+    if pmc:
+        clock = pmc.get("clock_ghz") or 2.35
+        out["roofline"]["traffic"] = pmc.get("traffic_bytes")
+        out["roofline"]["valu"] = {"insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES, "simds": SIMDS, "clock_ghz": clock,
+                                   "frac": round(pmc["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * clock * 1e9 * dp_ms * 1e-3), 4)}
+        out["roofline"]["pmc"] = {"source": pmc["source"], "stale": pmc["stale"], "kernel_avg_ms_in_stats_run": round(pmc.get("avg_ns", 0) / 1e6, 3)}
     if exchange:
         out["exchange"] = exchange
+    if world > 1:
+        # What makes a first multi-GPU run self-verifying: which physical device every rank held (PCI bus id + name from the
+        # library's own context), every rank's own rate, and the spread.  distinct_devices < n_gpus means ranks shared a GPU
+        # (the MZ_BENCH_SHARE_GPU development switch) and the number is NOT a scaling measurement.
+        ident = api.device_identity(0).encode()[:127]
+        mine = torch.zeros(128, dtype=torch.uint8)
+        mine[: len(ident)] = torch.tensor(list(ident), dtype=torch.uint8)
+        mine = mine.to(red)
+        all_id = [torch.zeros(128, dtype=torch.uint8, device=red) for _ in range(world)]
+        dist.all_gather(all_id, mine)
+        mine_rate = torch.tensor([cells * args.steps / max(elapsed_local, 1e-9) / 1e9, float(cells)], dtype=torch.float64, device=red)
+        all_rate = [torch.zeros(2, dtype=torch.float64, device=red) for _ in range(world)]
+        dist.all_gather(all_rate, mine_rate)
+        idents = [bytes(t.cpu().tolist()).rstrip(b"\0").decode() for t in all_id]
+        rates = [round(float(t[0].item()), 2) for t in all_rate]
+        out["devices"] = idents
+        out["distinct_devices"] = len(set(idents))
+        out["per_rank_gcups"] = rates
+        out["rank_max_over_min"] = round(max(rates) / max(min(rates), 1e-9), 3)
+        out["backend"] = "gloo (ranks share GPU 0: development switch, not a scaling measurement)" if share else "nccl (RCCL)"
 
     # ---- the first column of SURVEY 8(d): host buffers in, malloc()ed merged columns out, through mz_yama_batch()
     # (pack, H2D, kernels, D2H, unpack; chunks pipelined four deep).  N = 1 only: it measures one GPU's PCIe link.

@@ -163,6 +163,8 @@ int  mz_init(int device);
  * the drivers mz_multiz / mz_multic use a whole node. */
 int  mz_init_multi(int ngpu, const int *devices);
 int  mz_device_count(void);               /* GPUs the library is running on (0 before initialisation) */
+/* "<PCI bus id> <device name>" of the GPU context ctx (0 .. mz_device_count()-1) runs on; 0, or -1 */
+int  mz_device_identity(int ctx, char *buf, int len);
 void mz_finalize(void);
 const char *mz_last_error(void);
 /* the hipStream_t the library launches on (for callers that time with HIP events) */

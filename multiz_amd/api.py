@@ -90,6 +90,22 @@ def init(device: int = 0):
     _check(lib().mz_init(device), "mz_init")
 
 
+def init_multi(ngpu: int, devices: Optional[Sequence[int]] = None):
+    """several GPUs in ONE process (mz_init_multi): mz_yama_batch() then deals a host list out over them"""
+    f = lib().mz_init_multi
+    f.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    arr = (C.c_int * ngpu)(*devices) if devices is not None else None
+    _check(f(ngpu, arr), "mz_init_multi")
+
+
+def device_identity(ctx: int = 0) -> str:
+    """'<PCI bus id> <device name>' of the GPU a context runs on"""
+    buf = C.create_string_buffer(256)
+    f = lib().mz_device_identity
+    f.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    return buf.value.decode() if f(ctx, buf, 256) == 0 else "?"
+
+
 def set_scores_hoxd70():
     lib().init_scores70()
 

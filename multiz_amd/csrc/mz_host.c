@@ -192,6 +192,19 @@ int mz_init_multi(int ngpu, const int *devices)
 
 int mz_device_count(void) { return g_ndev; }
 
+/* which physical GPU context `ctx` (0 .. mz_device_count()-1) runs on: "<PCI bus id> <device name>" -- what a multi-GPU
+ * bench line prints per rank so that N ranks provably sat on N distinct devices */
+int mz_device_identity(int ctx, char *buf, int len)
+{
+    char pci[64] = "?";
+    hipDeviceProp_t prop;
+    if (ctx < 0 || ctx >= g_ndev || !buf || len < 2) return -1;
+    if (hipDeviceGetPCIBusId(pci, (int)sizeof pci, g_dev[ctx].device) != hipSuccess) snprintf(pci, sizeof pci, "device%d", g_dev[ctx].device);
+    if (hipGetDeviceProperties(&prop, g_dev[ctx].device) != hipSuccess) prop.name[0] = 0;
+    snprintf(buf, (size_t)len, "%s %s", pci, prop.name);
+    return 0;
+}
+
 /* helper streams at normal priority (measured: lowest priority starves them behind the DP and costs 4 % of the
  * pipelined rate, highest gains nothing); MZ_HELPER_PRIO overrides for experiments */
 int mzi_lazy_stream(hipStream_t *s)

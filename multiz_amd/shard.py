@@ -182,13 +182,28 @@ def gather_results(res: dict, my_idx: np.ndarray, n_total: int, widths: Optional
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
     sh = Sharded(n_total, widths)
-    for r, (om, st, off, idx, out) in bufs.items():
-        i = idx.cpu().numpy()
-        sh.om[i] = om.cpu().numpy()
-        sh.status[i] = st.cpu().numpy()
-        sh.off[i] = off.cpu().numpy()
+    # every rank's buffers to the host: pinned destinations, all copies issued before the one synchronisation (the DMA
+    # engine streams them back to back at link rate; a .cpu() per tensor went through pageable staging, one at a time)
+    on_gpu = any(t.is_cuda for b in bufs.values() for t in b)
+    host = {}
+    for r, b in bufs.items():
+        if on_gpu:
+            dst = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in b)
+            for d_, t in zip(dst, b):
+                d_.copy_(t, non_blocking=True)
+            host[r] = dst
+        else:
+            host[r] = b
+    if on_gpu:
+        torch.cuda.synchronize()
+    for r, (om, st, off, idx, out) in host.items():
+        i = idx.numpy()
+        sh.om[i] = om.numpy()
+        sh.status[i] = st.numpy()
+        sh.off[i] = off.numpy()
         sh.owner[i] = r
-        sh.bufs[r] = out.cpu().numpy()
+        sh.bufs[r] = out.numpy()
+    sh._keep = host                                          # (the numpy views live in these tensors)
     return sh
 
 

@@ -105,8 +105,25 @@ def test_bench_two_ranks_on_one_gpu(extra):
     line = [l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == 6000 and d["value"] > 0
+    # the self-verifying part of a multi-GPU line: which device every rank held, every rank's own rate, the spread
+    assert len(d["devices"]) == 2 and d["distinct_devices"] == 1 and "gloo" in d["backend"]      # (both ranks on GPU 0 here)
+    assert len(d["per_rank_gcups"]) == 2 and min(d["per_rank_gcups"]) > 0 and d["rank_max_over_min"] >= 1.0
     if extra:
         assert d["exchange"]["ranks_used"] == 2 and "RCCL" in d["config"]["parallelism"]
+
+
+def test_bench_one_process_two_contexts():
+    # `--mode ngpu`: the C path (mz_init_multi + mz_yama_batch over a host list) that mz_multiz / mz_roast use on a node;
+    # two contexts on GPU 0 here (MZ_ALLOW_DUP_DEVICES=1)
+    env = dict(os.environ, MZ_ALLOW_DUP_DEVICES="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--mode", "ngpu", "--gpus", "2", "--config", "c4", "--pairs", "6000", "--steps", "3", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1])
+    assert d["mode"] == "ngpu" and d["n_gpus"] == 2 and d["config"]["pairs_total"] == 12000 and d["value"] > 0
+    assert len(d["devices"]) == 2 and d["distinct_devices"] == 1 and d["link_bytes_per_pair"]["up"] > 0
 
 
 def test_bench_refuses_a_mismatched_world():

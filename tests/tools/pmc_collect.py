@@ -1,0 +1,92 @@
+"""rocprofv3 kernel stats and PMC counters of bench.py's kernels, as a machine-readable record.
+
+    python tests/tools/pmc_collect.py <tag> <config> [<config> ...]        (on the GPU box; writes under gpurun_out/<tag>/)
+
+Per config: `rocprofv3 --kernel-trace --stats -- python3 bench.py --config <cfg> --steps 20 --warmup 3 --no-cpu --no-host`
+(MZ_DP_STREAMS=1: the DPs of consecutive steps back to back, so that a launch's duration is its own) and one
+`rocprofv3 --kernel-trace --pmc <group>` run per counter group, in separate passes as MI355X_MICROARCH.md prescribes
+(FETCH_SIZE and WRITE_SIZE cannot share one; never together with a trace domain beyond --kernel-trace).
+
+Output: <tag>_kernel_stats_<cfg>.csv (rocprofv3's own summary), <tag>_pmc.json --
+    {"sources_hash": sha256 of multiz_amd/csrc/mz_device.hip + kernels/*.inc  (what bench.py checks: "stale" when it differs),
+     "records": {"<cfg>:<pairs>": {"<kernel>": {"avg_ns", "calls", "SQ_INSTS_VALU", ..., "FETCH_SIZE_KB", "WRITE_SIZE_KB",
+                                               "traffic_bytes": (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (gfx950: FETCH_SIZE reports
+                                               half of a wide coalesced read), "clock_ghz": GRBM_GUI_ACTIVE / 8 XCDs / avg_ns}}}}
+Never starts the profiled program through a shell or env wrapper: the profiler's preloaded library initialises the GPU,
+and an exec after that takes the node down (see the round's environment notes)."""
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GROUPS = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM",
+          "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"]
+
+
+def sources_hash() -> str:
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "multiz_amd", "csrc")
+    for f in [os.path.join(base, "mz_device.hip")] + sorted(glob.glob(os.path.join(base, "kernels", "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run(cmd, env):
+    subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+
+
+def main():
+    tag, configs = sys.argv[1], sys.argv[2:]
+    out = os.path.join(ROOT, "gpurun_out", tag)
+    os.makedirs(out, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp", MZ_DP_STREAMS="1")
+    sys.path.insert(0, ROOT)
+    from multiz_amd import synth
+    rec = {"sources_hash": sources_hash(), "records": {}}
+    for cfg in configs:
+        pairs = synth.CONFIGS[cfg]["pairs"]
+        key = f"{cfg}:{pairs}"
+        k = collections.defaultdict(dict)
+        d = os.path.join(out, f"stats_{cfg}")
+        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
+             "python3", "bench.py", "--config", cfg, "--steps", "20", "--warmup", "3", "--no-cpu", "--no-host"], env)
+        fs = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
+        if fs:
+            os.replace(fs[0], os.path.join(out, f"{tag}_kernel_stats_{cfg}.csv"))
+            for row in csv.DictReader(open(os.path.join(out, f"{tag}_kernel_stats_{cfg}.csv"))):
+                name = row["Name"].split("(")[0]
+                if name.startswith("k_"):
+                    k[name]["avg_ns"] = float(row["AverageNs"]); k[name]["calls"] = int(row["Calls"])
+                    k[name]["min_ns"] = float(row["MinNs"]); k[name]["max_ns"] = float(row["MaxNs"])
+        for g in GROUPS:
+            d = os.path.join(out, f"pmc_{cfg}_" + g.replace(" ", "_")[:40])
+            run(["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["--output-format", "csv", "-d", d, "--",
+                 "python3", "bench.py", "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host"], env)
+            fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if not fs:
+                continue
+            acc, cnt = collections.defaultdict(float), collections.Counter()
+            for row in csv.DictReader(open(fs[0])):
+                kk = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+                acc[kk] += float(row["Counter_Value"]); cnt[kk] += 1
+            for (name, counter), v in acc.items():
+                if name.startswith("k_"):
+                    k[name][counter + ("_KB" if counter in ("FETCH_SIZE", "WRITE_SIZE") else "")] = round(v / cnt[(name, counter)])
+        for name, r in k.items():
+            if "FETCH_SIZE_KB" in r and "WRITE_SIZE_KB" in r:
+                r["traffic_bytes"] = (2 * r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]) * 1024
+            if "GRBM_GUI_ACTIVE" in r and "avg_ns" in r:
+                r["clock_ghz"] = round(r["GRBM_GUI_ACTIVE"] / 8.0 / r["avg_ns"], 3)
+        rec["records"][key] = dict(k)
+        json.dump(rec, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+        print(key, {n: {c: v for c, v in r.items() if c in ("avg_ns", "SQ_INSTS_VALU", "traffic_bytes", "clock_ghz")} for n, r in k.items() if n.startswith("k_dp")})
+
+
+if __name__ == "__main__":
+    main()
