@@ -51,6 +51,7 @@ int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
 int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream);
 int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream);
 const char *mzk_last_error(void);
+void mzk_set_abreast(int k);           /* DPs of k consecutive batches run side by side (kernel choice of mzk_dp_range) */
 void mzk_release_device(int dev);      /* destroy the launchers' side streams and events of one GPU (mz_finalize) */
 #ifdef __cplusplus
 }

@@ -383,6 +383,11 @@ extern "C" void mzk_release_device(int dev)
     if (have) (void)hipSetDevice(cur);
 }
 
+// how many batches' DPs the caller runs side by side (mz_dev_run_async): what counts for the choice of the
+// latency-tolerant row kernel is the waves on the GPU, not the blocks of one launch
+static int g_abreast = 1;
+extern "C" void mzk_set_abreast(int k) { g_abreast = k < 1 ? 1 : k; }
+
 extern "C" int mz_dp_hint(int n, const int64_t *totals)
 {
     const long long failed = totals[3], wf = totals[5] & 0xffffffffLL, rowbig = totals[5] >> 32, wide = totals[8] & 0xffffffffLL, lag = totals[8] >> 32;
@@ -429,6 +434,8 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (count <= 0) return 0;
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
+    static int lat_max = -1;                      // MZ_LAT_MAX=<waves>: launches that leave the GPU at most that many row-parallel waves take k_dp_row_lat (0: never)
+    if (lat_max < 0) { const char *e = getenv("MZ_LAT_MAX"); lat_max = e ? atoi(e) : 2048; }
     static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
     if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
     hipStream_t main_s = (hipStream_t)stream;
@@ -463,8 +470,14 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         hipStream_t s = main_s;
         if (side) { s = S->s[used]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
         // (the row kernels: a block per pair of the batch, or -- whole batch, counts known -- per entry of the plan's list)
-        if (kinds[i] == MZ_DP_ROW)
-            hipLaunchKernelGGL(k_dp_row, dim3(rows_listed ? b->dp_rows : count), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
+        if (kinds[i] == MZ_DP_ROW) {
+            // few pairs -- a wave or two per SIMD, nothing to hide a latency behind: the latency-tolerant build (kernels/row.inc)
+            const int blocks = rows_listed ? b->dp_rows : count;
+            if ((long long)blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
+                hipLaunchKernelGGL(k_dp_row_lat, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
+            else
+                hipLaunchKernelGGL(k_dp_row, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
+        }
         else if (kinds[i] == MZ_DP_ROWBIG)
             hipLaunchKernelGGL(k_dp_row_big, dim3(rows_listed ? b->dp_rows : count), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 2);
         // (the counter kernels: no more waves than pairs -- a wave that finds the counter exhausted still had to wait for

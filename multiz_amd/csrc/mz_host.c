@@ -509,7 +509,7 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
 {
     hipStream_t s;
     mz_dev_batch tmp;
-    int w, slot = -1;
+    int w, slot = -1, rc_dp;
     if (mzi_ensure_init() || mzi_sync_scores() || mzi_lazy_stream(&G.stream2) || mzi_lazy_stream(&G.stream3)) return -1;
     b = checked_hints(b, &tmp);
     s = (hipStream_t)pick_stream(stream);
@@ -555,7 +555,10 @@ int mz_dev_run_async(const mz_dev_batch *b, void *stream, void *ready_event)
             }
         }
         HIPCK(hipStreamWaitEvent(sd, G.evs[3], 0));
-        if (mzk_dp(b, sd)) return mzi_set_err("%s", mzk_last_error());
+        mzk_set_abreast(depth);
+        rc_dp = mzk_dp(b, sd);
+        mzk_set_abreast(1);
+        if (rc_dp) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(G.evs[2], sd));
     }
     HIPCK(hipStreamWaitEvent(G.stream2, G.evs[2], 0));
