@@ -740,3 +740,55 @@ void mz_free_outs(int n, mz_out *outs)
     int p;
     for (p = 0; p < n; ++p) { mzi_block_put(outs[p].block); outs[p].block = NULL; outs[p].cols = NULL; }
 }
+
+/* ------------------------------------------------------------------------------------------------ host-side probe
+ * tests/tools/hostprobe.py: what the packing of a chunk costs on this machine's host threads, without a GPU in the
+ * loop -- the same pack_range() over the same jobs into an ordinary (not pinned) staging block, `reps` times; returns
+ * seconds per repetition, or -1.  what: 1 = everything, 2 = column classes only, 3 = band steps only. */
+typedef struct probe_ctx { pack_ctx pc; int what; } probe_ctx;
+static void probe_range(void *ctx, int lo, int hi)
+{
+    const probe_ctx *P = (const probe_ctx *)ctx;
+    const pack_ctx *q = &P->pc;
+    int p;
+    if (P->what == 1) { pack_range((void *)q, lo, hi); return; }
+    for (p = lo; p < hi; ++p) {
+        const mz_job *j = &q->jobs[p];
+        if (!job_ok(j)) continue;
+        if (P->what == 2) {
+            mz_pack_classes_stream(j->A, (size_t)j->K * j->M, q->hA + q->hoA[p] / 2, cols_padded(j->K, j->M) / 2);
+            mz_pack_classes_stream(j->B, (size_t)j->L * j->N, q->hB + q->hoB[p] / 2, cols_padded(j->L, j->N) / 2);
+        } else {
+            mz_pack_band_nib_stream(j->LB, j->RB, j->M, q->hC + q->hoC[p], band_slot(j->M));
+        }
+    }
+    _mm_sfence();
+}
+double mz_host_pack_probe(int n, const mz_job *jobs, int what, int reps)
+{
+    size_t eA = 0, eB = 0, bytesC = 0, oa = 0, ob = 0, oc = 0;
+    int64_t *hoA, *hoB, *hoC;
+    uint8_t *buf, *fmt;
+    uint32_t *esz;
+    probe_ctx P;
+    double t0;
+    int p, r;
+    for (p = 0; p < n; ++p) if (job_ok(&jobs[p])) { eA += cols_padded(jobs[p].K, jobs[p].M); eB += cols_padded(jobs[p].L, jobs[p].N); bytesC += band_slot(jobs[p].M); }
+    hoA = (int64_t *)malloc(3 * ((size_t)n + 1) * sizeof *hoA); hoB = hoA + n + 1; hoC = hoB + n + 1;
+    buf = (uint8_t *)aligned_alloc(256, mzi_al256(eA / 2) + mzi_al256(eB / 2) + mzi_al256(bytesC) + 256);
+    fmt = (uint8_t *)malloc((size_t)n + 1); esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *esz);
+    if (!hoA || !buf || !fmt || !esz) return -1.0;
+    for (p = 0; p < n; ++p) {
+        hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoC[p] = (int64_t)oc;
+        if (job_ok(&jobs[p])) { oa += cols_padded(jobs[p].K, jobs[p].M); ob += cols_padded(jobs[p].L, jobs[p].N); oc += band_slot(jobs[p].M); }
+    }
+    P.what = what;
+    P.pc.jobs = jobs; P.pc.hoA = hoA; P.pc.hoB = hoB; P.pc.hoC = hoC; P.pc.hFmt = fmt; P.pc.esz = esz; P.pc.hE = NULL;
+    P.pc.hC = buf; P.pc.hA = buf + mzi_al256(bytesC); P.pc.hB = P.pc.hA + mzi_al256(eA / 2);
+    mzi_parallel_for(n, pack_grain(n), probe_range, &P);             /* warm: pages, pool */
+    t0 = mzi_now_s();
+    for (r = 0; r < reps; ++r) mzi_parallel_for(n, pack_grain(n), probe_range, &P);
+    t0 = (mzi_now_s() - t0) / (reps > 0 ? reps : 1);
+    free(hoA); free(buf); free(fmt); free(esz);
+    return t0;
+}

@@ -21,49 +21,43 @@
  * until the replay.  They are never resized or freed one by one: they come from a bump arena that is released as
  * a whole (thirty malloc/free pairs per merge otherwise -- a sixth of a 20 000-block run). */
 typedef struct arena_chunk { struct arena_chunk *next; size_t used, cap; } arena_chunk;
-static arena_chunk *g_arena;
-
-static void *arena_alloc(size_t n)
+/* one arena per record (a run's list walk): the tree driver walks the lists of sibling nodes on several threads */
+static void *arena_alloc(arena_chunk **arena, size_t n)
 {
-    void *p;
+    char *p;
     n = (n + 15) & ~(size_t)15;
-    if (!g_arena || g_arena->used + n > g_arena->cap) {
-        const size_t cap = n > ((size_t)8 << 20) ? n : ((size_t)8 << 20);
+    if (!*arena || (*arena)->used + n > (*arena)->cap) {
+        const size_t cap = n > ((size_t)1 << 20) ? n : ((size_t)1 << 20);
         arena_chunk *c = (arena_chunk *)mz_xmalloc(sizeof *c + cap);
-        c->next = g_arena; c->used = 0; c->cap = cap;
-        g_arena = c;
+        c->next = *arena; c->used = 0; c->cap = cap;
+        *arena = c;
     }
-    p = (char *)(g_arena + 1) + g_arena->used;
-    g_arena->used += n;
+    p = (char *)(*arena + 1) + (*arena)->used;
+    (*arena)->used += n;
     return p;
 }
-static char *arena_strdup(const char *s)
+static char *arena_strdup(arena_chunk **arena, const char *s)
 {
-    size_t n;
-    if (!s) return NULL;
-    n = strlen(s) + 1;
-    return (char *)memcpy(arena_alloc(n), s, n);
+    const size_t n = strlen(s) + 1;
+    return (char *)memcpy(arena_alloc(arena, n), s, n);
 }
-static int g_arena_users;                 /* records alive: several runs may be pending at once (the tree driver) */
-static void arena_release(void)
+static void arena_release(arena_chunk **arena)
 {
-    if (--g_arena_users > 0) return;
-    g_arena_users = 0;
-    while (g_arena) { arena_chunk *c = g_arena; g_arena = c->next; free(c); }
+    while (*arena) { arena_chunk *c = *arena; *arena = c->next; free(c); }
 }
 
-static struct mafAli *clone_ali(const struct mafAli *a)      /* arena-owned: never passed to mafAliFree() */
+static struct mafAli *clone_ali(arena_chunk **arena, const struct mafAli *a)      /* arena-owned: never passed to mafAliFree() */
 {
-    struct mafAli *b = (struct mafAli *)arena_alloc(sizeof *b);
+    struct mafAli *b = (struct mafAli *)arena_alloc(arena, sizeof *b);
     struct mafComp *c, *tail = NULL;
     *b = *a;
     b->next = NULL; b->components = NULL;
     for (c = a->components; c; c = c->next) {
-        struct mafComp *d = (struct mafComp *)arena_alloc(sizeof *d);
+        struct mafComp *d = (struct mafComp *)arena_alloc(arena, sizeof *d);
         *d = *c;
         d->next = NULL; d->mafPosMap = NULL;
-        d->src = arena_strdup(c->src); d->name = arena_strdup(c->name); d->contig = arena_strdup(c->contig);
-        d->text = arena_strdup(c->text);
+        d->src = arena_strdup(arena, c->src); d->name = arena_strdup(arena, c->name); d->contig = arena_strdup(arena, c->contig);
+        d->text = arena_strdup(arena, c->text);
         if (tail) tail->next = d; else b->components = d;
         tail = d;
     }
@@ -123,6 +117,7 @@ typedef struct {
     event *ev; int nev, capev;
     merge *mg; int nmg, capmg;
     int has1, has2;           /* out1 / out2 sinks exist */
+    arena_chunk *arena;       /* the private block copies of this run's events and merges */
 } record;
 
 static event *new_event(record *R, int sink)
@@ -139,12 +134,12 @@ static event *new_event(record *R, int sink)
 static void rec_block(record *R, int sink, struct mafAli *a)
 {
     event *e = new_event(R, sink);
-    e->src = clone_ali(a); e->cbeg = -1; e->cend = -1;
+    e->src = clone_ali(&R->arena, a); e->cbeg = -1; e->cend = -1;
 }
 static void rec_part(record *R, int sink, struct mafAli *a, int cbeg, int cend)
 {
     event *e = new_event(R, sink);
-    e->src = clone_ali(a); e->cbeg = cbeg; e->cend = cend;
+    e->src = clone_ali(&R->arena, a); e->cbeg = cbeg; e->cend = cend;
 }
 static void render_events(record *R)
 {
@@ -170,7 +165,7 @@ static void rec_merge(record *R, struct mafAli *a1, struct mafAli *a2, int beg, 
     if (R->nmg == R->capmg) { R->capmg = R->capmg ? 2 * R->capmg : 256; R->mg = (merge *)realloc(R->mg, (size_t)R->capmg * sizeof(merge)); if (!R->mg) mz_fatalf("out of memory"); }
     g = &R->mg[R->nmg];
     memset(g, 0, sizeof *g);
-    g->a1 = clone_ali(a1); g->a2 = clone_ali(a2);
+    g->a1 = clone_ali(&R->arena, a1); g->a2 = clone_ali(&R->arena, a2);
     g->beg = beg; g->end = end; g->radius = radius; g->v = v;
     /* stage 1 (run_merges) may write to out2 -- nothing of a1 left to align, mz_preyama.c:193-196 -- and that
      * text belongs at this point of the output */
@@ -474,8 +469,8 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
         }
     }
     free(R->ev); free(R->mg);
+    arena_release(&R->arena);
     memset(R, 0, sizeof *R);
-    arena_release();
 }
 
 /* A multiz run in three steps, so that several independent runs can share their GPU batches:
@@ -492,7 +487,6 @@ struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2,
     memset(run, 0, sizeof *run);
     run->minw = min_output_wid;
     run->R.has1 = has_out1; run->R.has2 = has_out2;
-    ++g_arena_users;
     while (*list1 && *list2) {                              /* one reference contig at a time, in file-1 order */
         struct mafAli *wk1 = NULL, *wk2 = NULL;
         char *chr = mz_xstrdup((*list1)->components->src);

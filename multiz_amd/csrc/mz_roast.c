@@ -196,11 +196,14 @@ static int is_single(const rnode *n, const char *name) { return n->nnames == 1 &
  * (speciesTree.c:78-90 around mz_merge(), auto_mz.c:52-118).  begin_node() does everything up to the aligner; when
  * that is multiz the run is left prepared (nd->run) for the shared batch, and end_node() finishes the node. */
 
-static void begin_node(rnode *nd)
+/* begin_node() in three steps, so that a round's nodes go through each step side by side:
+ *   node_inputs()   (serial: buffers change hands, leaf files are read, the stock driver's messages keep their order)
+ *   node_parse()    (a task per node and side: MAF text -> blocks -> projected list)
+ *   node_prepare()  (a task per node: the list walk of mz_multiz_prepare -- its record has its own arena) */
+static void node_inputs(rnode *nd)
 {
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
     buf left = { NULL, 0, 0 }, right = { NULL, 0, 0 };
-    int l, r;
 
     if (x->id >= 0) { left = x->mz; x->mz.p = NULL; x->mz.n = x->mz.cap = 0; }          /* mv MZ<i> left.maf<id> */
     if (y->id >= 0) { right = y->mz; y->mz.p = NULL; y->mz.n = y->mz.cap = 0; }
@@ -223,29 +226,30 @@ static void begin_node(rnode *nd)
     }
     if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); }
     if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); }
-    /* maf_project left REF > U1; mv U1 left (and the same on the right), then the aligner reads both: the projected
-     * blocks go on as lists -- what the stock chain's write-and-read-again would re-derive (sizes, text lengths, scores
-     * with one decimal: printing a score twice gives what printing it once gives) is already in them -- and the two
-     * sides are parsed and projected on two threads */
     if (!left.p) mz_fatalf("Cannot open %s.", "left.maf");
     if (!right.p) mz_fatalf("Cannot open %s.", "right.maf");
-    {
-        const double t_ = mz_now_s();
-#pragma omp parallel sections num_threads(2)
-        {
-#pragma omp section
-            nd->l1 = mz_project_lists(mz_maf_read_mem(left.p, left.n, "left.maf"), T.ref, NULL);
-#pragma omp section
-            nd->l2 = mz_project_lists(mz_maf_read_mem(right.p, right.n, "right.maf"), T.ref, NULL);
-        }
-        g_t[2] += mz_now_s() - t_;
-    }
-    buf_free(&left); buf_free(&right);
-    l = has_ref(x); r = has_ref(y);
+    nd->left_in = left; nd->right_in = right;
+}
+
+/* maf_project left REF > U1; mv U1 left (and the same on the right), then the aligner reads both: the projected
+ * blocks go on as lists -- what the stock chain's write-and-read-again would re-derive (sizes, text lengths, scores
+ * with one decimal: printing a score twice gives what printing it once gives) is already in them */
+static void node_parse(rnode *nd, int side)
+{
+    buf *in = side ? &nd->right_in : &nd->left_in;
+    struct mafAli *l = mz_project_lists(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
+    if (side) nd->l2 = l; else nd->l1 = l;
+    buf_free(in);
+}
+
+static void node_prepare(rnode *nd)
+{
+    rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
+    const int l = has_ref(x), r = has_ref(y);
     if (!l && !r) nd->both_leaves = x->nnames == 1 && y->nnames == 1;
     else if (r) { struct mafAli *t = nd->l1; nd->l1 = nd->l2; nd->l2 = t; }
     if (!T.use_multic)
-        TIMED(3, nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1));
+        nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
 }
 
 static void end_node(rnode *nd)
@@ -371,12 +375,33 @@ int mz_roast_main(int argc, char **argv)
             if (nd->id >= 0 && !nd->done && T.nd[nd->left].done && T.nd[nd->right].done) ready[nready++] = i;
         }
         if (nready == 0) break;
-        for (i = 0; i < nready; ++i) {
-            begin_node(&T.nd[ready[i]]);
-            if (T.nd[ready[i]].run) runs[nruns++] = T.nd[ready[i]].run;
+        {
+            int todo[MAX_NODES], ntodo = 0, k;
+            for (i = 0; i < nready; ++i) {
+                node_inputs(&T.nd[ready[i]]);
+                if (!T.nd[ready[i]].done) todo[ntodo++] = ready[i];
+            }
+            /* the round's inputs parsed and projected, a task per node and side; then the list walks, a task per node */
+            { const double t_ = mz_now_s();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 0)
+              for (k = 0; k < 2 * ntodo; ++k) node_parse(&T.nd[todo[k >> 1]], k & 1);
+              g_t[2] += mz_now_s() - t_; }
+            { const double t_ = mz_now_s();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 1)
+              for (k = 0; k < ntodo; ++k) node_prepare(&T.nd[todo[k]]);
+              g_t[3] += mz_now_s() - t_; }
+            for (k = 0; k < ntodo; ++k) if (T.nd[todo[k]].run) runs[nruns++] = T.nd[todo[k]].run;
         }
         if (nruns) { TIMED(4, mz_multiz_align(runs, nruns)); ++batches; }
-        for (i = 0; i < nready; ++i) TIMED(5, end_node(&T.nd[ready[i]]));
+        /* replay and rendering of every node of the round, side by side (multic nodes: one after the other -- its driver
+         * keeps state of its own) */
+        { const double t_ = mz_now_s();
+          if (T.use_multic) { for (i = 0; i < nready; ++i) end_node(&T.nd[ready[i]]); }
+          else {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (nready > 1)
+              for (i = 0; i < nready; ++i) end_node(&T.nd[ready[i]]);
+          }
+          g_t[5] += mz_now_s() - t_; }
         ++rounds;
     }
     if (T.nd[root].id < 0) mz_fatalf("tree specification is improper");

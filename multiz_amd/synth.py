@@ -22,6 +22,11 @@ CONFIGS = {
     # not a BASELINE configuration: C2's blocks with the bands pre_yama derives when the blocks have indels against the
     # shared reference row, 10 runs of unshared columns per 1 000 (mean length 3) -- rows wider than 64 columns
     "c2i": dict(K=2, L=2, mlo=900, mhi=1100, pairs=20000, radius=30, indel=10),
+    # not BASELINE configurations: C2's blocks with bands too wide AND too high for the row-parallel kernels -- radius 50 (rows of
+    # 101 columns: the tagged anti-diagonal wavefront, MZ_MODE_FASTT) and radius 100 (rows of 201: 64-row strips, MZ_MODE_STRIP);
+    # the fallback kernels' rates for the record
+    "c2w": dict(K=2, L=2, mlo=900, mhi=1100, pairs=20000, radius=50),
+    "c2s": dict(K=2, L=2, mlo=900, mhi=1100, pairs=10000, radius=100),
     # ... and the guide-tree workload's blocks (1..29 rows) with such bands
     "c4i": dict(K=0, L=0, mlo=200, mhi=1000, pairs=50000, radius=30, indel=10),
 }

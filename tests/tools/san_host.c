@@ -15,6 +15,9 @@ void mz_synth_shapes_tree(int n, uint64_t seed, int64_t first_pair, int mlo, int
 void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius, const int32_t *aK, const int32_t *aL, const int32_t *aM,
                    const int32_t *aN, const int64_t *offA, const int64_t *offB, const int64_t *offBand, uint8_t *poolA, uint8_t *poolB,
                    int32_t *poolLB, int32_t *poolRB);
+void mz_assemble_cols(int K, int L, int M, int N, const uint8_t *A, const uint8_t *B, const uint8_t *script, int om, uint8_t *out);
+void mz_pack_classes_stream(const uint8_t *src, size_t n, uint8_t *dst, size_t slot);
+uint32_t mz_pack_band_nib_stream(const int *LB, const int *RB, int M, uint8_t *dst, size_t slot);
 int mz_gather_segments(int64_t n, int64_t elem, const int64_t *off, const int64_t *len, const int64_t *pos, const void *src, void *dst);
 
 int main(void)
@@ -49,6 +52,39 @@ int main(void)
             free(map); free(map2); free(buf); free(X + 1);
         }
         free(A); free(B); free(LB); free(RB); free(G);
+    }
+    /* the host half of mz_yama_batch()'s link formats (mz_pack.c) on exactly-sized heap blocks: the 16-byte copies of
+     * the column assembly and the streaming forms must stay inside their arrays (ASan sees every byte beyond) */
+    {
+        int kk, ll;
+        for (kk = 1; kk <= 40; kk += (kk < 6 ? 1 : 17)) for (ll = 1; ll <= 33; ll += (ll < 5 ? 1 : 14)) {
+            const int M_ = 37 + kk, N_ = 29 + ll, om = M_ + N_ - 20;      /* 20 aligned columns, the rest one-sided */
+            uint8_t *a = malloc((size_t)kk * M_), *b = malloc((size_t)ll * N_), *scr = calloc((size_t)(om + 3) / 4, 1);
+            uint8_t *out = malloc((size_t)om * (kk + ll)), *nib;
+            int *lb = malloc(sizeof(int) * (M_ + 1)), *rb = malloc(sizeof(int) * (M_ + 1)), m, ia = 0, ib = 0;
+            size_t slot;
+            memset(a, 'A', (size_t)kk * M_); memset(b, 'c', (size_t)ll * N_);
+            for (m = 0; m < om; ++m) {                   /* C while both last, then D's, then I's; 2 bits per column */
+                const unsigned op = (m < 20) ? 0u : (ia < M_ ? 2u : 1u);
+                scr[m >> 2] |= (uint8_t)(op << (2 * (m & 3)));
+                ia += op != 1u; ib += op != 2u;
+            }
+            if (ia != M_ || ib != N_) { fprintf(stderr, "bad test script\n"); return 1; }
+            mz_assemble_cols(kk, ll, M_, N_, a, b, scr, om, out);
+            sum += out[0] + out[(size_t)om * (kk + ll) - 1];
+            slot = (((size_t)kk * M_ + 63) & ~(size_t)63) / 2;
+            nib = aligned_alloc(32, slot);
+            mz_pack_classes_stream(a, (size_t)kk * M_, nib, slot);
+            sum += nib[0] + nib[slot - 1];
+            free(nib);
+            for (m = 0; m <= M_; ++m) { lb[m] = m / 2; rb[m] = m / 2 + 11 + (m & 3); }
+            for (m = 1; m <= M_; ++m) if (rb[m] < rb[m - 1]) rb[m] = rb[m - 1];
+            slot = ((size_t)M_ + 31) & ~(size_t)31;
+            nib = aligned_alloc(32, slot);
+            sum += mz_pack_band_nib_stream(lb, rb, M_, nib, slot) + nib[slot - 1];
+            free(nib);
+            free(a); free(b); free(scr); free(out); free(lb); free(rb);
+        }
     }
     init_scores70(); init_scores85(); init_scores70();
     printf("san host ok %lld\n", sum);
