@@ -15,8 +15,11 @@
  * prepared (mz_multiz_prepare), then ALL their pending block-pair alignments go to the GPU as one batch per wave
  * (mz_multiz_align) -- the per-tree-level batch of BASELINE config 4 -- and each run is replayed into its node.
  *
- * Output: the destination file, block for block what the stock roast writes (comment lines differ: the stock ones
- * carry temp-file names with the process id).  grep -v eof / grep -v maf of the stock chain act on text lines here
+ * Output: the destination file, block for block what the stock roast writes.  COMMENT LINES ARE NOT CARRIED: the stock
+ * chain's programs echo the '#' lines of their inputs (maf_project and multiz read with mafReadAll(file, 1)), so its
+ * destination holds the tools' own comments -- temp-file names with the process id -- and whatever '#' lines the
+ * .sing.maf inputs had; the readers here run with verbose = 0 and the destination gets the header and the command line
+ * only (tests/test_roast_inprocess.py compares the two outputs with '#' lines left out on both sides).  grep -v eof / grep -v maf of the stock chain act on text lines here
  * as well; like there, a species whose NAME contains "maf" or "eof" would lose its rows to them.
  */
 #include "mz_drivers.h"
