@@ -341,7 +341,8 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
 extern "C" int mzk_prep(const mz_dev_batch *b, void *stream)
 {
     if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_rowprep, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b, 0, b->n);
+    // few pairs: long pairs as likely as not -- their rows in 16 segments (blockIdx.y)
+    hipLaunchKernelGGL(k_rowprep, dim3(b->n, b->n <= 4096 ? 16 : 1), dim3(WAVE), 0, (hipStream_t)stream, *b, 0, b->n);
     CK(hipGetLastError(), "prep launch");
     return 0;
 }

@@ -1,10 +1,18 @@
-# end-of-round check: the whole GPU suite, smoke, the default bench line and the other configurations
+# end-of-round measurements: tests, bench lines of every configuration, PMC records   (tests/tools/final.sh <tag>)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/final; mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; tail -c 2500 $O/bench_c2.json
-for c in c3 c4 c5; do timeout 900 python bench.py --config $c --cpu-seconds 8 > $O/bench_$c.json 2> $O/bench_$c.err; python3 -c "import json; d=json.load(open('$O/bench_$c.json')); print('$c', d['value'], d['ms_per_step'], d['kernel_gcups'], d.get('value_host'), d['cpu_baseline']['value'], d['parity'][:40])"; done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-host > $O/stats_c2.log 2>&1
-f=$(find $O/stats_c2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" < /dev/null
+TAG=${1:-r3}
+O=gpurun_out/${TAG}_final; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/gputests.txt 2>&1; tail -3 $O/gputests.txt
+python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err
+for c in c3 c4 c5 c2i c4i c2w c2s; do python bench.py --config $c --steps 30 > $O/${TAG}_bench_$c.json 2> $O/bench_$c.err; done
+python - "$O" "$TAG" <<'PY'
+import json, sys, glob, os
+for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json"))):
+    try:
+        d = json.load(open(f))
+        print(os.path.basename(f), d["value"], "host", d.get("value_host"), d.get("host_ms_per_batch"), "serial", d["kernel_gcups"], d["kernel_ms"], "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("socket_linear"), d.get("vs_cpu"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+timeout 1500 python tests/tools/pmc_collect.py ${TAG} c2 c3 c4 c5 c2i > $O/pmc_collect.txt 2>&1; tail -6 $O/pmc_collect.txt
