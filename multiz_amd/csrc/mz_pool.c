@@ -70,6 +70,12 @@ static int grab(pjob *j, int *lo, int *hi)
     return 1;
 }
 
+/* jobs posted so far: with MZ_POOL_SPIN_US=<n> a worker that has run out of work watches this for n microseconds before
+ * it goes to sleep.  Off by default: measured on the 50 000-pair C2 call (a job every ~0.3 ms), 0 / 40 / 100 / 300 us all
+ * gave 9.4-9.8 ms -- the wake-up of the sleepers is not what the packing waits for */
+static unsigned g_posted;
+static int g_spin_us = -1;
+
 static void *pool_worker(void *arg)
 {
     (void)arg;
@@ -78,7 +84,28 @@ static void *pool_worker(void *arg)
         pjob *j;
         int lo, hi;
         for (j = g_pool.head; j && j->next >= j->n; j = j->link) ;
-        if (!j) { pthread_cond_wait(&g_pool.work, &g_pool.mu); continue; }
+        if (!j) {
+            if (g_spin_us > 0) {
+                const unsigned seen = __atomic_load_n(&g_posted, __ATOMIC_RELAXED);
+                struct timespec t0, t1;
+                pthread_mutex_unlock(&g_pool.mu);
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                for (;;) {
+                    int k;
+                    for (k = 0; k < 64; ++k) __builtin_ia32_pause();
+                    if (__atomic_load_n(&g_posted, __ATOMIC_ACQUIRE) != seen) break;
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L >= g_spin_us) break;
+                }
+                pthread_mutex_lock(&g_pool.mu);
+                if (g_pool.quit) break;
+                for (j = g_pool.head; j && j->next >= j->n; j = j->link) ;
+                if (j) goto work;
+            }
+            pthread_cond_wait(&g_pool.work, &g_pool.mu);
+            continue;
+        }
+work:
         grab(j, &lo, &hi);
         pthread_mutex_unlock(&g_pool.mu);
         j->fn(j->ctx, lo, hi);
@@ -100,6 +127,7 @@ static void pool_start_locked(void)
     if (want > MZ_COPY_THREADS && !(e && atoi(e) > 0)) want = MZ_COPY_THREADS;
     if (want < 1) want = 1;
     if (want > POOL_MAX) want = POOL_MAX;
+    if (g_spin_us < 0) { const char *sp = getenv("MZ_POOL_SPIN_US"); g_spin_us = sp ? atoi(sp) : 0; }
     g_pool.started = 1;
     g_pool.nthreads = 0;
     for (i = 0; i < want - 1; ++i) {
@@ -132,6 +160,7 @@ void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx)
     if (!g_pool.started) pool_start_locked();
     for (pp = &g_pool.head; *pp; pp = &(*pp)->link) ;       /* jobs in arrival order: the older chunk first */
     *pp = &job;
+    __atomic_fetch_add(&g_posted, 1u, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_pool.work);
     while (grab(&job, &lo, &hi)) {
         pthread_mutex_unlock(&g_pool.mu);

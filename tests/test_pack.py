@@ -117,7 +117,7 @@ def pack2(ops: np.ndarray) -> np.ndarray:
     return (o[:, 0] | (o[:, 1] << 2) | (o[:, 2] << 4) | (o[:, 3] << 6)).astype(np.uint8)
 
 
-@pytest.mark.parametrize("K,L", [(1, 1), (2, 2), (1, 3), (4, 4), (3, 2), (5, 2), (10, 10), (2, 17), (29, 1), (40, 33)])
+@pytest.mark.parametrize("K,L", [(1, 1), (2, 2), (1, 2), (2, 1), (1, 3), (4, 4), (3, 2), (5, 2), (10, 10), (2, 17), (29, 1), (40, 33)])
 def test_assemble_matches_the_oracle(lib, K, L):
     rng = np.random.default_rng(K * 100 + L)
     for M, N in ((1, 1), (3, 9), (60, 47), (180, 200)):
