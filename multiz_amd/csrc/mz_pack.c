@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <immintrin.h>
+#include <pthread.h>
 
 #include "mz_pack.h"
 
@@ -258,10 +259,13 @@ static int g_ssse3;
 
 __attribute__((constructor)) static void shuf_init_cpu(void) { __builtin_cpu_init(); g_ssse3 = __builtin_cpu_supports("ssse3") && !(getenv("MZ_NO_SSSE3") && atoi(getenv("MZ_NO_SSSE3"))); }
 
+static pthread_mutex_t g_shuf_mu = PTHREAD_MUTEX_INITIALIZER;
 static void shuf_build(int K, int L)
 {
     shuf_tab *T = &g_shuf[K][L];
     int x, k, r;
+    pthread_mutex_lock(&g_shuf_mu);            /* ONE builder: a second one would blank entries a reader is using */
+    if (T->ready) { pthread_mutex_unlock(&g_shuf_mu); return; }
     for (x = 0; x < 256; ++x) {
         int ia = 0, ib = 0, o = 0;
         memset(T->sh[x], 0x80, 16); memset(T->dash[x], 0, 16);
@@ -275,6 +279,7 @@ static void shuf_build(int K, int L)
         T->adv_a[x] = (uint8_t)(ia * K); T->adv_b[x] = (uint8_t)(ib * L);
     }
     __atomic_store_n(&T->ready, 1, __ATOMIC_RELEASE);
+    pthread_mutex_unlock(&g_shuf_mu);
 }
 
 /* columns [m0, m1), m0 a multiple of 4; returns the first column NOT done (the caller finishes the rest): the steps stop
@@ -302,7 +307,7 @@ static inline void assemble_piece(int K, int L, const uint8_t **pa, const uint8_
                                   const uint8_t *s, int m0, int m1, uint8_t *o)
 {
     if (K <= 2 && L <= 2 && g_ssse3) {
-        if (!__atomic_load_n(&g_shuf[K][L].ready, __ATOMIC_ACQUIRE)) shuf_build(K, L);     /* (idempotent: racing builders write the same bytes) */
+        if (!__atomic_load_n(&g_shuf[K][L].ready, __ATOMIC_ACQUIRE)) shuf_build(K, L);
         m0 = assemble_shuf(K, L, pa, aend, pb, bend, s, m0, m1, &o);
         if (m0 >= m1) return;
     }

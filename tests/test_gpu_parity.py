@@ -798,3 +798,45 @@ print("walk ok")
     env = dict(os.environ, MZ_WALK=walk)
     p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, timeout=900)
     assert p.returncode == 0 and b"walk ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+def test_host_path_sweep(mz):
+    # mz_yama_batch() end to end on shapes that take every branch of its host half: thin blocks (four columns per
+    # step by byte shuffle), blocks of up to 4+4 rows (fixed-size moves), wider ones (16-byte copies); band bounds whose
+    # steps need the nibble, the byte and the raw format in one call; pairs the plan refuses in between (the
+    # reference's own status, nothing assembled for them).  tests/tools/host_sweep.py is the long form.
+    rng = np.random.default_rng(910_000)
+    pairs, want_bad = [], []
+    while len(pairs) < 500:
+        kind = int(rng.integers(0, 7))
+        K, L = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        M, N = int(rng.integers(1, 600)), int(rng.integers(1, 600))
+        R = int(rng.choice([3, 10, 30, 31, 64]))
+        band = str(rng.choice(["diag", "wander", "wander", "full"]))
+        if kind == 0:
+            K, L = int(rng.integers(5, 40)), int(rng.integers(5, 40)); M, N = int(rng.integers(5, 200)), int(rng.integers(5, 200))
+        elif kind == 1:
+            K, L = int(rng.integers(1, 3)), int(rng.integers(1, 3)); M, N = int(rng.integers(800, 3000)), int(rng.integers(800, 3000)); band = "diag"
+        A, B, LB, RB = inputs.make_pair(rng, K, L, M, N, R, band, mo.smooth,
+                                        dash=float(rng.choice([0.0, 0.08, 0.5])), odd=float(rng.choice([0.0, 0.05, 0.6])))
+        if band == "full" and M * N > 60000:
+            continue
+        if kind == 2 and M > 8:                      # a jump of tens / hundreds of columns in the bounds
+            j = int(rng.integers(2, M - 2)); jump = int(rng.choice([20, 90, 300, 700]))
+            if N > jump + 40:
+                LB = LB.copy(); RB = RB.copy()
+                RB[j:] = np.minimum(RB[j:] + jump, N); LB[j + 1:] = np.minimum(LB[j + 1:] + jump, N - 11 if N > 11 else 0)
+                LB = np.maximum.accumulate(LB); RB = np.maximum.accumulate(RB); RB[-1] = N
+        rc = mo.check(M, N, LB, RB)[0]
+        if rc != 0 and rng.random() < 0.9:
+            continue
+        pairs.append((A, B, LB.astype(np.int32), RB.astype(np.int32))); want_bad.append(rc)
+    assert sum(1 for r in want_bad if r) >= 3
+    _kernels(mz, 2)
+    res = mz.yama_batch(pairs)
+    for i, ((A, B, LB, RB), r) in enumerate(zip(pairs, res)):
+        if want_bad[i]:
+            assert r.status == want_bad[i] and r.cols is None, i
+            continue
+        w = mo.yama(A, B, LB, RB, variant="profile")
+        assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), (i, A.shape, B.shape)

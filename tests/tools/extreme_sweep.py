@@ -11,7 +11,7 @@ from multiz_amd import synth
 from oracle import mzoracle as mo
 mz.api.init(0)
 tot = bad = 0
-modes = np.zeros(9, dtype=np.int64)
+modes = np.zeros(13, dtype=np.int64)
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(70_000 + seed)
     pairs = []
@@ -35,7 +35,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     for fast, row in ((1, 1), (1, 0), (0, 0)):
         mz.lib().mz_enable_fast(fast); mz.lib().mz_enable_row(row)
         db = mz.DevBatch(batch); db.run(); res = db.results(); out = db.out.cpu().numpy()
-        modes += np.bincount(res["mode"], minlength=9)
+        modes += np.bincount(res["mode"], minlength=13)
         for i in range(len(pairs)):
             m_, o0 = int(res["om"][i]), int(res["offOut"][i])
             w = pairs[i][0].shape[1] + pairs[i][1].shape[1]
