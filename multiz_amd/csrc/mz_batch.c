@@ -52,6 +52,7 @@ static size_t band_slot(int M) { return ((size_t)M + 31) & ~(size_t)31; }      /
  * long pairs -- BASELINE config 5 -- in pieces of 64 kept two threads busy and took 13 ms to assemble) */
 static int pack_grain(int n)
 {
+    if (n <= 16) return n;                               /* (a single yama() call: the caller alone, no pool is started) */
     const int g = n / (4 * mzi_pool_threads());
     return g < 1 ? 1 : g > 64 ? 64 : g;
 }
