@@ -25,7 +25,6 @@ int mzk_emit(const mz_dev_batch *b, void *stream);
 int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
 int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);
 int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream);
-int mzk_emit_packed(const mz_dev_batch *b, void *stream);
 /* device side of pre_yama() around the DP (kernels/prepost.inc): all device pointers */
 typedef struct mz_pre_batch {
     int n;

@@ -526,24 +526,17 @@ extern "C" int mz_walk_choice(int n, const int64_t *totals)
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)
 {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, 0);
-    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, 0);
-    CK(hipGetLastError(), "emit launch");
-    return 0;
-}
-// the emit of a whole batch with the outputs PACKED (after the walk): szScript becomes the pairs' offsets into b.out,
-// totals[12] the bytes they fill
-extern "C" int mzk_emit_packed(const mz_dev_batch *b, void *stream)
-{
-    if (b->n <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (b->n + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL(k_pack1, dim3(nblk), dim3(WAVE), 0, s, *b);
-    hipLaunchKernelGGL(k_pack2, dim3(1), dim3(WAVE), 0, s, *b, nblk);
-    hipLaunchKernelGGL(k_pack3, dim3(nblk), dim3(WAVE), 0, s, *b);
-    hipLaunchKernelGGL(k_emit, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
-    hipLaunchKernelGGL(k_emit_wide, dim3(b->n), dim3(WAVE), 0, s, *b, 0, b->n, 1);
-    CK(hipGetLastError(), "packed emit launch");
+    // a launch of few pairs: long thin pairs by several waves each (kernels/emit.inc; the count kernel reuses the head of the
+    // pair's traceback slice, which the walk -- earlier on this stream -- has finished with)
+    const int split = count <= 4096;
+    hipLaunchKernelGGL(k_emit, dim3(count), dim3(WAVE), 0, s, *b, first, count, split);
+    if (split) {
+        hipLaunchKernelGGL(k_emit_long_count, dim3(count, EMIT_MAXSEG), dim3(WAVE), 0, s, *b, first, count);
+        hipLaunchKernelGGL(k_emit_long, dim3(count, EMIT_MAXSEG), dim3(WAVE), 0, s, *b, first, count);
+    }
+    hipLaunchKernelGGL(k_emit_wide, dim3(count), dim3(WAVE), 0, s, *b, first, count);
+    CK(hipGetLastError(), "emit launch");
     return 0;
 }
 // The host path's result: per pair a 32-byte record and the edit script at two bits per merged column, in column order
