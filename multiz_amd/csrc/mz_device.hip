@@ -545,7 +545,13 @@ extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void 
 extern "C" int mzk_script_pack(const mz_dev_batch *b, void *hdr, void *recs, void *packed, void *stream)
 {
     if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_script_pack, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *b, (long long *)hdr, (mz_res_rec *)recs, (uint8_t *)packed);
+    const int split = b->n <= 4096;                 // long thin pairs by several waves each (kernels/emit.inc)
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_script_pack, dim3(b->n), dim3(WAVE), 0, s, *b, (long long *)hdr, (mz_res_rec *)recs, (uint8_t *)packed, split);
+    if (split) {
+        hipLaunchKernelGGL(k_script_pack_long, dim3(b->n, EMIT_MAXSEG), dim3(WAVE), 0, s, *b, (uint8_t *)packed);
+        hipLaunchKernelGGL(k_script_fin, dim3((b->n + 255) / 256), dim3(256), 0, s, *b, (long long *)hdr, (mz_res_rec *)recs);
+    }
     CK(hipGetLastError(), "script pack launch");
     return 0;
 }
