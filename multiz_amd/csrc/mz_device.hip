@@ -506,8 +506,12 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
     const int hint = (force || !beside_dp || count <= 16384) ? 0 : b->walk_hint;
     const bool both = !force && beside_dp && count > 16384 && hint == MZ_WALK_AUTO;
-    if (force ? force == 1 : (both || hint != MZ_WALK_CHASE))
-        hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+    if (force ? force == 1 : (both || hint != MZ_WALK_CHASE)) {
+        if (count <= 4096)      // a launch of few pairs: long ones as likely as not -- the variant that fetches its next window ahead
+            hipLaunchKernelGGL(k_walk_wave_ahead, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+    }
     if (force ? force == 2 : (both || hint == MZ_WALK_CHASE)) {
         const int waves = (count + WALK_LANES - 1) / WALK_LANES;
         CK(hipMemsetAsync(&b->totals[10], 0, sizeof(int64_t), (hipStream_t)stream), "walk counter");      // the chase's pair counter
