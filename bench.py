@@ -168,7 +168,10 @@ def cpu_leg(spec_path):
         g = c_ / (time.perf_counter() - t) / 1e9
         base = base or g
         curve.append({"threads": th, "gcups": round(g, 5), "efficiency": round(g / base / th, 3)})
-    best = max(curve, key=lambda r: r["gcups"])
+    # the FEWEST threads within 3 % of the best rate: past the quota more threads give the same rate (or less: the quota
+    # throttles all of them), and socket_linear = rate x cores / threads must not be halved by a tie
+    top = max(r["gcups"] for r in curve)
+    best = min((r for r in curve if r["gcups"] >= 0.97 * top), key=lambda r: r["threads"])
     # ---- the headline sample at the best thread count (its hashes are the parity gate)
     nsample = int(max(min(cores, pairs), min(pairs, spec["seconds"] * 2.0 / 3.0 * best["gcups"] / max(curve[0]["gcups"], 1e-9) / max(per_pair, 1e-7))))
     idx = np.sort(order[:nsample])
