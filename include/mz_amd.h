@@ -80,6 +80,7 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
        MZ_MODE_WIDE = 9, MZ_MODE_WIDESTRIP = 10 /* blocks of 128..255 rows: WF64 / STRIP with int16 gap vectors */,
        MZ_MODE_LAG = 11 /* ROW for bands with rows of 65..127 columns: the 64-column periods run a few rows apart (kernels/lag.inc) */ };
 
+#define MZ_TOTALS 96        /* int64 entries of mz_dev_batch.totals */
 typedef struct mz_dev_batch {
     int32_t n;
     int32_t dp_hint;       /* 0: unknown -- every DP kernel is launched, one after the other; else mz_dp_hint() of the plan's totals:
@@ -112,9 +113,9 @@ typedef struct mz_dev_batch {
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
-                              [11] rows (K+L) of all valid pairs, [12] bytes of the packed outputs (host path), [16..18] work counters of k_dp / k_dp_wide / k_dp_lag; 32 entries in all */
-    int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other */
-    int64_t *scanAux;      /* scratch of the prefix-sum kernels: 6 * (n/1024 + 2) entries             */
+                              [11] rows (K+L) of all valid pairs, [12] bytes of the packed outputs (host path), [16..18] work counters of k_dp / k_dp_wide / k_dp_lag, [32..95] the pair lists' totals per (kind, size class): 128 ints; MZ_TOTALS entries in all */
+    int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other, each with the pairs of most cells first */
+    int64_t *scanAux;      /* scratch of the prefix-sum kernels: (8 + 64) * (n/64 + 2) entries (8 sums, then 128 ints of list counts, per 64 pairs) */
     /* workspaces + results (device) */
     uint32_t *tbw;
     uint8_t  *script;

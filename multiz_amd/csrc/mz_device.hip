@@ -329,7 +329,7 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
     {
         const int nblk = (b->n + SCAN_B - 1) / SCAN_B;
         hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_B), 0, s, *b);
-        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(64), 0, s, *b, nblk);
+        hipLaunchKernelGGL(k_scan2, dim3(SCAN_Q + ORD_KEYS), dim3(64), 0, s, *b, nblk);
         hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(SCAN_B), 0, s, *b);
     }
     hipLaunchKernelGGL(k_fit, dim3((b->n + 255) / 256), dim3(256), 0, s, *b);
@@ -453,7 +453,8 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         for (int i = 0; known && i < 4; ++i)                         // move it to the end, the rest keep their order
             if (kinds[i] == most) { for (int j = i; j < 4; ++j) kinds[j] = kinds[j + 1]; kinds[4] = most; break; }
     }
-    const bool rows_listed = known && b->dp_rows > 0 && b->dp_rows < count && first == 0 && count == b->n;
+    // (whole batch, counts known: the row kernels' blocks take the plan's list too -- it is ordered, most cells first)
+    const bool rows_listed = known && b->dp_rows > 0 && first == 0 && count == b->n;
     int nk = 0, last = 0;
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
