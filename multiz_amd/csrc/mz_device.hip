@@ -196,6 +196,14 @@ __device__ __forceinline__ void for_my_pairs(const mz_dev_batch &b, unsigned lon
     }
 }
 
+// A block per pair, whole batch: block k takes the k-th entry of the plan's lists (every valid pair is on one of the four,
+// most cells first within each: the blocks the dispatcher hands out last are short ones); a part of a batch: its pairs in order.
+__device__ __forceinline__ int listed_pair(const mz_dev_batch &b, int first, int count, int k)     // -1: no pair for this block
+{
+    if (first != 0 || count != b.n) return k < count ? first + k : -1;
+    return k < b.n - (int)b.totals[3] ? b.packList[k] : -1;
+}
+
 #include "kernels/plan.inc"
 #include "kernels/wavefront_exact.inc"
 #include "kernels/wavefront_fast.inc"
