@@ -443,6 +443,8 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (count <= 0) return 0;
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
     if (dyn_lds < 0) { const char *e = getenv("MZ_DYN_LDS"); dyn_lds = e ? atoi(e) : 0; }
+    static int dyn_lds_lag = -1;                  // MZ_DYN_LDS_LAG=<bytes>: the same for k_dp_lag
+    if (dyn_lds_lag < 0) { const char *e = getenv("MZ_DYN_LDS_LAG"); dyn_lds_lag = e ? atoi(e) : 0; }
     static int lat_max = -1;                      // MZ_LAT_MAX=<waves>: launches that leave the GPU at most that many row-parallel waves take k_dp_row_lat (0: never)
     if (lat_max < 0) { const char *e = getenv("MZ_LAT_MAX"); lat_max = e ? atoi(e) : 2048; }
     static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
@@ -497,7 +499,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         else if (kinds[i] == MZ_DP_WIDE)
             hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
         else
-            hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), 0, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), dyn_lds_lag, s, *b, first, count);
         if (side) { CK(hipEventRecord(S->join[used], s), "dp join"); ++used; }
     }
     for (int i = 0; i < used; ++i) CK(hipStreamWaitEvent(main_s, S->join[i], 0), "dp join wait");
