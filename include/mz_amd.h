@@ -212,6 +212,11 @@ typedef struct mz_out {
  * Calls are serialised (the library state is process-wide).  MZ_TIMING=1 in the environment: one JSON line per call on
  * stderr (pairs, band cells, seconds, GCUPS, bytes over the link each way); MZ_TIMING=2: and one per chunk. */
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
+
+/* Start the GPU in the background (HIP runtime, context, streams, code object: ~0.3 s of a process's first batch call)
+ * and return at once; the first batch call waits for what is left of it.  For drivers that read files first; set the
+ * score tables before the call.  Without it the first batch call does the same work itself. */
+void mz_warm_start(void);
 /* bytes the last mz_yama_batch() call moved over the PCIe link: to the device(s), and back */
 void mz_link_bytes(int64_t *up, int64_t *down);
 /* free the result blocks of a finished call (all n entries of it) and reset cols / block to NULL */

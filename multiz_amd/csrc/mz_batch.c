@@ -748,7 +748,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     }
     g_last_up = st.bytes_up; g_last_down = st.bytes_down;
     pthread_mutex_unlock(&g_big);
-    if (g_timing && rc >= 0) {
+    if (g_timing && rc >= 0 && !mzi_warm_thread) {
         /* one JSON line per call: pairs, band cells, seconds, GCUPS, bytes over the link each way */
         const double dt = mzi_now_s() - t_call;
         fprintf(stderr, "{\"mz_yama_batch\": {\"pairs\": %d, \"failed\": %d, \"cells\": %lld, \"seconds\": %.6f, \"gcups\": %.2f, \"bytes_up\": %lld, \"bytes_down\": %lld, "

@@ -90,6 +90,7 @@ MZ_INTERNAL int mzi_dev_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_host_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_lazy_stream(hipStream_t *s);
 MZ_INTERNAL int mzi_ensure_init(void);
+extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_warm_start(): its batch prints no MZ_TIMING line */
 MZ_INTERNAL int mzi_sync_scores(void);
 MZ_INTERNAL void mzi_workers_stop(mz_ctx *X);           /* mz_batch.c: ctx_close() ends the context's helper threads */
 

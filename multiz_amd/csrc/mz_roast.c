@@ -361,6 +361,7 @@ int mz_roast_main(int argc, char **argv)
 
     mz_tune_malloc();
     init_scores70();
+    mz_warm_start();                                     /* the GPU starts up while the inputs are read */
     root = parse_tree(argv[1]);
     if (!T.execute) {                                     /* "-": show the plan */
         for (i = 0; i < T.nn; ++i) if (T.nd[i].id >= 0)
