@@ -244,6 +244,55 @@ def test_every_kernel_family_is_exercised(mz):
         assert np.array_equal(got, want.cols), (i, int(res["mode"][i]))
 
 
+def test_plan_lists_hold_every_valid_pair_once_largest_first(mz):
+    # The DP kernels take their pairs from the plan's lists (wavefront / 128+ rows / lagged / row-parallel, one after the other;
+    # kernels/plan.inc: a counting sort on the half-octave class of the band cells, largest class first).  A pair missing
+    # from its list would never be computed, one listed twice computed twice: the lists together must be a permutation of
+    # the valid pairs, each list must hold exactly the pairs of its kind, and its classes must not grow along the list.
+    from multiz_amd import synth
+    rng = np.random.default_rng(5)
+    pairs = []
+    for K, L, M, N, R, band in ((2, 2, 300, 300, 30, "diag"), (2, 2, 900, 1000, 30, "diag"), (3, 1, 120, 150, 30, "diag"),
+                                (1, 4, 260, 200, 30, "diag"), (2, 2, 150, 230, 25, "wander"), (2, 2, 500, 500, 60, "diag"),
+                                (2, 2, 40, 45, 10, "diag"), (20, 16, 300, 280, 30, "diag"), (2, 2, 2000, 2100, 30, "diag")):
+        for _ in range(40):
+            A, B, LB, RB = inputs.make_pair(rng, K, L, M + int(rng.integers(0, 40)), N + int(rng.integers(0, 40)), R, band, mo.smooth)
+            if rng.random() < 0.05:
+                LB = LB.copy(); LB[0] = 1                 # an invalid band: the pair fails in the plan and is on no list
+            pairs.append((A, B, LB, RB))
+    order = rng.permutation(len(pairs))
+    batch = synth.pack_pairs([pairs[i] for i in order])
+    for lag_pairs in (False, True):
+        if lag_pairs:                                      # the bench's indel mix: mostly lagged pairs
+            c = synth.CONFIGS["c2i"]
+            batch = synth.make_batch(3000, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], indel=c["indel"])
+        _kernels(mz, 2)
+        db = mz.DevBatch(batch)
+        db.run()
+        res = db.results()
+        n = len(res["status"])
+        tot = db._view(db.c.totals, 16, np.int64)
+        plist = db._view(db.c.packList, n, np.int32)
+        ok = res["status"] == 0
+        nwf, nwide, nlag = int(tot[5] & 0xffffffff), int(tot[8] & 0xffffffff), int(tot[8] >> 32)
+        nvalid = int(ok.sum())
+        assert n - nvalid == int(tot[3])
+        listed = plist[:nvalid]
+        assert np.array_equal(np.sort(listed), np.flatnonzero(ok)), "the lists are not a permutation of the valid pairs"
+        mode = res["mode"]
+        kind = np.where(mode < 5, 0, np.where((mode == 9) | (mode == 10), 1, np.where(mode == 11, 2, 3)))
+        bounds = [0, nwf, nwf + nwide, nwf + nwide + nlag, nvalid]
+        cells = np.maximum(res["cells"], 256)
+        lg = np.floor(np.log2(cells)).astype(np.int64)
+        cls = np.minimum(2 * (lg - 8) + ((cells >> (lg - 1)) & 1), 31)
+        for k in range(4):
+            part = listed[bounds[k]: bounds[k + 1]]
+            assert (kind[part] == k).all(), k
+            assert (np.diff(cls[part]) <= 0).all(), f"list {k} is not ordered by size class"
+        if lag_pairs:
+            assert nlag > 2000 and bounds[4] - bounds[3] > 0
+
+
 def test_large_score_magnitudes(mz):
     # columns whose dash pattern flips from one column to the next make every row pair open a gap at every step:
     # final scores of -1e7 .. -9e7, within a small factor of the magnitude bounds under which the plan admits
