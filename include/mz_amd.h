@@ -217,6 +217,9 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs);
  * and return at once; the first batch call waits for what is left of it.  For drivers that read files first; set the
  * score tables before the call.  Without it the first batch call does the same work itself. */
 void mz_warm_start(void);
+/* Wait for that thread (a no-op without one).  A program that may end without a single batch call calls this before it
+ * returns from main(): the HIP runtime must not be torn down under a thread that is still starting it. */
+void mz_warm_wait(void);
 /* bytes the last mz_yama_batch() call moved over the PCIe link: to the device(s), and back */
 void mz_link_bytes(int64_t *up, int64_t *down);
 /* free the result blocks of a finished call (all n entries of it) and reset cols / block to NULL */

@@ -39,10 +39,12 @@ int mzi_set_err(const char *fmt, ...)
 /* same shape as the reference's fatalf(): "<argv0 basename>: message\n", exit(1) */
 int mz_scores_explicit;                  /* set by mz_set_scores(), cleared by init_scores70/85() */
 
+void mz_warm_wait(void);
 __attribute__((noreturn)) void mz_fatalf(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
+    mz_warm_wait();                                    /* no thread of ours inside the HIP runtime while the process exits */
     fflush(stdout);
     if (argv0) {
         const char *p = strrchr(argv0, '/');
@@ -259,16 +261,17 @@ static void *warm_main(void *arg)
     if (mz_yama_batch(1, &job, &out) >= 0) mz_free_outs(1, &out);
     return NULL;
 }
-static void warm_join(void)
+void mz_warm_wait(void)
 {
-    if (g_warm_on) { g_warm_on = 0; pthread_join(g_warm_th, NULL); }
+    if (g_warm_on && !mzi_warm_thread) { g_warm_on = 0; pthread_join(g_warm_th, NULL); }
 }
 void mz_warm_start(void)
 {
     if (g_warm_on || g_ndev) return;
     if (pthread_create(&g_warm_th, NULL, warm_main, NULL) != 0) return;      /* (no thread: the first call starts the GPU as ever) */
     g_warm_on = 1;
-    atexit(warm_join);                                   /* a run that never gets to a batch must not exit under the thread */
+    atexit(mz_warm_wait);                                /* a run that never gets to a batch must not exit under the thread (the
+                                                          * drivers also wait before they return from main) */
 }
 
 /* ------------------------------------------------------------------ scores */

@@ -1,3 +1,4 @@
 /* mz_multic: the multic command line on libmzamd.so (reference multic.c main(), :259-403) */
 #include "../../include/mz_multiz.h"
-int main(int argc, char **argv) { return mz_multic_main(argc, argv); }
+void mz_warm_wait(void);      /* (include/mz_amd.h) */
+int main(int argc, char **argv) { const int rc = mz_multic_main(argc, argv); mz_warm_wait(); return rc; }

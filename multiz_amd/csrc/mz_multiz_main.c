@@ -1,3 +1,4 @@
 /* mz_multiz: the multiz command line on libmzamd.so (reference multiz.c main(), :180-294) */
 #include "../../include/mz_multiz.h"
-int main(int argc, char **argv) { return mz_multiz_main(argc, argv); }
+void mz_warm_wait(void);      /* (include/mz_amd.h) */
+int main(int argc, char **argv) { const int rc = mz_multiz_main(argc, argv); mz_warm_wait(); return rc; }

@@ -1,2 +1,3 @@
 #include "../../include/mz_multiz.h"
-int main(int argc, char **argv) { return mz_roast_main(argc, argv); }
+void mz_warm_wait(void);      /* (include/mz_amd.h) */
+int main(int argc, char **argv) { const int rc = mz_roast_main(argc, argv); mz_warm_wait(); return rc; }

@@ -98,6 +98,30 @@ def test_several_contigs_and_orphans(tmp_path):
     both(d2, ["../a.maf", "../b.maf", "0"])
 
 
+def test_runs_that_never_reach_the_gpu(tmp_path):
+    # The driver starts the GPU in a background thread while it reads its inputs (mz_warm_start).  Runs that end before that
+    # thread has finished -- files without a common contig, and a command line in error -- must still end cleanly, with the
+    # stock binary's bytes and exit status, and never under a thread that is inside the HIP runtime.
+    rng = np.random.default_rng(99)
+    for name, f, tag in (("ref.chrA", "a.maf", "p"), ("ref.chrB", "b.maf", "q")):
+        ref = inputs.ACGT[rng.integers(0, 4, size=6 * 260 + 300)]
+        bl = inputs.random_maf_file(rng, ref, 5, 2, tag)
+        for blk in bl:
+            blk.rows[0].src = name
+        inputs.write_maf(str(tmp_path / f), bl)
+    for rep in range(5):                                   # (a race, if there is one, needs more than one try)
+        d = tmp_path / f"run{rep}"
+        d.mkdir()
+        for f in ("a.maf", "b.maf"):
+            os.link(str(tmp_path / f), str(d / f))
+        both(d, ["../a.maf", "../b.maf", "1", "u1", "u2"], ("u1", "u2"))
+    d = tmp_path / "usage"
+    d.mkdir()
+    want = run(REF_BIN, ["../a.maf"], str(d), "ref", ())
+    got = run(OUR_BIN, ["../a.maf"], str(d), "gpu", ())
+    assert got[1] == want[1] == 1 and got[0] == want[0]
+
+
 def test_reader_oddities(tmp_path):
     # comment lines (echoed by the stock reader), i/e/q lines (skipped), amplifier=/copy= tags on the "a" line,
     # tabs and extra blanks, lowercase and N bases, a trailing block without a final blank line
