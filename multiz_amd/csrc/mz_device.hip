@@ -333,7 +333,10 @@ extern "C" int mzk_plan(const mz_dev_batch *b, void *stream)
 {
     if (b->n <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_plan, dim3(b->n), dim3(WAVE), 0, s, *b);
+    // few pairs: long pairs as likely as not -- their rows in PLAN_SEGS stretches first (kernels/plan.inc)
+    const int folded = b->n <= MZ_PLAN_FOLD_MAX;
+    if (folded) hipLaunchKernelGGL(k_plan_seg, dim3(b->n, PLAN_SEGS), dim3(WAVE), 0, s, *b);
+    hipLaunchKernelGGL(k_plan, dim3(b->n), dim3(WAVE), 0, s, *b, folded);
     {
         const int nblk = (b->n + SCAN_B - 1) / SCAN_B;
         hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_B), 0, s, *b);

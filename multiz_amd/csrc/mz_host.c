@@ -440,7 +440,7 @@ size_t mz_dev_plan_bytes(int n)
     s += 5 * mzi_al256(4 * N);                 /* status, badrow, mode, edgeLo, edgeHi */
     s += 9 * mzi_al256(8 * N);                 /* cells, 4 sizes, 4 offsets */
     s += mzi_al256(8 * MZ_TOTALS);             /* totals */
-    s += mzi_al256(4 * N) + mzi_al256((8 * 8 + 4 * 128) * (N / 64 + 2));    /* packList, scanAux (8 sums and 128 list keys per 64 pairs) */
+    s += mzi_al256(4 * N) + mzi_al256(MZ_SCAN_AUX_BYTES(N));    /* packList, scanAux (8 sums and 128 list keys per 64 pairs; the plan's segment results of small batches) */
     s += mzi_al256(4 * N) + mzi_al256(12 * N);     /* om, final3 */
     return s;
 }
@@ -456,7 +456,7 @@ void mz_dev_carve(mz_dev_batch *b, void *mem)
     TAKE(szTb, int64_t *, 8 * N); TAKE(szScript, int64_t *, 8 * N); TAKE(szOut, int64_t *, 8 * N); TAKE(szPrep, int64_t *, 8 * N);
     TAKE(offTb, int64_t *, 8 * N); TAKE(offScript, int64_t *, 8 * N); TAKE(offOut, int64_t *, 8 * N); TAKE(offPrep, int64_t *, 8 * N);
     TAKE(totals, int64_t *, 8 * MZ_TOTALS);
-    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, (8 * 8 + 4 * 128) * (N / 64 + 2));
+    TAKE(packList, int32_t *, 4 * N); TAKE(scanAux, int64_t *, MZ_SCAN_AUX_BYTES(N));
     TAKE(om, int32_t *, 4 * N); TAKE(final3, int32_t *, 12 * N);
 #undef TAKE
 }
