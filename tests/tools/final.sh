@@ -4,6 +4,9 @@ export TMPDIR=/tmp
 TAG=${1:-r3}
 O=gpurun_out/${TAG}_final; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/gputests.txt 2>&1; tail -3 $O/gputests.txt
+# the counters first: bench.py reads profiles/<tag>_pmc.json (roofline.traffic / roofline.valu) and marks it stale when the device sources changed
+timeout 1500 python tests/tools/pmc_collect.py ${TAG} c2 c3 c4 c5 c2i > $O/pmc_collect.txt 2>&1; tail -6 $O/pmc_collect.txt
+cp gpurun_out/${TAG}/${TAG}_pmc.json profiles/${TAG}_pmc.json
 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err
 for c in c3 c4 c5 c2i c4i c2w c2s; do python bench.py --config $c --steps 30 > $O/${TAG}_bench_$c.json 2> $O/bench_$c.err; done
 python - "$O" "$TAG" <<'PY'
@@ -15,4 +18,3 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json
     except Exception as e:
         print(f, "unreadable", e)
 PY
-timeout 1500 python tests/tools/pmc_collect.py ${TAG} c2 c3 c4 c5 c2i > $O/pmc_collect.txt 2>&1; tail -6 $O/pmc_collect.txt
