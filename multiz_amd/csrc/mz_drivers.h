@@ -29,7 +29,6 @@ static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MON
 /* mz_mafio.c */
 struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE *echo);
 struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name);
-struct mafAli *mz_maf_read_own(const char *text, size_t len, const char *name, int threads);   /* text rendered by this library: parsed in pieces, side by side */
 /* mz_project.c */
 struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others);
 /* mz_multic.c */

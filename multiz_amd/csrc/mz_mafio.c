@@ -180,57 +180,6 @@ struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name)
     return list;
 }
 
-/* The same for text this library rendered itself (the in-process tree driver's intermediate alignments: well formed, every
- * block closed by an empty line): cut at block boundaries into pieces that are parsed side by side and joined in order.
- * Text from outside goes through mz_maf_read_mem() -- one reader, the reference's messages with the reference's line numbers. */
-struct mafAli *mz_maf_read_own(const char *text, size_t len, const char *name, int threads)
-{
-    enum { MAXP = 16 };
-    const char *cut[MAXP + 1];
-    struct mafAli *head[MAXP], *tail[MAXP], *first = NULL, *last = NULL;
-    const char *body, *end = text + len;
-    int np, k, version;
-    if (threads > MAXP) threads = MAXP;
-    if (threads < 2 || len < ((size_t)1 << 20)) return mz_maf_read_mem(text, len, name);
-    if (sscanf(text, "##maf version=%d", &version) != 1) return mz_maf_read_mem(text, len, name);
-    body = (const char *)memchr(text, '\n', len);
-    if (!body) return mz_maf_read_mem(text, len, name);
-    ++body;
-    cut[0] = body;
-    for (np = 1; np < threads; ++np) {                     /* the first "\n\na " at or after the np-th share of the body */
-        const char *p = body + (size_t)(end - body) / (size_t)threads * (size_t)np, *q = NULL;
-        if (p < cut[np - 1]) p = cut[np - 1];
-        for (; p + 3 < end; ++p)
-            if (p[0] == '\n' && p[1] == '\n' && p[2] == 'a' && p[3] == ' ') { q = p + 2; break; }
-        if (!q) break;
-        cut[np] = q;
-    }
-    cut[np] = end;
-#pragma omp parallel for schedule(static, 1) num_threads(np)
-    for (k = 0; k < np; ++k) {
-        maf_in in;
-        struct mafAli *a;
-        head[k] = tail[k] = NULL;
-        if (cut[k + 1] <= cut[k]) continue;
-        memset(&in, 0, sizeof in);
-        in.name = name;
-        in.fp = fmemopen((void *)cut[k], (size_t)(cut[k + 1] - cut[k]), "r");
-        if (!in.fp) mz_fatalf("Cannot open %s.", name);
-        while ((a = maf_next(&in)) != NULL) {
-            if (tail[k]) tail[k]->next = a; else head[k] = a;
-            tail[k] = a;
-        }
-        free(in.line);
-        fclose(in.fp);
-    }
-    for (k = 0; k < np; ++k)
-        if (head[k]) {
-            if (last) last->next = head[k]; else first = head[k];
-            last = tail[k];
-        }
-    return first;
-}
-
 /* ------------------------------------------------------------------------------------------------ list helpers */
 
 struct mafAli *mz_pop_first(struct mafAli **head)

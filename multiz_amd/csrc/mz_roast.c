@@ -24,7 +24,6 @@
  */
 #include "mz_drivers.h"
 #include <ctype.h>
-#include <omp.h>
 
 #define ROAST_VERSION 3
 #define MAX_NODES 2000
@@ -41,7 +40,6 @@ typedef struct rnode {
     struct mz_mzrun *run;
     struct mafAli *l1, *l2;
     buf left_in, right_in;
-    int own_in[2];               /* the input is a child node's result (text this program rendered), not a leaf file */
     int both_leaves;
 } rnode;
 
@@ -229,7 +227,6 @@ static void node_inputs(rnode *nd)
         nd->done = 1;
         return;
     }
-    nd->own_in[0] = x->nnames != 1; nd->own_in[1] = y->nnames != 1;
     if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); }
     if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); }
     if (!left.p) mz_fatalf("Cannot open %s.", "left.maf");
@@ -243,10 +240,7 @@ static void node_inputs(rnode *nd)
 static void node_parse(rnode *nd, int side)
 {
     buf *in = side ? &nd->right_in : &nd->left_in;
-    /* (a child's result is this program's own text: parsed in pieces side by side -- the late rounds have one node and two
-     * inputs of tens of MB; a leaf file goes through the one reader with the stock messages) */
-    struct mafAli *l = mz_project_lists(nd->own_in[side] ? mz_maf_read_own(in->p, in->n, side ? "right.maf" : "left.maf", 8)
-                                                         : mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
+    struct mafAli *l = mz_project_lists(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
     if (side) nd->l2 = l; else nd->l1 = l;
     buf_free(in);
 }
@@ -367,7 +361,6 @@ int mz_roast_main(int argc, char **argv)
 
     mz_tune_malloc();
     init_scores70();
-    omp_set_max_active_levels(2);                        /* (node_parse: pieces of one input inside the round's tasks) */
     mz_warm_start();                                     /* the GPU starts up while the inputs are read */
     root = parse_tree(argv[1]);
     if (!T.execute) {                                     /* "-": show the plan */
