@@ -58,16 +58,25 @@ def pmc_record(config, pairs, kernel):
     tests/tools/pmc_collect.py: separate rocprofv3 --pmc passes, FETCH_SIZE doubled as the guide prescribes for gfx950).
     Measured, never estimated; "stale": the device sources have changed since they were collected."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    for f in reversed(files):
+    import re
+
+    def round_of(f):                                   # r10 after r9 (a plain sort puts "r10" before "r3")
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        return (int(m.group(1)) if m else -1, os.path.basename(f))
+    cur, found = sources_hash(), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), key=round_of, reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
         r = d.get("records", {}).get(f"{config}:{pairs}", {}).get(kernel)
-        if r and "SQ_INSTS_VALU" in r:
-            return dict(r, source=os.path.relpath(f, ROOT), stale=d.get("sources_hash") != sources_hash())
-    return None
+        if not r or "SQ_INSTS_VALU" not in r or r.get("incomplete"):
+            continue
+        rec = dict(r, source=os.path.relpath(f, ROOT), stale=d.get("sources_hash") != cur)
+        if not rec["stale"]:
+            return rec                                 # a record of the current device sources wins over a newer stale one
+        found = found or rec
+    return found
 
 
 def spawn_ranks(args):

@@ -40,7 +40,9 @@ typedef struct chunk {
     double t_pack0, t_pack1, t_launch0, t_launch1, t_launch2, t_col0, t_col1, t_col2;
 } chunk;
 
-static int job_ok(const mz_job *j) { return j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1 && j->K <= 255 && j->L <= 255; }
+/* a job whose arrays the host may read: the packing loops run before the device's validity prologue (a NULL array is a
+ * shape error of the call, MZ_E_SHAPE: the plan sees M = 0) */
+static int job_ok(const mz_job *j) { return j->K >= 1 && j->L >= 1 && j->M >= 1 && j->N >= 1 && j->K <= 255 && j->L <= 255 && j->A && j->B && j->LB && j->RB; }
 /* (K, L > 255: the plan refuses the pair (MZ_E_ROWS) from K and L alone; its columns do not travel) */
 
 /* expanded bytes of a block's columns on the device: whole 64-byte groups, so that the class nibbles of a pair fill
@@ -115,7 +117,7 @@ static void pack_exceptions(void *ctx, int lo, int hi)
     }
 }
 
-static int g_timing = -1;                  /* MZ_TIMING: 1 = one JSON line per call, 2 = and one per chunk (stderr) */
+static int g_timing = -1;                  /* mzi_timing(): 1 = one JSON line per call, 2 = and one per chunk (stderr) */
 #define TSTAMP(X, set, k, st) do { if (g_timing >= 2 && (X)->btime_ready) HIPCK(hipEventRecord((X)->btime[set][k], st)); } while (0)
 
 static int up_prio(void)                   /* MZ_UP_PRIO=1: upload + expansion + plan on a high-priority stream per set.  Off by default: measured
@@ -206,7 +208,8 @@ static int chunk_upload(mz_ctx *X, chunk *c, int index, int set, int n, const mz
         for (p = 0; p < n; ++p) {                            /* offsets first ... */
             const mz_job *j = &jobs[p];
             const int ok = job_ok(j);
-            hK[p] = j->K; hL[p] = j->L; hM[p] = j->M; hN[p] = j->N;
+            const int nul = !j->A || !j->B || !j->LB || !j->RB;                 /* (reported as MZ_E_SHAPE: the plan sees M = N = 0) */
+            hK[p] = j->K; hL[p] = j->L; hM[p] = nul ? 0 : j->M; hN[p] = nul ? 0 : j->N;
             hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
             hLen[p] = ok ? j->M + 1 : 1;
             hLB0[p] = ok ? j->LB[0] : 0; hRB0[p] = ok ? j->RB[0] : 0;         /* (an invalid job: one dummy entry, LB[0] = RB[0] = 0) */
@@ -676,7 +679,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     batch_stats st = { 0, 0, 0 };
     double t_call = mzi_now_s();
     if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
-    if (g_timing < 0) { const char *e = getenv("MZ_TIMING"); g_timing = e ? (atoi(e) > 0 ? atoi(e) : 1) : 0; }
+    if (g_timing < 0) g_timing = mzi_timing();
     if (n <= 0) return 0;
     for (p = 0; outs && p < n; ++p) {                    /* "not computed" until a chunk says otherwise */
         outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL;

@@ -92,6 +92,7 @@ MZ_INTERNAL int mzi_lazy_stream(hipStream_t *s);
 MZ_INTERNAL int mzi_ensure_init(void);
 extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_warm_start(): its batch prints no MZ_TIMING line */
 MZ_INTERNAL int mzi_sync_scores(void);
+MZ_INTERNAL int mzi_timing(void);                       /* MZ_TIMING, parsed once: 0 quiet, 1 per call, 2 per chunk */
 MZ_INTERNAL void mzi_workers_stop(mz_ctx *X);           /* mz_batch.c: ctx_close() ends the context's helper threads */
 
 /* mz_pool.c: the host threads of the batch pipeline (no OpenMP there: see the file), recycled result blocks */

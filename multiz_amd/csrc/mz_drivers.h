@@ -23,7 +23,8 @@ extern char *argv0;
 #define MZ_STAGE_THREADS 32     /* host threads of the per-merge stages (allocation-heavy: more does not help) */
 #define MERGE_FAILED 99         /* merge state: yama() refused the job (beside the MZ_PY_* states) */
 
-/* MZ_TIMING=1: phase times of a run on stderr */
+/* MZ_TIMING=1: phase times of a run on stderr (mz_host.c: parsed once; "0" is quiet) */
+__attribute__((visibility("hidden"))) int mzi_timing(void);
 static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 /* mz_mafio.c */

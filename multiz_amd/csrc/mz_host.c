@@ -40,9 +40,29 @@ int mzi_set_err(const char *fmt, ...)
 int mz_scores_explicit;                  /* set by mz_set_scores(), cleared by init_scores70/85() */
 
 void mz_warm_wait(void);
+
+/* MZ_TIMING in the environment, parsed once: unset or "0" = quiet, 1 = one JSON line per call, 2 = and one per chunk;
+ * a value that is not a number (MZ_TIMING=yes) counts as 1 */
+int mzi_timing(void)
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MZ_TIMING");
+        char *end = NULL;
+        long x = e ? strtol(e, &end, 10) : 0;
+        v = !e ? 0 : (end == e ? 1 : x < 0 ? 0 : x > 9 ? 9 : (int)x);
+    }
+    return v;
+}
+
+/* One caller at a time, and only one ever gets to exit(): the drivers' worker threads (OpenMP regions of mz_roast.c /
+ * mz_multiz.c) can fail together; exit() runs the atexit handlers once, the later callers wait here for the process to
+ * end. */
+static pthread_mutex_t g_fatal_mu = PTHREAD_MUTEX_INITIALIZER;
 __attribute__((noreturn)) void mz_fatalf(const char *fmt, ...)
 {
     va_list ap;
+    pthread_mutex_lock(&g_fatal_mu);                   /* (never released: the winner exits) */
     va_start(ap, fmt);
     mz_warm_wait();                                    /* no thread of ours inside the HIP runtime while the process exits */
     fflush(stdout);
@@ -263,13 +283,14 @@ static void *warm_main(void *arg)
 }
 void mz_warm_wait(void)
 {
-    if (g_warm_on && !mzi_warm_thread) { g_warm_on = 0; pthread_join(g_warm_th, NULL); }
+    /* one joiner: whoever takes the flag down (mz_fatalf() from a worker thread and the atexit handler may both come by) */
+    if (!mzi_warm_thread && __atomic_exchange_n(&g_warm_on, 0, __ATOMIC_ACQ_REL)) pthread_join(g_warm_th, NULL);
 }
 void mz_warm_start(void)
 {
-    if (g_warm_on || g_ndev) return;
+    if (__atomic_load_n(&g_warm_on, __ATOMIC_ACQUIRE) || g_ndev) return;
     if (pthread_create(&g_warm_th, NULL, warm_main, NULL) != 0) return;      /* (no thread: the first call starts the GPU as ever) */
-    g_warm_on = 1;
+    __atomic_store_n(&g_warm_on, 1, __ATOMIC_RELEASE);
     atexit(mz_warm_wait);                                /* a run that never gets to a batch must not exit under the thread (the
                                                           * drivers also wait before they return from main) */
 }
@@ -785,7 +806,7 @@ static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs
         }
     }
     if (oom) return mzi_set_err("out of memory for the merged rows");
-    if (getenv("MZ_TIMING"))
+    if (mzi_timing())
         fprintf(stderr, "{\"mz_preyama_batch_pass\": {\"merges\": %d, \"two_stage\": %d, \"bytes_up\": %zu, \"bytes_down\": %zu}}\n",
                 n, any0, in_bytes, res_bytes);
     return failed;

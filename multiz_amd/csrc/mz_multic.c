@@ -271,7 +271,7 @@ int mz_multic_lists(struct mafAli **list1, struct mafAli **list2, int v, int rad
             free(list);
         }
     }
-    if (getenv("MZ_TIMING"))
+    if (mzi_timing())
         fprintf(stderr, "mz_multic: enumerate %.3f s (%d merges), stages + yama batches %.3f s, replay + unused parts %.3f s\n",
                 tm[2] - tm[1], R.nmg, tm[3] - tm[2], mz_now_s() - tm[3]);
     free(R.mg); free(R.ct);
@@ -329,7 +329,7 @@ int mz_multic_main(int argc, char **argv)
     l1 = mz_maf_read_all(argv[1], 1);
     l2 = mz_maf_read_all(argv[2], 1);
     tm[1] = mz_now_s();
-    if (getenv("MZ_TIMING")) fprintf(stderr, "mz_multic: read %.3f s\n", tm[1] - tm[0]);
+    if (mzi_timing()) fprintf(stderr, "mz_multic: read %.3f s\n", tm[1] - tm[0]);
 
     mz_multic_lists(&l1, &l2, v, radius, minw, align_cate, stdout, fpw[0], fpw[1]);
     for (a = l1; a; a = a->next)                            /* contigs that only one file has */

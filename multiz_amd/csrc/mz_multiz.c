@@ -377,7 +377,7 @@ static void run_merges(record **RR, int nrec, int minw)
     mz_out *outs;
     int *who;
     mref *all;
-    const int timing = getenv("MZ_TIMING") != NULL;
+    const int timing = mzi_timing() != 0;
     double t0 = mz_now_s(), t1;
     for (r = 0; r < nrec; ++r) nmg += RR[r]->nmg;
     jobs = (mz_job *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(mz_job));
@@ -516,7 +516,7 @@ void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2)
 int mz_multiz_lists(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
                     FILE *out, FILE *out1, FILE *out2)
 {
-    const int timing = getenv("MZ_TIMING") != NULL;
+    const int timing = mzi_timing() != 0;
     const double t0 = mz_now_s();
     double t1, t2;
     struct mz_mzrun *run = mz_multiz_prepare(list1, list2, v, radius, min_output_wid, out1 != NULL, out2 != NULL);
@@ -585,7 +585,7 @@ int mz_multiz_main(int argc, char **argv)
         t1 = mz_now_s();
         mz_multiz_lists(&l1, &l2, v, radius, minw, stdout, f1, f2);
         t2 = mz_now_s();
-        if (getenv("MZ_TIMING")) fprintf(stderr, "mz_multiz: read %.3f s, walk + merges + replay %.3f s\n", t1 - t0, t2 - t1);
+        if (mzi_timing()) fprintf(stderr, "mz_multiz: read %.3f s, walk + merges + replay %.3f s\n", t1 - t0, t2 - t1);
     }
 
     for (a = l1; a; a = a->next)                            /* contigs that only one file has */

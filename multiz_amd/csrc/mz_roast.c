@@ -421,7 +421,7 @@ int mz_roast_main(int argc, char **argv)
     }
     fprintf(dst, "##eof maf\n");
     fclose(dst);
-    if (getenv("MZ_TIMING"))
+    if (mzi_timing())
         fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s (reading leaves %.3f, final projection %.3f, parsing + projecting the inputs %.3f, "
                 "list walks %.3f, alignment batches with their host stages %.3f, replay + rendering + line filters %.3f)\n",
                 T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5]);

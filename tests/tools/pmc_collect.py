@@ -37,8 +37,28 @@ def sources_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def run(cmd, env):
-    subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+PY = os.path.realpath(sys.executable)      # the interpreter binary itself after `--`: no PATH shim, no exec hop behind the profiler
+
+
+def run(cmd, env, log):
+    """one profiler pass in its own process group; True when it ended with status 0 (output kept in `log`)"""
+    import signal
+    with open(log, "ab") as lf:
+        lf.write((" ".join(cmd) + "\n").encode())
+        lf.flush()
+        p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=lf, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            rc = p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)       # the profiler AND the profiled python
+            except ProcessLookupError:
+                pass
+            p.wait()
+            lf.write(b"TIMEOUT\n")
+            return False
+        lf.write(f"exit {rc}\n".encode())
+        return rc == 0
 
 
 def main():
@@ -54,9 +74,11 @@ def main():
         key = f"{cfg}:{pairs}"
         k = collections.defaultdict(dict)
         d = os.path.join(out, f"stats_{cfg}")
-        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
-             "python3", "bench.py", "--config", cfg, "--steps", "20", "--warmup", "3", "--no-cpu", "--no-host"], env)
+        log = os.path.join(out, f"log_{cfg}.txt")
+        complete = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--",
+             PY, "bench.py", "--config", cfg, "--steps", "20", "--warmup", "3", "--no-cpu", "--no-host"], env, log)
         fs = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
+        complete = complete and bool(fs)
         if fs:
             os.replace(fs[0], os.path.join(out, f"{tag}_kernel_stats_{cfg}.csv"))
             for row in csv.DictReader(open(os.path.join(out, f"{tag}_kernel_stats_{cfg}.csv"))):
@@ -66,10 +88,11 @@ def main():
                     k[name]["min_ns"] = float(row["MinNs"]); k[name]["max_ns"] = float(row["MaxNs"])
         for g in GROUPS:
             d = os.path.join(out, f"pmc_{cfg}_" + g.replace(" ", "_")[:40])
-            run(["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["--output-format", "csv", "-d", d, "--",
-                 "python3", "bench.py", "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host"], env)
+            ok = run(["rocprofv3", "--kernel-trace", "--pmc"] + g.split() + ["--output-format", "csv", "-d", d, "--",
+                      PY, "bench.py", "--config", cfg, "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host"], env, log)
             fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-            if not fs:
+            if not ok or not fs:
+                complete = False
                 continue
             acc, cnt = collections.defaultdict(float), collections.Counter()
             for row in csv.DictReader(open(fs[0])):
@@ -83,10 +106,17 @@ def main():
                 r["traffic_bytes"] = (2 * r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]) * 1024
             if "GRBM_GUI_ACTIVE" in r and "avg_ns" in r:
                 r["clock_ghz"] = round(r["GRBM_GUI_ACTIVE"] / 8.0 / r["avg_ns"], 3)
+        if not complete:                               # a failed or timed-out pass: the record says so and bench.py skips it
+            for r in k.values():
+                r["incomplete"] = True
+            rec.setdefault("incomplete", []).append(key)
         rec["records"][key] = dict(k)
         json.dump(rec, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
         print(key, {n: {c: v for c, v in r.items() if c in ("avg_ns", "SQ_INSTS_VALU", "traffic_bytes", "clock_ghz")} for n, r in k.items() if n.startswith("k_dp")})
 
 
+    return 1 if rec.get("incomplete") else 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
