@@ -37,6 +37,14 @@
 extern "C" {
 #endif
 
+/* Layout / ownership version of the additive batch API below (mz_job, mz_out, mz_prejob, mz_preout): bumped whenever a
+ * struct of this header changes size or the owner of a result changes, so that a caller built against another
+ * revision fails to compile (#if MZ_AMD_ABI != ...) instead of corrupting its heap.
+ *   2 (round 3): mz_out gained `block`; `cols` points into it (free with mz_free_outs(), not free(cols), unless n == 1)
+ *   3 (round 4): mz_preout gained `block`; `rows` / `size` point into it (free with mz_free_preouts(), not free(rows)) */
+#define MZ_AMD_ABI 3
+int mz_abi_version(void);                  /* MZ_AMD_ABI of the library that is loaded */
+
 #define MZ_NEG      (-1073741824)          /* reference mz_yama.c:29, INT_MIN/2 */
 #define MZ_BIG      (0x3fffffff)
 #define MZ_FC 0                            /* reference mz_yama.c:24-26 */
@@ -232,11 +240,15 @@ void mz_free_outs(int n, mz_out *outs);
  * N independent merges -- pre_yama(a1, a2, beg, end, radius, v, ...) of reference mz_preyama.c:152-359: one stage
  * (v = 1, :152-262) or two (v = 0: the first block's top row sits the first yama() out and is aligned against its
  * result by a second one whose band comes from mapping(), :265-336, the reference's two defects there included) --
- * given as the TEXT of the two blocks over their overlap.  Everything between the text and the text happens on
- * the GPU (kernels/prepost.inc around the DP): column packing, removal of all-dash columns (rmColDash), the band from
- * the shared reference row and smooth(), yama() itself, the merged columns back to rows with their base counts and
- * mafScoreRange() of the block that mafBuild() would assemble (rows without a base left out).  The caller keeps
- * what only it knows: names, strands and start coordinates of the rows. */
+ * given as the TEXT of the two blocks over their overlap.  Everything between the text and the text that needs the
+ * alignment happens on the GPU (kernels/prepost.inc around the DP): column packing, removal of all-dash columns
+ * (rmColDash), the band from the shared reference row and smooth(), yama() itself -- both of them for v = 0 --, the base
+ * counts and mafScoreRange() of the block that mafBuild() would assemble (rows without a base left out).  What crosses
+ * the PCIe link is the byte CLASSES of the text (two per byte: the DP and the score only distinguish A/a C/c G/g T/t,
+ * '-' and "other") and, back, a record, the base counts and a few bits per merged column; the merged block's ROWS are
+ * put together on the host from the caller's own text (which must stay valid until the call returns), on the
+ * library's host threads, a chunk of the call at a time while the GPU works on the next ones.  The caller keeps what
+ * only it knows: names, strands and start coordinates of the rows. */
 typedef struct mz_prejob {
     int K;                        /* rows of the first block, its top row included (v = 0 needs K >= 2: with
                                      nothing below the top row pre_yama() returns NULL after writing the second
@@ -259,13 +271,21 @@ typedef struct mz_preout {
     int M, N;                     /* yama()'s M and N (after the dash columns went)                         */
     int OM;                       /* columns of the merged block                                            */
     double score;                 /* mafScoreRange(block, 0, OM) over the rows that keep a base             */
-    const int *size;              /* bases per row, K + L entries (inside the `rows` allocation)            */
-    unsigned char *rows;          /* malloc()ed, caller frees: K + L rows of OM bytes, row after row        */
+    const int *size;              /* bases per row, K + L entries (inside `block`, behind the rows)         */
+    unsigned char *rows;          /* K + L rows of OM bytes, row after row; NULL without a block.  Inside `block` of
+                                     this or an earlier entry of the call -- not a heap pointer of its own   */
+    void *block;                  /* non-NULL on the first merge of each chunk of the call: ONE malloc()ed block holding
+                                     the rows and base counts of that chunk's merges (mz_free_preouts())     */
 } mz_preout;
 
 /* Returns the number of pairs without a block (refused or NULL), -1 on a device error, -2 when the current score
- * tables lack the structure the device form of mafScoreRange() needs (symmetric classes): use the host path then. */
+ * tables lack the structure the device form of mafScoreRange() needs (symmetric classes): use the host path then.
+ * MZ_TIMING=1: one JSON line per call on stderr (merges, band cells, seconds, GCUPS, link bytes); 2: and one per chunk. */
 int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs);
+/* free the result blocks of a finished call (all n entries of it) and reset rows / size / block to NULL */
+void mz_free_preouts(int n, mz_preout *outs);
+/* bytes the last mz_preyama_batch() call moved over the PCIe link: to the device(s), and back; band cells it computed */
+void mz_pre_link_bytes(int64_t *up, int64_t *down, int64_t *cells);
 
 /* ---------------------------------------------------------------- device-resident API */
 

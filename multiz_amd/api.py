@@ -202,7 +202,7 @@ class PreJob(C.Structure):
 
 class PreOut(C.Structure):
     _fields_ = [("status", C.c_int), ("badrow", C.c_int), ("null_result", C.c_int), ("stage", C.c_int), ("M", C.c_int), ("N", C.c_int),
-                ("OM", C.c_int), ("score", C.c_double), ("size", C.POINTER(C.c_int)), ("rows", C.c_void_p)]
+                ("OM", C.c_int), ("score", C.c_double), ("size", C.POINTER(C.c_int)), ("rows", C.c_void_p), ("block", C.c_void_p)]
 
 
 def preyama_batch(jobs: Sequence[tuple]):
@@ -232,8 +232,10 @@ def preyama_batch(jobs: Sequence[tuple]):
             d["size"] = [o.size[k] for k in range(W)]
             raw = C.string_at(o.rows, W * o.OM)
             d["rows"] = [raw[k * o.OM:(k + 1) * o.OM] for k in range(W)]
-            lib().free_cols(o.rows)
         out.append(d)
+    fr = lib().mz_free_preouts
+    fr.argtypes = [C.c_int, C.POINTER(PreOut)]
+    fr(n, co)                                        # the call's result blocks (one per chunk: mz_preout.block)
     return out
 
 

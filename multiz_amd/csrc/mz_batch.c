@@ -440,9 +440,18 @@ static void chunk_report(const mz_pipe *P, const chunk *c)
             since0, g[0], g[1], g[2], g[3], g[4]);
 }
 
-/* stage 2: for chunk k = 0, 1, ...: wait until it is uploaded, wait for its plan, issue its kernels */
-static void launcher_main(mz_pipe *P)
+static void stage_done(mz_pipe *P)          /* the last thing a stage does with the pipe: the caller may free it at once */
 {
+    pthread_mutex_lock(&P->mu);
+    P->done++;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+
+/* stage 2: for chunk k = 0, 1, ...: wait until it is uploaded, wait for its plan, issue its kernels */
+static void launcher_main(void *arg)
+{
+    mz_pipe *P = (mz_pipe *)arg;
     int k;
     hipSetDevice(P->X->device);
     for (k = 0;; ++k) {
@@ -456,11 +465,13 @@ static void launcher_main(mz_pipe *P)
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
     }
+    stage_done(P);
 }
 
 /* stage 3: wait for the results of chunk k, assemble its merged columns, free its buffer set */
-static void collector_main(mz_pipe *P)
+static void collector_main(void *arg)
 {
+    mz_pipe *P = (mz_pipe *)arg;
     int k;
     hipSetDevice(P->X->device);
     for (k = 0;; ++k) {
@@ -479,69 +490,14 @@ static void collector_main(mz_pipe *P)
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
     }
+    stage_done(P);
 }
 
-/* persistent helper threads: their OpenMP teams are built once, not once per call */
-static void *worker_main(void *arg)
-{
-    mz_worker *w = (mz_worker *)arg;
-    for (;;) {
-        mz_pipe *P;
-        pthread_mutex_lock(&w->mu);
-        while (!w->quit && !w->job) pthread_cond_wait(&w->cv, &w->mu);
-        if (w->quit) { pthread_mutex_unlock(&w->mu); break; }
-        P = w->job;
-        pthread_mutex_unlock(&w->mu);
-        w->fn(P);
-        pthread_mutex_lock(&w->mu);
-        w->job = NULL;                                   /* free for the next call BEFORE this one is told: it may return at once */
-        pthread_mutex_unlock(&w->mu);
-        pthread_mutex_lock(&P->mu);
-        P->done++;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-    return NULL;
-}
-
-static int workers_start(mz_ctx *X)
-{
-    int i;
-    for (i = 0; i < 2; ++i) {
-        mz_worker *w = &X->worker[i];
-        if (w->started) continue;
-        pthread_mutex_init(&w->mu, NULL);
-        pthread_cond_init(&w->cv, NULL);
-        w->quit = 0; w->job = NULL;
-        if (pthread_create(&w->th, NULL, worker_main, w) != 0) { pthread_mutex_destroy(&w->mu); pthread_cond_destroy(&w->cv); return -1; }
-        w->started = 1;
-    }
-    return 0;
-}
-
-static void worker_give(mz_worker *w, void (*fn)(mz_pipe *), mz_pipe *P)
-{
-    pthread_mutex_lock(&w->mu);
-    w->fn = fn; w->job = P;
-    pthread_cond_signal(&w->cv);
-    pthread_mutex_unlock(&w->mu);
-}
-
+/* the two helper threads of a context are persistent (mz_pool.c: mzi_workers_start / mzi_worker_give) */
 void mzi_workers_stop(mz_ctx *X)
 {
-    int i;
-    for (i = 0; i < 2; ++i) {
-        mz_worker *w = &X->worker[i];
-        if (!w->started) continue;
-        pthread_mutex_lock(&w->mu);
-        w->quit = 1;
-        pthread_cond_signal(&w->cv);
-        pthread_mutex_unlock(&w->mu);
-        pthread_join(w->th, NULL);
-        pthread_mutex_destroy(&w->mu);
-        pthread_cond_destroy(&w->cv);
-        w->started = 0;
-    }
+    mzi_workers_end(X->worker, 2);
+    mzi_workers_end(X->pworker, 3);
 }
 
 /* what a pair weighs in the cutting of chunks: its input bytes as the caller holds them */
@@ -600,7 +556,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
     /* one chunk: the three steps inline (no thread is woken for a single yama() call); also when no thread can be had */
-    threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n && workers_start(X) == 0;
+    threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n && mzi_workers_start(X->worker, 2) == 0;
     if (!threaded) {
         while (up < n) {
             chunk *c = &P->ck[0];
@@ -613,8 +569,8 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
         }
         if (rc >= 0) rc = P->failed;
     } else {
-        worker_give(&X->worker[0], launcher_main, P);
-        worker_give(&X->worker[1], collector_main, P);
+        mzi_worker_give(&X->worker[0], launcher_main, P);
+        mzi_worker_give(&X->worker[1], collector_main, P);
         /* stage 1 here: cut, pack, upload, plan.  The first chunk is a half-size one: the GPU starts that much earlier. */
         while (up < n) {
             const int first_half = k == 0 && (max_pairs >= 2048 || max_bytes >= ((size_t)32 << 20));

@@ -13,12 +13,20 @@
 #include "mz_device.h"
 
 #define MZ_INTERNAL __attribute__((visibility("hidden")))
+#define MZ_INTERNAL_DECL __attribute__((visibility("hidden")))
 
 typedef struct gbuf { void *p; size_t cap; } gbuf;
 
 #define MZ_SLICES 4                        /* (number of helper events) */
 #define MZ_SETS 10                         /* buffer sets of the chunk pipeline (mz_batch.c): being packed, uploading + planning,
                                             * computing, copying back, being unpacked -- and one of slack */
+/* mz_preyama_batch()'s own buffers of a set.  Device: staging image (header + class nibbles), text expanded to a byte per class, the
+ * pools A / B of the first stage, its band pools, k_pre's scratch, per-merge arrays of both stages, merged columns of the first and of
+ * the second stage, the second stage's A pool (top rows), band pools, plan arrays and workspaces, results.  Pinned host: staging,
+ * results, the second plan's totals. */
+enum { MZ_PD_IN, MZ_PD_TXT, MZ_PD_COLS, MZ_PD_BAND, MZ_PD_SCR, MZ_PD_META, MZ_PD_OUT1, MZ_PD_OUT2, MZ_PD_A2, MZ_PD_BAND2, MZ_PD_PLAN2, MZ_PD_TB2,
+       MZ_PD_SCRIPT2, MZ_PD_PREP2, MZ_PD_RES, MZ_PD_N };
+enum { MZ_PH_IN, MZ_PH_RES, MZ_PH_TOT2, MZ_PH_N };
 #define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
 #define MZ_MAX_DEV 16
 #define MZ_MULTI_MIN 2048                  /* pairs per GPU below which dealing a batch out is not worth a thread */
@@ -34,9 +42,15 @@ typedef struct mz_worker {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     int started, quit, busy;
-    void (*fn)(struct mz_pipe *);
-    struct mz_pipe *job;
+    void (*fn)(void *);
+    void *job;
 } mz_worker;
+
+/* mz_pool.c: start the helper threads w[0..n) (idempotent; -1 when a thread cannot be had), hand one a job -- fn(job) runs on it; the
+ * worker is free again when fn returns, and mzi_worker_give() waits for that --, end them */
+MZ_INTERNAL_DECL int mzi_workers_start(mz_worker *w, int n);
+MZ_INTERNAL_DECL void mzi_worker_give(mz_worker *w, void (*fn)(void *), void *job);
+MZ_INTERNAL_DECL void mzi_workers_end(mz_worker *w, int n);
 
 /* Everything the library holds on ONE GPU.  g_dev[0] is the primary context: the device-resident API (mz_dev_*)
  * and single-GPU runs live there.  mz_init_multi() / MZ_NGPU add contexts on further GPUs, each driven by its own
@@ -62,8 +76,11 @@ typedef struct mz_ctx {
      *   d_res / h_res  results: header, a record per pair, the packed edit scripts */
     gbuf h_in[MZ_SETS], d_in[MZ_SETS], h_exc[MZ_SETS], d_exc[MZ_SETS], d_cols[MZ_SETS], d_band[MZ_SETS], d_plan[MZ_SETS], h_tot[MZ_SETS],
          d_tb[MZ_SETS], d_script[MZ_SETS], d_prep[MZ_SETS], d_res[MZ_SETS], h_res[MZ_SETS];
-    gbuf d_out0;                           /* mz_preyama_batch(): merged columns (k_post reads them on the device) */
-    gbuf d_pre[10], h_pre[2];               /* mz_preyama_batch(): text + descriptors, pools, scratch, rows, row results / pinned in, out */
+    /* mz_preyama_batch() (mz_prebatch.c), per set, beside d_plan / d_tb / d_script / d_prep / h_tot / the stream and events above (its first
+     * stage uses those): device buffers pd[set][PD_*], pinned host buffers ph[set][PH_*]; `pplan2`: the second stage's plan is through */
+    gbuf pd[MZ_SETS][MZ_PD_N], ph[MZ_SETS][MZ_PH_N];
+    hipEvent_t pplan2[MZ_SETS];
+    mz_worker pworker[3];                  /* first launcher, second launcher, collector of mz_preyama_batch() */
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipStream_t ustream[MZ_SETS];          /* and one of high priority for its upload, expansion and plan: a chunk's plan must not queue
                                             * behind the DP waves of the chunks before it (the launcher waits for its totals) */
@@ -94,6 +111,7 @@ extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_
 MZ_INTERNAL int mzi_sync_scores(void);
 MZ_INTERNAL int mzi_timing(void);                       /* MZ_TIMING, parsed once: 0 quiet, 1 per call, 2 per chunk */
 MZ_INTERNAL void mzi_workers_stop(mz_ctx *X);           /* mz_batch.c: ctx_close() ends the context's helper threads */
+MZ_INTERNAL int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int64_t stats[3]);   /* mz_prebatch.c */
 
 /* mz_pool.c: the host threads of the batch pipeline (no OpenMP there: see the file), recycled result blocks */
 typedef void (*mz_pfn)(void *ctx, int lo, int hi);

@@ -30,25 +30,32 @@ typedef struct mz_pre_batch {
     int n;
     const int32_t *K, *L, *Ma, *Na, *rad;      /* K: rows of the first block, its top row included; L: rows of the second below its top row */
     const int32_t *v;                          /* 1: one-stage merge (all K rows align); 0: two stages (mz_preyama.c:265-336) */
-    const int64_t *offT1, *offT2;
+    int stride64;                              /* 1: the text rows of a slice lie (columns rounded up to 64) bytes apart -- the host-buffer path,
+                                                  whose rows travel as whole 32-byte lines of class nibbles; 0: columns bytes apart */
+    const int64_t *offT1;                      /* the first block's K rows; the second block's L + 1 rows follow them */
     const uint8_t *txt;
     const int64_t *offScr;
     int32_t *scr;
     int32_t *nullres;
 } mz_pre_batch;
-typedef struct mz_post_batch {
-    const int32_t *v;                          /* with only_v1: pairs whose v is 0 are left alone (their block comes from the second stage) */
-    int only_v1;
-    uint8_t *rows;
-    const int64_t *offRow;
+/* what mz_preyama_batch() copies back instead of rows (k_fin, kernels/prepost.inc): a record per merge, bases per row,
+ * and per merged column / slice column the bits from which the host puts the rows together out of the caller's own text */
+typedef struct mz_pre_rec { int32_t status, badrow, nullres, stage, M, N, om, om1; int64_t score; } mz_pre_rec;
+typedef struct mz_fin_batch {
+    int any0;                                  /* the batch has two-stage merges (b2 is valid) */
+    const int64_t *offRow;                     /* first of merge p's K + L entries of `size` */
     int32_t *size;
-    int64_t *score;
-} mz_post_batch;
+    const int64_t *offMask;                    /* byte offset (a multiple of 8) of merge p's mask block in `masks` */
+    uint8_t *masks;
+    mz_pre_rec *recs;
+    long long *hdr;                            /* [0]: band cells of the yama() calls that ran (zeroed by the caller) */
+} mz_fin_batch;
 int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
 /* between the two stages of the v == 0 merges: the second yama() job of every such pair of b1 into b2 (same indices;
  * the other pairs of b2 get M = 0, which the plan refuses) */
 int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream);
-int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream);
+/* b2: the second stage of the two-stage merges (ignored unless f->any0) */
+int mzk_fin(const mz_pre_batch *q, const mz_fin_batch *f, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream);
 const char *mzk_last_error(void);
 void mzk_set_abreast(int k);           /* DPs of k consecutive batches run side by side (kernel choice of mzk_dp_range) */
 void mzk_release_device(int dev);      /* destroy the launchers' side streams and events of one GPU (mz_finalize) */

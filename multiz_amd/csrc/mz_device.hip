@@ -587,11 +587,11 @@ extern "C" int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_d
     CK(hipGetLastError(), "mid launch");
     return 0;
 }
-extern "C" int mzk_post(const mz_post_batch *q, const mz_dev_batch *b, void *stream)
+extern "C" int mzk_fin(const mz_pre_batch *q, const mz_fin_batch *f, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream)
 {
-    if (b->n <= 0) return 0;
-    hipLaunchKernelGGL(k_post, dim3(b->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *b);
-    CK(hipGetLastError(), "post launch");
+    if (b1->n <= 0) return 0;
+    hipLaunchKernelGGL(k_fin, dim3(b1->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *f, *b1, f->any0 ? *b2 : *b1);
+    CK(hipGetLastError(), "fin launch");
     return 0;
 }
 extern "C" int mzk_dp(const mz_dev_batch *b, void *stream)   { return mzk_dp_range(b, 0, b->n, stream); }

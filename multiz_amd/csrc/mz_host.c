@@ -117,6 +117,7 @@ static int ctx_open(mz_ctx *X, int device)
     for (i = 0; i < MZ_SETS; ++i) {
         HIPCK(hipEventCreateWithFlags(&X->bdone[i], hipEventDisableTiming));
         HIPCK(hipEventCreateWithFlags(&X->bplan[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&X->pplan2[i], hipEventDisableTiming));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&X->evs[i], hipEventDisableTiming));
@@ -145,9 +146,11 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->bdone[s]);
         hipEventDestroy(X->bplan[s]);
     }
-    if (X->d_out0.p) { hipFree(X->d_out0.p); X->d_out0.p = NULL; X->d_out0.cap = 0; }
-    for (i = 0; i < 10; ++i) if (X->d_pre[i].p) { hipFree(X->d_pre[i].p); X->d_pre[i].p = NULL; X->d_pre[i].cap = 0; }
-    for (i = 0; i < 2; ++i) if (X->h_pre[i].p) { hipHostFree(X->h_pre[i].p); X->h_pre[i].p = NULL; X->h_pre[i].cap = 0; }
+    for (s = 0; s < MZ_SETS; ++s) {
+        for (i = 0; i < MZ_PD_N; ++i) if (X->pd[s][i].p) { hipFree(X->pd[s][i].p); X->pd[s][i].p = NULL; X->pd[s][i].cap = 0; }
+        for (i = 0; i < MZ_PH_N; ++i) if (X->ph[s][i].p) { hipHostFree(X->ph[s][i].p); X->ph[s][i].p = NULL; X->ph[s][i].cap = 0; }
+        hipEventDestroy(X->pplan2[s]);
+    }
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);
     for (i = 0; i < MZ_WS_MAX; ++i) if (X->ws[i].used) { hipEventDestroy(X->ws[i].done); X->ws[i].used = 0; }
@@ -213,6 +216,7 @@ int mz_init_multi(int ngpu, const int *devices)
 }
 
 int mz_device_count(void) { return g_ndev; }
+int mz_abi_version(void) { return MZ_AMD_ABI; }
 
 /* which physical GPU context `ctx` (0 .. mz_device_count()-1) runs on: "<PCI bus id> <device name>" -- what a multi-GPU
  * bench line prints per rank so that N ranks provably sat on N distinct devices */
@@ -632,268 +636,6 @@ int mz_dev_wait(void *stream)
     for (w = 0; w < MZ_WS_MAX; ++w)
         if (G.ws[w].used) HIPCK(hipStreamWaitEvent(s, G.ws[w].done, 0));
     return 0;
-}
-
-/* ------------------------------------------------------------------ pre_yama() batches */
-
-/* One pass over one GPU (the primary context): the slices' text goes up once, k_pre derives A, B and the band where
- * the DP kernels read them, the usual plan / DP / walk / emit run on those pools; for the two-stage merges (v == 0)
- * k_mid derives the second yama() job from the first one's result and a second plan / DP / walk / emit follows on the
- * same pair indices; k_post turns the merged columns into rows with base counts and score, and rows + per-row
- * results come back.  Calls of more than ~1 GB of text are cut into several passes. */
-static int plan_and_run(mz_ctx *X, mz_dev_batch *b, int set, int n, gbuf *out, int64_t totals[16], hipStream_t st)
-{
-    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n))) return -1;
-    mz_dev_carve(b, X->d_plan[set].p);
-    b->capTb = b->capScript = b->capOut = b->capPrep = INT64_MAX;
-    if (mzk_plan(b, st)) return mzi_set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(totals, b->totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-    if (mzi_dev_reserve(&X->d_tb[set], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[set], (size_t)totals[1] + 256) ||
-        mzi_dev_reserve(out, (size_t)totals[2] + 256) || mzi_dev_reserve(&X->d_prep[set], 4 * (size_t)totals[4] + 256)) return -1;
-    b->tbw = (uint32_t *)X->d_tb[set].p; b->script = (uint8_t *)X->d_script[set].p; b->out = (uint8_t *)out->p;
-    b->prep = (uint32_t *)X->d_prep[set].p; b->capPrep = (int64_t)(X->d_prep[set].cap / 4);
-    b->capTb = (int64_t)(X->d_tb[set].cap / 4); b->capScript = (int64_t)X->d_script[set].cap; b->capOut = (int64_t)out->cap;
-    b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
-    if (mzk_prep(b, st) || mzk_dp(b, st) || mzk_walk(b, st, 0) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
-    return 0;
-}
-
-static int preyama_pass(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs)
-{
-    hipStream_t st = X->stream;
-    mz_dev_batch b, b2;
-    mz_pre_batch q;
-    mz_post_batch r;
-    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, hdr, in_bytes, res_bytes;
-    int64_t *hT1, *hT2, *hoA, *hoB, *hoBand, *hoScr, *hoRow, *hoA2, totals[16], totals2[16];
-    int32_t *hK, *hL, *hMa, *hNa, *hRad, *hV;
-    char *h, *d, *hres;
-    uint8_t *hTxt;
-    int p, failed = 0, oom = 0, any0 = 0, any1 = 0;
-
-    for (p = 0; p < n; ++p) {
-        const mz_prejob *j = &jobs[p];
-        if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1) return mzi_set_err("mz_preyama_batch: job %d has an empty block or slice", p);
-        if (j->v != 0 && j->v != 1) return mzi_set_err("mz_preyama_batch: job %d: v = %d (0 or 1)", p, j->v);
-        txt += (size_t)j->K * j->M_all + (size_t)j->L1 * j->N_all;
-        szA += (size_t)j->K * j->M_all; szB += (size_t)(j->L1 - 1) * j->N_all; szA2 += (size_t)j->M_all + 8;
-        nband += (size_t)j->M_all + 1; nscr += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
-        nrow += (size_t)j->K + j->L1 - 1;
-        if (j->v == 0) any0 = 1; else any1 = 1;
-    }
-    /* pinned staging: K L Ma Na rad v (int32 x n), offT1 offT2 offA offB offBand offScr offRow offA2 (int64 x n), text */
-    hdr = 6 * mzi_al256(4 * (size_t)n) + 8 * mzi_al256(8 * (size_t)n);
-    in_bytes = hdr + mzi_al256(txt);
-    if (mzi_host_reserve(&X->h_pre[0], in_bytes) || mzi_dev_reserve(&X->d_pre[0], in_bytes) ||
-        mzi_dev_reserve(&X->d_pre[1], mzi_al256(szA) + mzi_al256(szB) + 256) || mzi_dev_reserve(&X->d_pre[2], 2 * mzi_al256(4 * nband)) ||
-        mzi_dev_reserve(&X->d_pre[3], 4 * nscr + 256)) return -1;
-    h = (char *)X->h_pre[0].p; d = (char *)X->d_pre[0].p;
-    memset(&b, 0, sizeof b); memset(&b2, 0, sizeof b2); memset(&q, 0, sizeof q); memset(&r, 0, sizeof r);
-    b.n = b2.n = q.n = n;
-#define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
-    SL(hK, int32_t, q.K, 4 * (size_t)n); SL(hL, int32_t, q.L, 4 * (size_t)n); SL(hMa, int32_t, q.Ma, 4 * (size_t)n);
-    SL(hNa, int32_t, q.Na, 4 * (size_t)n); SL(hRad, int32_t, q.rad, 4 * (size_t)n); SL(hV, int32_t, q.v, 4 * (size_t)n);
-    SL(hT1, int64_t, q.offT1, 8 * (size_t)n); SL(hT2, int64_t, q.offT2, 8 * (size_t)n);
-    SL(hoA, int64_t, b.offA, 8 * (size_t)n); SL(hoB, int64_t, b.offB, 8 * (size_t)n); SL(hoBand, int64_t, b.offBand, 8 * (size_t)n);
-    SL(hoScr, int64_t, q.offScr, 8 * (size_t)n); SL(hoRow, int64_t, r.offRow, 8 * (size_t)n); SL(hoA2, int64_t, b2.offA, 8 * (size_t)n);
-    SL(hTxt, uint8_t, q.txt, txt);
-#undef SL
-    {
-        size_t ot = 0, oa = 0, ob = 0, od = 0, os = 0, orow = 0, oa2 = 0;
-        for (p = 0; p < n; ++p) {
-            const mz_prejob *j = &jobs[p];
-            hK[p] = j->K; hL[p] = j->L1 - 1; hMa[p] = j->M_all; hNa[p] = j->N_all; hRad[p] = j->radius; hV[p] = j->v;
-            hT1[p] = (int64_t)ot; ot += (size_t)j->K * j->M_all;
-            hT2[p] = (int64_t)ot; ot += (size_t)j->L1 * j->N_all;
-            hoA[p] = (int64_t)oa; oa += (size_t)j->K * j->M_all;
-            hoB[p] = (int64_t)ob; ob += (size_t)(j->L1 - 1) * j->N_all;     /* (upper bound: dash columns go on the device) */
-            hoBand[p] = (int64_t)od; od += (size_t)j->M_all + 1;            /* (both stages: the second job has at most M_all rows) */
-            hoScr[p] = (int64_t)os; os += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
-            hoRow[p] = (int64_t)orow; orow += (size_t)j->K + j->L1 - 1;
-            hoA2[p] = (int64_t)oa2; oa2 += (size_t)j->M_all + 8;            /* the first block's top row without its dashes */
-        }
-#pragma omp parallel for schedule(static) num_threads(X->copy_threads) if (n > 256)
-        for (p = 0; p < n; ++p) {
-            const mz_prejob *j = &jobs[p];
-            int k;
-            for (k = 0; k < j->K; ++k) memcpy(hTxt + hT1[p] + (size_t)k * j->M_all, j->rows1[k], (size_t)j->M_all);
-            for (k = 0; k < j->L1; ++k) memcpy(hTxt + hT2[p] + (size_t)k * j->N_all, j->rows2[k], (size_t)j->N_all);
-        }
-    }
-    HIPCK(hipMemcpyAsync(X->d_pre[0].p, X->h_pre[0].p, in_bytes, hipMemcpyHostToDevice, st));
-    b.poolA = (const uint8_t *)X->d_pre[1].p; b.poolB = (const uint8_t *)X->d_pre[1].p + mzi_al256(szA);
-    b.poolLB = (const int32_t *)X->d_pre[2].p; b.poolRB = (const int32_t *)((char *)X->d_pre[2].p + mzi_al256(4 * nband));
-    q.scr = (int32_t *)X->d_pre[3].p;
-    /* K L M N of the two device batches, offB of the second, the NULL flags, sizes, scores: one more device block */
-    if (mzi_dev_reserve(&X->d_pre[4], 9 * mzi_al256(4 * (size_t)n) + mzi_al256(4 * nrow) + 2 * mzi_al256(8 * (size_t)n))) return -1;
-    {
-        char *e = (char *)X->d_pre[4].p;
-#define TK(field) do { field = (const int32_t *)e; e += mzi_al256(4 * (size_t)n); } while (0)
-        TK(b.K); TK(b.L); TK(b.M); TK(b.N); TK(b2.K); TK(b2.L); TK(b2.M); TK(b2.N);
-#undef TK
-        q.nullres = (int32_t *)e; e += mzi_al256(4 * (size_t)n);
-        r.size = (int32_t *)e; e += mzi_al256(4 * nrow);
-        r.score = (int64_t *)e; e += mzi_al256(8 * (size_t)n);
-        b2.offB = (const int64_t *)e;
-    }
-    r.v = q.v;
-    if (mzk_pre(&q, &b, st)) return mzi_set_err("%s", mzk_last_error());
-    if (plan_and_run(X, &b, 0, n, &X->d_out0, totals, st)) return -1;
-    memset(totals2, 0, sizeof totals2);
-    if (any0) {
-        /* second stage of the v == 0 merges: its A (the top rows), its band, and the first stage's merged columns as its B */
-        if (mzi_dev_reserve(&X->d_pre[6], szA2 + 256) || mzi_dev_reserve(&X->d_pre[7], 2 * mzi_al256(4 * nband))) return -1;
-        b2.poolA = (const uint8_t *)X->d_pre[6].p; b2.poolB = b.out;
-        b2.poolLB = (const int32_t *)X->d_pre[7].p; b2.poolRB = (const int32_t *)((char *)X->d_pre[7].p + mzi_al256(4 * nband));
-        b2.offBand = b.offBand;
-        if (mzk_mid(&q, &b, &b2, st)) return mzi_set_err("%s", mzk_last_error());
-        if (plan_and_run(X, &b2, 1, n, &X->d_pre[8], totals2, st)) return -1;
-    }
-    /* rows of the one-stage merges from the first batch, of the two-stage merges from the second */
-    if (mzi_dev_reserve(&X->d_pre[5], (size_t)totals[2] + 256) || (any0 && mzi_dev_reserve(&X->d_pre[9], (size_t)totals2[2] + 256))) return -1;
-    if (any1) { r.rows = (uint8_t *)X->d_pre[5].p; r.only_v1 = 1; if (mzk_post(&r, &b, st)) return mzi_set_err("%s", mzk_last_error()); }
-    if (any0) { r.rows = (uint8_t *)X->d_pre[9].p; r.only_v1 = 0; if (mzk_post(&r, &b2, st)) return mzi_set_err("%s", mzk_last_error()); }
-
-    /* results: status badrow om M N nullres status2 badrow2 om2 (int32 x n), offOut offOut2 score (int64 x n), sizes (int32 x rows), the rows */
-    {
-        const size_t rows1 = any1 ? (size_t)totals[2] : 0, rows2 = any0 ? (size_t)totals2[2] : 0;
-        res_bytes = 9 * mzi_al256(4 * (size_t)n) + 3 * mzi_al256(8 * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256(rows1) + mzi_al256(rows2);
-        if (mzi_host_reserve(&X->h_pre[1], res_bytes)) return -1;
-        hres = (char *)X->h_pre[1].p;
-        {
-            char *o = hres;
-#define DOWN(src, bytes) do { if ((src) != NULL && (size_t)(bytes) > 0) HIPCK(hipMemcpyAsync(o, src, bytes, hipMemcpyDeviceToHost, st)); o += mzi_al256(bytes); } while (0)
-            DOWN(b.status, 4 * (size_t)n); DOWN(b.badrow, 4 * (size_t)n); DOWN(b.om, 4 * (size_t)n);
-            DOWN(b.M, 4 * (size_t)n); DOWN(b.N, 4 * (size_t)n); DOWN(q.nullres, 4 * (size_t)n);
-            DOWN(any0 ? b2.status : NULL, 4 * (size_t)n); DOWN(any0 ? b2.badrow : NULL, 4 * (size_t)n); DOWN(any0 ? b2.om : NULL, 4 * (size_t)n);
-            DOWN(b.offOut, 8 * (size_t)n); DOWN(any0 ? b2.offOut : NULL, 8 * (size_t)n); DOWN(r.score, 8 * (size_t)n); DOWN(r.size, 4 * nrow);
-            DOWN(any1 ? X->d_pre[5].p : NULL, rows1); DOWN(any0 ? X->d_pre[9].p : NULL, rows2);
-#undef DOWN
-        }
-        HIPCK(hipStreamSynchronize(st));
-        {
-            const size_t a4 = mzi_al256(4 * (size_t)n), a8 = mzi_al256(8 * (size_t)n);
-            const int32_t *rs = (const int32_t *)hres, *rb = (const int32_t *)(hres + a4), *ro = (const int32_t *)(hres + 2 * a4),
-                          *rM = (const int32_t *)(hres + 3 * a4), *rN = (const int32_t *)(hres + 4 * a4), *rnull = (const int32_t *)(hres + 5 * a4),
-                          *rs2 = (const int32_t *)(hres + 6 * a4), *rb2 = (const int32_t *)(hres + 7 * a4), *ro2 = (const int32_t *)(hres + 8 * a4);
-            const int64_t *roff = (const int64_t *)(hres + 9 * a4), *roff2 = (const int64_t *)(hres + 9 * a4 + a8), *rsc = (const int64_t *)(hres + 9 * a4 + 2 * a8);
-            const int32_t *rsz = (const int32_t *)(hres + 9 * a4 + 3 * a8);
-            const uint8_t *rrows = (const uint8_t *)rsz + mzi_al256(4 * nrow), *rrows2 = rrows + mzi_al256(rows1);
-#pragma omp parallel for schedule(static) num_threads(X->copy_threads) reduction(+:failed) reduction(|:oom) if (n > 256)
-            for (p = 0; p < n; ++p) {
-                mz_preout *o = &outs[p];
-                const int W = jobs[p].K + jobs[p].L1 - 1, two = jobs[p].v == 0;
-                /* a two-stage merge: the first failure in stage order; its block is the second stage's */
-                const int stat = rnull[p] ? MZ_OK : rs[p] != MZ_OK ? rs[p] : two ? rs2[p] : MZ_OK;
-                const int om = two ? ro2[p] : ro[p];
-                memset(o, 0, sizeof *o);
-                o->null_result = rnull[p];
-                o->status = stat; o->badrow = (two && rs[p] == MZ_OK) ? rb2[p] : rb[p]; o->M = rM[p]; o->N = rN[p];
-                o->stage = (two && rs[p] == MZ_OK && !rnull[p]) ? 2 : 1;
-                if (rnull[p] || stat != MZ_OK) { failed++; continue; }
-                o->OM = om;
-                o->score = (double)rsc[p];
-                {
-                    const size_t nb = (size_t)W * (size_t)om, pad = (nb + 7) & ~(size_t)7;
-                    o->rows = (unsigned char *)malloc(pad + 4 * (size_t)W + 8);
-                    if (!o->rows) { oom = 1; o->status = MZ_E_DEVICE; continue; }
-                    memcpy(o->rows, two ? rrows2 + roff2[p] : rrows + roff[p], nb);
-                    memcpy(o->rows + pad, rsz + hoRow[p], 4 * (size_t)W);
-                    o->size = (const int *)(o->rows + pad);
-                }
-            }
-        }
-    }
-    if (oom) return mzi_set_err("out of memory for the merged rows");
-    if (mzi_timing())
-        fprintf(stderr, "{\"mz_preyama_batch_pass\": {\"merges\": %d, \"two_stage\": %d, \"bytes_up\": %zu, \"bytes_down\": %zu}}\n",
-                n, any0, in_bytes, res_bytes);
-    return failed;
-}
-
-/* a context's share of a call, in passes of at most ~1 GB of text */
-static int preyama_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs)
-{
-    int done = 0, failed = 0;
-    if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
-    while (done < n) {
-        size_t bytes = 0;
-        int m = 0, rc;
-        while (done + m < n && m < (1 << 20) && bytes < ((size_t)1 << 30)) {
-            const mz_prejob *j = &jobs[done + m];
-            bytes += (size_t)(j->K > 0 ? j->K : 0) * (size_t)(j->M_all > 0 ? j->M_all : 0) + (size_t)(j->L1 > 0 ? j->L1 : 0) * (size_t)(j->N_all > 0 ? j->N_all : 0);
-            ++m;
-        }
-        rc = preyama_pass(X, m, jobs + done, outs + done);
-        if (rc < 0) return -1;
-        failed += rc;
-        done += m;
-    }
-    return failed;
-}
-
-typedef struct pre_task { mz_ctx *X; int n, rc; const mz_prejob *jobs; mz_preout *outs; char err[600]; } pre_task;
-static void *pre_worker(void *arg)
-{
-    pre_task *t = (pre_task *)arg;
-    t->rc = preyama_on_ctx(t->X, t->n, t->jobs, t->outs);
-    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, g_err);
-    return NULL;
-}
-
-int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
-{
-    int failed = 0, a, b, use, rc, p;
-    if (n <= 0) return 0;
-    pthread_mutex_lock(&g_big);
-    if (mzi_ensure_init() || mzi_sync_scores()) { pthread_mutex_unlock(&g_big); return -1; }
-    for (a = 0; a < 128; ++a)                              /* k_post's pair sums need ss[x][y] == ss[y][x] */
-        for (b = 0; b < a; ++b)
-            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); mzi_set_err("score table is not symmetric"); return -2; }
-    for (p = 0; p < n; ++p) { memset(&outs[p], 0, sizeof outs[p]); outs[p].status = MZ_E_DEVICE; }
-    use = g_ndev;
-    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
-    if (use == 1) {
-        rc = preyama_on_ctx(&G, n, jobs, outs);
-        pthread_mutex_unlock(&g_big);
-        return rc;
-    }
-    {
-        /* several GPUs: contiguous ranges of about equal text volume, one host thread per GPU (as mz_yama_batch) */
-        pre_task task[MZ_MAX_DEV];
-        pthread_t th[MZ_MAX_DEV];
-        double total = 0.0, acc = 0.0;
-        int d = 0, start = 0, started[MZ_MAX_DEV];
-        for (p = 0; p < n; ++p) total += (double)jobs[p].K * jobs[p].M_all + (double)jobs[p].L1 * jobs[p].N_all;
-        for (p = 0; p < n && d < use; ++p) {
-            acc += (double)jobs[p].K * jobs[p].M_all + (double)jobs[p].L1 * jobs[p].N_all;
-            if (d == use - 1) { p = n - 1; acc = total; }
-            if (acc >= total * (d + 1) / use || p == n - 1) {
-                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
-                task[d].n = p + 1 - start; task[d].rc = 0; task[d].err[0] = 0;
-                start = p + 1; ++d;
-            }
-        }
-        use = d;
-        for (d = 0; d < use; ++d) g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
-        for (d = 1; d < use; ++d) {
-            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, pre_worker, &task[d]) == 0;
-            if (!started[d] && task[d].n > 0) pre_worker(&task[d]);
-        }
-        if (task[0].n > 0) pre_worker(&task[0]);
-        rc = 0;
-        for (d = 0; d < use; ++d) {
-            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
-            if (task[d].n <= 0) continue;
-            if (task[d].rc < 0) { rc = -1; mzi_set_err("%s", task[d].err); }
-            else failed += task[d].rc;
-        }
-        hipSetDevice(G.device);
-        for (d = 0; d < g_ndev; ++d) g_dev[d].copy_threads = MZ_COPY_THREADS;
-        pthread_mutex_unlock(&g_big);
-        return rc < 0 ? -1 : failed;
-    }
 }
 
 /* ------------------------------------------------------------------ yama(): a batch of one */

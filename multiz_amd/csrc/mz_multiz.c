@@ -355,7 +355,6 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
         }
         g->result = block_from_rows(o, g->a1, cb1[i], g->a2, cb2[i]);
         g->state = MZ_PY_DONE;
-        free(o->rows);
         if (g->result && g->result->components->size >= minw) {
             FILE *m = open_memstream(&g->text, &g->len);
             mafWrite(m, g->result);
@@ -363,6 +362,7 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
         }
         mafAliFree(&g->result);
     }
+    mz_free_preouts(n, outs);
     if (timing) fprintf(stderr, "mz_multiz: %d merges, block text to block text on the GPU %.3f s, blocks assembled and rendered %.3f s\n",
                         n, t1 - t0, mz_now_s() - t1);
     free(jobs); free(outs); free(who); free(cb1); free(cb2); free(ptrs);

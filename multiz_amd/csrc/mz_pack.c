@@ -356,3 +356,130 @@ void mz_assemble_cols(int K, int L, int M, int N, const uint8_t *A, const uint8_
     }
     if (fill > first) memcpy(line + first, buf + first, fill - first);
 }
+
+/* ------------------------------------------------------------------------------------------------ merged rows
+ * mz_preyama_batch() (mz_prebatch.c): the rows of a merged block, from the caller's own block text and what the device
+ * sends back per merge (k_fin, kernels/prepost.inc) -- for every group of rows one bit per merged column (take the
+ * row's next source byte, or a dash: reference mz_yama.c:293-313 through mafBuild, mz_preyama.c:61-66) and, where
+ * rmColDash (mz_preyama.c:87-108) dropped columns of the slice, one bit per slice column (kept or not).  A row is its
+ * source bytes, squeezed by the second kind of mask and spread out by the first: eight columns per table look-up
+ * (pshufb), the rows of a block one after the other through the same L1 buffer and streaming stores as the columns above. */
+static uint8_t g_exp[256][8] __attribute__((aligned(16)));      /* spread: source byte index per output byte, 0x80 where a dash goes */
+static uint8_t g_expd[256][8] __attribute__((aligned(16)));     /* '-' where a dash goes */
+static uint8_t g_cmp[256][8] __attribute__((aligned(16)));      /* squeeze: the kept bytes to the front */
+static uint8_t g_pop8[256];
+
+__attribute__((constructor)) static void rows_init(void)
+{
+    int x, k;
+    for (x = 0; x < 256; ++x) {
+        int i = 0;
+        memset(g_cmp[x], 0x80, 8);
+        for (k = 0; k < 8; ++k) {
+            if (x >> k & 1) { g_exp[x][k] = (uint8_t)i; g_expd[x][k] = 0; g_cmp[x][i] = (uint8_t)k; ++i; }
+            else { g_exp[x][k] = 0x80; g_expd[x][k] = '-'; }
+        }
+        g_pop8[x] = (uint8_t)i;
+    }
+}
+
+#define MASK8(m, c) ((unsigned)((m)[(c) >> 6] >> ((c) & 63)) & 255u)
+
+/* columns [c0, c1) of one row into o (c0 a multiple of 16; o may be written up to 15 bytes past the last column):
+ * *ps = the row's next unread source byte, send = the end of its source */
+__attribute__((target("ssse3"))) static void spread_ssse3(const uint8_t **ps, const uint8_t *send, const uint64_t *ops, int c0, int c1, uint8_t *o)
+{
+    const uint8_t *s = *ps;
+    int c = c0;
+    for (; c + 16 <= c1 && s + 16 <= send; c += 16) {
+        const unsigned m0 = MASK8(ops, c), m1 = MASK8(ops, c + 8);
+        const __m128i v0 = _mm_loadl_epi64((const __m128i *)s), v1 = _mm_loadl_epi64((const __m128i *)(s + g_pop8[m0]));
+        const __m128i r0 = _mm_or_si128(_mm_shuffle_epi8(v0, _mm_loadl_epi64((const __m128i *)g_exp[m0])), _mm_loadl_epi64((const __m128i *)g_expd[m0]));
+        const __m128i r1 = _mm_or_si128(_mm_shuffle_epi8(v1, _mm_loadl_epi64((const __m128i *)g_exp[m1])), _mm_loadl_epi64((const __m128i *)g_expd[m1]));
+        _mm_storeu_si128((__m128i *)(o + (c - c0)), _mm_unpacklo_epi64(r0, r1));
+        s += g_pop8[m0] + g_pop8[m1];
+    }
+    for (; c < c1; ++c) o[c - c0] = (ops[c >> 6] >> (c & 63) & 1) ? *s++ : (uint8_t)'-';
+    *ps = s;
+}
+static void spread_scalar(const uint8_t **ps, const uint64_t *ops, int c0, int c1, uint8_t *o)
+{
+    const uint8_t *s = *ps;
+    int c;
+    for (c = c0; c < c1; ++c) o[c - c0] = (ops[c >> 6] >> (c & 63) & 1) ? *s++ : (uint8_t)'-';
+    *ps = s;
+}
+
+/* src[0..n) without the bytes whose bit in `keep` is clear (dst: n + 16 bytes); returns the bytes kept */
+__attribute__((target("ssse3"))) static size_t squeeze_mask_ssse3(const uint8_t *src, int n, const uint64_t *keep, uint8_t *dst)
+{
+    size_t j = 0;
+    int c = 0;
+    for (; c + 8 <= n; c += 8) {
+        const unsigned m = MASK8(keep, c);
+        _mm_storel_epi64((__m128i *)(dst + j), _mm_shuffle_epi8(_mm_loadl_epi64((const __m128i *)(src + c)), _mm_loadl_epi64((const __m128i *)g_cmp[m])));
+        j += g_pop8[m];
+    }
+    for (; c < n; ++c) if (keep[c >> 6] >> (c & 63) & 1) dst[j++] = src[c];
+    return j;
+}
+/* ... without its dashes (the first block's top row as the second stage of a v = 0 merge aligns it, mz_preyama.c:282-290) */
+__attribute__((target("ssse3"))) static size_t squeeze_dash_ssse3(const uint8_t *src, int n, uint8_t *dst)
+{
+    const __m128i dash = _mm_set1_epi8('-');
+    size_t j = 0;
+    int c = 0;
+    for (; c + 16 <= n; c += 16) {
+        const __m128i v = _mm_loadu_si128((const __m128i *)(src + c));
+        const unsigned m = ~(unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, dash)) & 0xffffu, m0 = m & 255u, m1 = m >> 8;
+        _mm_storel_epi64((__m128i *)(dst + j), _mm_shuffle_epi8(v, _mm_loadl_epi64((const __m128i *)g_cmp[m0])));
+        j += g_pop8[m0];
+        _mm_storel_epi64((__m128i *)(dst + j), _mm_shuffle_epi8(_mm_srli_si128(v, 8), _mm_loadl_epi64((const __m128i *)g_cmp[m1])));
+        j += g_pop8[m1];
+    }
+    for (; c < n; ++c) if (src[c] != '-') dst[j++] = src[c];
+    return j;
+}
+
+/* nrows rows of om bytes, one after the other, to out (exactly nrows * om bytes).  tmp: room for the longest source row
+ * that has to be squeezed + 16 bytes (NULL when none has).  The device has checked that every mask takes exactly the
+ * bytes its row has (the closing check of mz_yama.c:310-312 on each stage's script); a spread never reads past `n`. */
+#define ROW_PIECE 2048
+void mz_assemble_rows(int nrows, const mz_rowspec *rows, int om, uint8_t *out)
+{
+    uint8_t buf[64 + ASM_BUF + 64] __attribute__((aligned(64)));
+    const size_t phase = (size_t)((uintptr_t)out & 63);
+    uint8_t *line = out - phase;
+    size_t fill = phase, first = phase;
+    int r, c0;
+    for (r = 0; r < nrows; ++r) {
+        const mz_rowspec *q = &rows[r];
+        const uint8_t *s = q->src, *send = q->src + q->n;
+        if (q->squeeze) {
+            size_t kept;
+            if (q->squeeze == 2) {
+                if (g_ssse3) kept = squeeze_dash_ssse3(q->src, q->n, q->tmp);
+                else { int c; for (c = 0, kept = 0; c < q->n; ++c) if (q->src[c] != '-') q->tmp[kept++] = q->src[c]; }
+            } else if (g_ssse3) kept = squeeze_mask_ssse3(q->src, q->n, q->keep, q->tmp);
+            else { int c; for (c = 0, kept = 0; c < q->n; ++c) if (q->keep[c >> 6] >> (c & 63) & 1) q->tmp[kept++] = q->src[c]; }
+            s = q->tmp; send = q->tmp + kept;
+        }
+        for (c0 = 0; c0 < om; c0 += ROW_PIECE) {
+            const int c1 = c0 + ROW_PIECE < om ? c0 + ROW_PIECE : om;
+            size_t full;
+            if (g_ssse3) spread_ssse3(&s, send, q->ops, c0, c1, buf + fill);
+            else spread_scalar(&s, q->ops, c0, c1, buf + fill);
+            fill += (size_t)(c1 - c0);
+            full = fill & ~(size_t)63;
+            if (full) {
+                size_t from = 0;
+                if (first) { memcpy(line + first, buf + first, 64 - first); from = 64; first = 0; }     /* the line shared with the merge before */
+                stream_lines(line + from, buf + from, full - from);
+                line += full;
+                memcpy(buf, buf + full, 64);
+                fill -= full;
+            }
+        }
+    }
+    if (fill > first) memcpy(line + first, buf + first, fill - first);
+}

@@ -16,4 +16,9 @@ uint32_t mz_pack_band_nib(const int *LB, const int *RB, int M, uint8_t *dst);
 void mz_pack_band_bytes(const int *LB, const int *RB, int M, uint8_t *dst);
 /* merged columns of one pair from its 2-bit edit script (reference mz_yama.c:293-313) */
 void mz_assemble_cols(int K, int L, int M, int N, const uint8_t *A, const uint8_t *B, const uint8_t *script, int om, uint8_t *out);
+/* one row of a merged block (mz_preyama_batch): n source bytes; squeeze 0: all of them are its bytes, 1: those whose bit
+ * in `keep` is set, 2: those that are not dashes (tmp: n + 16 bytes of scratch for 1 and 2); `ops`: one bit per merged
+ * column -- the row's next byte, or a dash */
+typedef struct mz_rowspec { const uint8_t *src; int n, squeeze; const uint64_t *keep, *ops; uint8_t *tmp; } mz_rowspec;
+void mz_assemble_rows(int nrows, const mz_rowspec *rows, int om, uint8_t *out);
 #endif

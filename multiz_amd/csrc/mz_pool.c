@@ -190,6 +190,68 @@ void mzi_pool_stop(void)
     pthread_mutex_unlock(&g_pool.mu);
 }
 
+/* ------------------------------------------------------------------------------------------------ stage threads
+ * The helper threads of a context's chunk pipelines (mz_batch.c: launcher, collector; mz_prebatch.c: two launchers, collector):
+ * persistent, asleep between calls.  fn(job) runs on the worker; the worker counts as free when fn has returned. */
+static void *stage_worker(void *arg)
+{
+    mz_worker *w = (mz_worker *)arg;
+    for (;;) {
+        void (*fn)(void *);
+        void *job;
+        pthread_mutex_lock(&w->mu);
+        while (!w->quit && !w->job) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->quit) { pthread_mutex_unlock(&w->mu); break; }
+        fn = w->fn; job = w->job;
+        pthread_mutex_unlock(&w->mu);
+        fn(job);
+        pthread_mutex_lock(&w->mu);
+        w->job = NULL;
+        pthread_cond_broadcast(&w->cv);                  /* (a giver may be waiting for the worker to come free) */
+        pthread_mutex_unlock(&w->mu);
+    }
+    return NULL;
+}
+
+int mzi_workers_start(mz_worker *w, int n)
+{
+    int i;
+    for (i = 0; i < n; ++i) {
+        if (w[i].started) continue;
+        pthread_mutex_init(&w[i].mu, NULL);
+        pthread_cond_init(&w[i].cv, NULL);
+        w[i].quit = 0; w[i].job = NULL;
+        if (pthread_create(&w[i].th, NULL, stage_worker, &w[i]) != 0) { pthread_mutex_destroy(&w[i].mu); pthread_cond_destroy(&w[i].cv); return -1; }
+        w[i].started = 1;
+    }
+    return 0;
+}
+
+void mzi_worker_give(mz_worker *w, void (*fn)(void *), void *job)
+{
+    pthread_mutex_lock(&w->mu);
+    while (w->job) pthread_cond_wait(&w->cv, &w->mu);    /* the previous call's stage has reported its end but not yet returned */
+    w->fn = fn; w->job = job;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+}
+
+void mzi_workers_end(mz_worker *w, int n)
+{
+    int i;
+    for (i = 0; i < n; ++i) {
+        if (!w[i].started) continue;
+        pthread_mutex_lock(&w[i].mu);
+        w[i].quit = 1;
+        pthread_cond_broadcast(&w[i].cv);
+        pthread_mutex_unlock(&w[i].mu);
+        pthread_join(w[i].th, NULL);
+        pthread_mutex_destroy(&w[i].mu);
+        pthread_cond_destroy(&w[i].cv);
+        w[i].started = 0;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ result blocks
  * The merged columns of a chunk are ONE malloc()ed block (mz_out.block).  A 27 MB block is an mmap() of its own
  * to malloc: fresh zero pages on every call (52 000 page faults per 50 000-pair C2 call, 600 000 for a C4 share) and an

@@ -1,0 +1,614 @@
+/* mz_prebatch.c -- mz_preyama_batch(): N independent pre_yama() merges (reference mz_preyama.c:152-359, with mafBuild
+ * :38-81 and mafScoreRange mz_scores.c:124-152) from block TEXT to block text -- what mz_multiz / mz_multic / mz_roast
+ * run every merge through.
+ *
+ * Like mz_yama_batch() (mz_batch.c) this path is bounded by the PCIe link and the host's own memory traffic, not by
+ * the kernels, and it is built the same way:
+ *
+ *   up     the text of the two slices as byte CLASSES, two per byte, every row a whole number of 32-byte lines
+ *          (mz_pack_classes_stream; k_unnib expands a nibble to a canonical letter of its class on the device: the DP,
+ *          rmColDash and mafScoreRange only distinguish A/a C/c G/g T/t, '-' and "other") -- no int32 band at all: the
+ *          band is derived on the device (k_pre: the shared reference row walked base by base, then smooth());
+ *   back   a 48-byte record per merge (status, M, N, OM, score), the bases per row, and per merged column one bit per
+ *          row group (k_fin) -- the ROWS are put together here, from the caller's own text (mz_assemble_rows);
+ *   pipe   a call is cut into chunks that go through four stages on MZ_SETS rotating sets of buffers and streams:
+ *            packer     (the calling thread)  classes into pinned memory on the pool's threads; copy, k_unnib, k_pre,
+ *                                             the first plan and the copy of its totals;
+ *            launcher 1 (helper thread)       waits for the totals, sizes the workspaces, issues DP / walk / emit; for
+ *                                             chunks with two-stage merges k_mid and the second plan, else k_fin + copy;
+ *            launcher 2 (helper thread)       chunks with two-stage merges: waits for the second plan's totals, issues
+ *                                             the second DP / walk / emit, k_fin and the copy of the results;
+ *            collector  (helper thread)       waits for the results, takes ONE block for the chunk's rows and assembles
+ *                                             them on the pool's threads.
+ *          No stage waits for a copy or a kernel another stage could work beside.  A call of one chunk runs inline.
+ */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <xmmintrin.h>
+
+#include "mz_ctx.h"
+#include "mz_pack.h"
+#include "../../include/mz_scores.h"
+
+typedef struct pchunk {
+    mz_ctx *X;
+    int set, n, index, any0;
+    const mz_prejob *jobs;
+    mz_preout *outs;
+    mz_dev_batch b, b2;
+    mz_pre_batch q;
+    mz_fin_batch f;
+    const int64_t *hoRow, *hoMask;         /* host copies (inside the set's pinned staging block) */
+    size_t nrow, mask_bytes, in_bytes, res_bytes;
+    int64_t cells;
+    double t_pack0, t_pack1, t_l1a, t_l1b, t_l2a, t_l2b, t_col0, t_col1, t_col2;
+} pchunk;
+
+static size_t row_stride(int cols) { return ((size_t)cols + 63) & ~(size_t)63; }
+static size_t text_bytes(const mz_prejob *j) { return (size_t)j->K * row_stride(j->M_all) + (size_t)j->L1 * row_stride(j->N_all); }
+static size_t mask_block(const mz_prejob *j)         /* bytes of a merge's mask block: the layout of k_fin (kernels/prepost.inc) */
+{
+    const size_t cap = j->v == 0 ? 2 * (size_t)j->M_all + j->N_all : (size_t)j->M_all + j->N_all, wc = (cap + 63) >> 6;
+    return 8 * (j->v == 0 ? 3 * wc + (((size_t)j->M_all + 63) >> 6) + (((size_t)j->N_all + 63) >> 6) : 2 * wc + (((size_t)j->N_all + 63) >> 6));
+}
+
+static int pre_grain(int n)
+{
+    if (n <= 16) return n;
+    const int g = n / (4 * mzi_pool_threads());
+    return g < 1 ? 1 : g > 64 ? 64 : g;
+}
+
+typedef struct ppack { const mz_prejob *jobs; const int64_t *hoT1; uint8_t *hTxt; } ppack;
+
+static void pack_text(void *ctx, int lo, int hi)
+{
+    const ppack *q = (const ppack *)ctx;
+    int p, k;
+    for (p = lo; p < hi; ++p) {
+        const mz_prejob *j = &q->jobs[p];
+        const size_t sA = row_stride(j->M_all), sB = row_stride(j->N_all);
+        uint8_t *d = q->hTxt + q->hoT1[p] / 2;
+        if (p + 1 < hi) { _mm_prefetch((const char *)q->jobs[p + 1].rows1[0], _MM_HINT_T0); _mm_prefetch((const char *)q->jobs[p + 1].rows2[0], _MM_HINT_T0); }
+        for (k = 0; k < j->K; ++k, d += sA / 2) mz_pack_classes_stream((const uint8_t *)j->rows1[k], (size_t)j->M_all, d, sA / 2);
+        for (k = 0; k < j->L1; ++k, d += sB / 2) mz_pack_classes_stream((const uint8_t *)j->rows2[k], (size_t)j->N_all, d, sB / 2);
+    }
+    _mm_sfence();
+}
+
+static int g_ptiming = -1;
+#define PD(i) (&X->pd[set][i])
+#define PH(i) (&X->ph[set][i])
+
+/* stage 1 (the caller): pack, copy, expand, k_pre, plan */
+static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const mz_prejob *jobs, mz_preout *outs)
+{
+    hipStream_t st;
+    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, nmask = 0, hdr, in_bytes;
+    int64_t *hT1, *hoA, *hoB, *hoBand, *hoScr, *hoRow, *hoA2, *hoMask;
+    int32_t *hK, *hL, *hMa, *hNa, *hRad, *hV;
+    uint8_t *hTxt;
+    const uint8_t *dNib;
+    char *h, *d;
+    int p, any0 = 0;
+
+    c->t_pack0 = mzi_now_s();
+    if (mzi_lazy_stream(&X->bstream[set])) return -1;
+    st = X->bstream[set];
+    memset(&c->b, 0, sizeof c->b); memset(&c->b2, 0, sizeof c->b2); memset(&c->q, 0, sizeof c->q); memset(&c->f, 0, sizeof c->f);
+    c->X = X; c->set = set; c->index = index; c->n = n; c->jobs = jobs; c->outs = outs;
+    for (p = 0; p < n; ++p) {
+        const mz_prejob *j = &jobs[p];
+        txt += text_bytes(j);
+        szA += (size_t)j->K * j->M_all; szB += (size_t)(j->L1 - 1) * j->N_all; szA2 += (size_t)j->M_all + 8;
+        nband += (size_t)j->M_all + 1; nscr += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
+        nrow += (size_t)j->K + j->L1 - 1; nmask += mask_block(j);
+        if (j->v == 0) any0 = 1;
+    }
+    /* pinned staging: K L Ma Na rad v (int32 x n), offT1 offA offB offBand offScr offRow offA2 offMask (int64 x n), class nibbles */
+    hdr = 6 * mzi_al256(4 * (size_t)n) + 8 * mzi_al256(8 * (size_t)n);
+    in_bytes = hdr + mzi_al256(txt / 2);
+    if (mzi_host_reserve(PH(MZ_PH_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_TXT), txt + 256) ||
+        mzi_dev_reserve(PD(MZ_PD_COLS), mzi_al256(szA) + mzi_al256(szB) + 256) || mzi_dev_reserve(PD(MZ_PD_BAND), 2 * mzi_al256(4 * nband)) ||
+        mzi_dev_reserve(PD(MZ_PD_SCR), 4 * nscr + 256)) return -1;
+    h = (char *)PH(MZ_PH_IN)->p; d = (char *)PD(MZ_PD_IN)->p;
+    c->b.n = c->b2.n = c->q.n = n;
+#define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
+    SL(hK, int32_t, c->q.K, 4 * (size_t)n); SL(hL, int32_t, c->q.L, 4 * (size_t)n); SL(hMa, int32_t, c->q.Ma, 4 * (size_t)n);
+    SL(hNa, int32_t, c->q.Na, 4 * (size_t)n); SL(hRad, int32_t, c->q.rad, 4 * (size_t)n); SL(hV, int32_t, c->q.v, 4 * (size_t)n);
+    SL(hT1, int64_t, c->q.offT1, 8 * (size_t)n);
+    SL(hoA, int64_t, c->b.offA, 8 * (size_t)n); SL(hoB, int64_t, c->b.offB, 8 * (size_t)n); SL(hoBand, int64_t, c->b.offBand, 8 * (size_t)n);
+    SL(hoScr, int64_t, c->q.offScr, 8 * (size_t)n); SL(hoRow, int64_t, c->f.offRow, 8 * (size_t)n); SL(hoA2, int64_t, c->b2.offA, 8 * (size_t)n);
+    SL(hoMask, int64_t, c->f.offMask, 8 * (size_t)n);
+    SL(hTxt, uint8_t, dNib, txt / 2);
+#undef SL
+    {
+        size_t ot = 0, oa = 0, ob = 0, od = 0, os = 0, orow = 0, oa2 = 0, om = 0;
+        for (p = 0; p < n; ++p) {
+            const mz_prejob *j = &jobs[p];
+            hK[p] = j->K; hL[p] = j->L1 - 1; hMa[p] = j->M_all; hNa[p] = j->N_all; hRad[p] = j->radius; hV[p] = j->v;
+            hT1[p] = (int64_t)ot; ot += text_bytes(j);
+            hoA[p] = (int64_t)oa; oa += (size_t)j->K * j->M_all;
+            hoB[p] = (int64_t)ob; ob += (size_t)(j->L1 - 1) * j->N_all;     /* (upper bound: dash columns go on the device) */
+            hoBand[p] = (int64_t)od; od += (size_t)j->M_all + 1;            /* (both stages: the second job has at most M_all rows) */
+            hoScr[p] = (int64_t)os; os += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
+            hoRow[p] = (int64_t)orow; orow += (size_t)j->K + j->L1 - 1;
+            hoA2[p] = (int64_t)oa2; oa2 += (size_t)j->M_all + 8;            /* the first block's top row without its dashes */
+            hoMask[p] = (int64_t)om; om += mask_block(j);
+        }
+    }
+    {
+        ppack pc;
+        pc.jobs = jobs; pc.hoT1 = hT1; pc.hTxt = hTxt;
+        mzi_parallel_for(n, pre_grain(n), pack_text, &pc);
+    }
+    c->t_pack1 = mzi_now_s();
+    c->hoRow = hoRow; c->hoMask = hoMask; c->nrow = nrow; c->mask_bytes = nmask; c->in_bytes = in_bytes; c->any0 = any0;
+    HIPCK(hipMemcpyAsync(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, in_bytes, hipMemcpyHostToDevice, st));
+    if (mzk_unnib(dNib, PD(MZ_PD_TXT)->p, (long long)txt, st)) return mzi_set_err("%s", mzk_last_error());
+    c->q.txt = (const uint8_t *)PD(MZ_PD_TXT)->p; c->q.stride64 = 1;
+    c->b.poolA = (const uint8_t *)PD(MZ_PD_COLS)->p; c->b.poolB = c->b.poolA + mzi_al256(szA);
+    c->b.poolLB = (const int32_t *)PD(MZ_PD_BAND)->p; c->b.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND)->p + mzi_al256(4 * nband));
+    c->q.scr = (int32_t *)PD(MZ_PD_SCR)->p;
+    /* K L M N of the two device batches, offB of the second, the NULL flags: one more device block */
+    if (mzi_dev_reserve(PD(MZ_PD_META), 9 * mzi_al256(4 * (size_t)n) + mzi_al256(8 * (size_t)n))) return -1;
+    {
+        char *e = (char *)PD(MZ_PD_META)->p;
+#define TK(field) do { field = (const int32_t *)e; e += mzi_al256(4 * (size_t)n); } while (0)
+        TK(c->b.K); TK(c->b.L); TK(c->b.M); TK(c->b.N); TK(c->b2.K); TK(c->b2.L); TK(c->b2.M); TK(c->b2.N);
+#undef TK
+        c->q.nullres = (int32_t *)e; e += mzi_al256(4 * (size_t)n);
+        c->b2.offB = (const int64_t *)e;
+    }
+    if (any0) {       /* the second stage's A (the top rows) and band pools; its B is the first stage's merged columns where they lie */
+        if (mzi_dev_reserve(PD(MZ_PD_A2), szA2 + 256) || mzi_dev_reserve(PD(MZ_PD_BAND2), 2 * mzi_al256(4 * nband))) return -1;
+        c->b2.poolA = (const uint8_t *)PD(MZ_PD_A2)->p;
+        c->b2.poolLB = (const int32_t *)PD(MZ_PD_BAND2)->p; c->b2.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND2)->p + mzi_al256(4 * nband));
+        c->b2.offBand = c->b.offBand;
+    }
+    if (mzk_pre(&c->q, &c->b, st)) return mzi_set_err("%s", mzk_last_error());
+    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
+    mz_dev_carve(&c->b, X->d_plan[set].p);
+    c->b.capTb = c->b.capScript = c->b.capOut = c->b.capPrep = INT64_MAX;
+    if (mzk_plan(&c->b, st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(X->h_tot[set].p, c->b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCK(hipEventRecord(X->bplan[set], st));
+    return 0;
+}
+
+/* size one stage's workspaces from its plan's totals and issue prep / DP / walk / emit */
+static int run_stage(mz_ctx *X, hipStream_t st, mz_dev_batch *b, int n, const int64_t *totals, gbuf *tb, gbuf *script, gbuf *prep, gbuf *out)
+{
+    if (mzi_dev_reserve(tb, 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(script, (size_t)totals[1] + 256) ||
+        mzi_dev_reserve(out, (size_t)totals[2] + 256) || mzi_dev_reserve(prep, 4 * (size_t)totals[4] + 256)) return -1;
+    b->tbw = (uint32_t *)tb->p; b->script = (uint8_t *)script->p; b->out = (uint8_t *)out->p; b->prep = (uint32_t *)prep->p;
+    b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap; b->capPrep = (int64_t)(prep->cap / 4);
+    b->walk_hint = mz_walk_choice(n, totals);
+    b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
+    (void)X;
+    if (mzk_prep(b, st) || mzk_dp(b, st) || mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
+    return 0;
+}
+
+/* k_fin and the copy of the results: 64-byte header, a record per merge, bases per row, the mask blocks */
+static int pchunk_finish(pchunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set, n = c->n;
+    hipStream_t st = X->bstream[set];
+    const size_t res_bytes = 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n) + mzi_al256(4 * c->nrow) + mzi_al256(c->mask_bytes);
+    char *dres;
+    if (mzi_dev_reserve(PD(MZ_PD_RES), res_bytes) || mzi_host_reserve(PH(MZ_PH_RES), res_bytes)) return -1;
+    dres = (char *)PD(MZ_PD_RES)->p;
+    c->f.any0 = c->any0;
+    c->f.hdr = (long long *)dres;
+    c->f.recs = (mz_pre_rec *)(dres + 64);
+    c->f.size = (int32_t *)(dres + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
+    c->f.masks = (uint8_t *)c->f.size + mzi_al256(4 * c->nrow);
+    HIPCK(hipMemsetAsync(dres, 0, 64, st));
+    if (mzk_fin(&c->q, &c->f, &c->b, &c->b2, st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipMemcpyAsync(PH(MZ_PH_RES)->p, dres, res_bytes, hipMemcpyDeviceToHost, st));
+    HIPCK(hipEventRecord(X->bdone[set], st));
+    c->res_bytes = res_bytes;
+    return 0;
+}
+
+/* stage 2: the first yama() of every merge */
+static int pchunk_launch1(pchunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set, n = c->n;
+    hipStream_t st = X->bstream[set];
+    c->t_l1a = mzi_now_s();
+    HIPCK(hipEventSynchronize(X->bplan[set]));
+    if (run_stage(X, st, &c->b, n, (const int64_t *)X->h_tot[set].p, &X->d_tb[set], &X->d_script[set], &X->d_prep[set], PD(MZ_PD_OUT1))) return -1;
+    if (c->any0) {
+        /* the second yama() job of the two-stage merges, derived where the first one's result lies (k_mid) */
+        c->b2.poolB = c->b.out;
+        if (mzk_mid(&c->q, &c->b, &c->b2, st)) return mzi_set_err("%s", mzk_last_error());
+        if (mzi_dev_reserve(PD(MZ_PD_PLAN2), mz_dev_plan_bytes(n)) || mzi_host_reserve(PH(MZ_PH_TOT2), 16 * sizeof(int64_t))) return -1;
+        mz_dev_carve(&c->b2, PD(MZ_PD_PLAN2)->p);
+        c->b2.capTb = c->b2.capScript = c->b2.capOut = c->b2.capPrep = INT64_MAX;
+        if (mzk_plan(&c->b2, st)) return mzi_set_err("%s", mzk_last_error());
+        HIPCK(hipMemcpyAsync(PH(MZ_PH_TOT2)->p, c->b2.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIPCK(hipEventRecord(X->pplan2[set], st));
+    } else if (pchunk_finish(c)) return -1;
+    c->t_l1b = mzi_now_s();
+    return 0;
+}
+
+/* stage 3: the second yama() of the two-stage merges (chunks without any pass through) */
+static int pchunk_launch2(pchunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set;
+    c->t_l2a = c->t_l2b = mzi_now_s();
+    if (!c->any0) return 0;
+    HIPCK(hipEventSynchronize(X->pplan2[set]));
+    if (run_stage(X, X->bstream[set], &c->b2, c->n, (const int64_t *)PH(MZ_PH_TOT2)->p, PD(MZ_PD_TB2), PD(MZ_PD_SCRIPT2), PD(MZ_PD_PREP2), PD(MZ_PD_OUT2))) return -1;
+    if (pchunk_finish(c)) return -1;
+    c->t_l2b = mzi_now_s();
+    return 0;
+}
+
+/* stage 4: results -> rows */
+typedef struct pasm {
+    const mz_prejob *jobs;
+    mz_preout *outs;
+    const mz_pre_rec *rec;
+    const int32_t *size;
+    const uint8_t *masks;
+    const int64_t *hoRow, *hoMask;
+    const size_t *where;
+    uint8_t *block;
+    int failed, oom;
+} pasm;
+
+#define PASM_ROWS 32
+static void assemble_merges(void *ctx, int lo, int hi)
+{
+    pasm *q = (pasm *)ctx;
+    int p, failed = 0;
+    for (p = lo; p < hi; ++p) {
+        const mz_prejob *j = &q->jobs[p];
+        const mz_pre_rec *r = &q->rec[p];
+        mz_preout *o = &q->outs[p];
+        const int W = j->K + j->L1 - 1, two = j->v == 0;
+        memset(o, 0, sizeof *o);
+        o->null_result = r->nullres; o->status = r->status; o->badrow = r->badrow; o->stage = r->stage; o->M = r->M; o->N = r->N;
+        if (r->nullres || r->status != MZ_OK) { failed++; continue; }
+        o->OM = r->om;
+        o->score = (double)r->score;
+        {
+            const size_t nb = (size_t)W * (size_t)r->om, pad = (nb + 7) & ~(size_t)7;
+            const size_t cap = two ? 2 * (size_t)j->M_all + j->N_all : (size_t)j->M_all + j->N_all, wc = (cap + 63) >> 6;
+            const uint64_t *mk = (const uint64_t *)(q->masks + q->hoMask[p]);
+            const uint64_t *opsA = mk, *opsB = mk + wc, *opsT = mk + 2 * wc, *keepA = mk + 3 * wc,
+                           *keepB = two ? keepA + (((size_t)j->M_all + 63) >> 6) : mk + 2 * wc;
+            const int sqA = two && r->M < j->M_all, sqB = r->N < j->N_all;      /* rmColDash dropped columns of that slice */
+            mz_rowspec small[PASM_ROWS], *rows = W <= PASM_ROWS ? small : (mz_rowspec *)malloc((size_t)W * sizeof *rows);
+            const size_t longest = (size_t)(j->M_all > j->N_all ? j->M_all : j->N_all);
+            uint8_t tmp_small[4096 + 16], *tmp = NULL;
+            int k;
+            if (two || sqB) tmp = longest + 16 <= sizeof tmp_small ? tmp_small : (uint8_t *)malloc(longest + 16);
+            if (!rows || ((two || sqB) && !tmp)) { if (rows != small) free(rows); q->oom = 1; o->status = MZ_E_DEVICE; failed++; continue; }
+            for (k = 0; k < j->K; ++k) {
+                mz_rowspec *s = &rows[k];
+                s->src = (const uint8_t *)j->rows1[k]; s->n = j->M_all; s->tmp = tmp;
+                if (two && k == 0) { s->squeeze = 2; s->keep = NULL; s->ops = opsT; }      /* the first block's top row: its bases */
+                else { s->squeeze = sqA; s->keep = keepA; s->ops = opsA; }
+            }
+            for (k = 1; k < j->L1; ++k) {
+                mz_rowspec *s = &rows[j->K + k - 1];
+                s->src = (const uint8_t *)j->rows2[k]; s->n = j->N_all; s->tmp = tmp;
+                s->squeeze = sqB; s->keep = keepB; s->ops = opsB;
+            }
+            o->rows = q->block + q->where[p];
+            if (p + 1 < hi) { _mm_prefetch((const char *)q->jobs[p + 1].rows1[0], _MM_HINT_T0); _mm_prefetch((const char *)q->jobs[p + 1].rows2[0], _MM_HINT_T0); }
+            mz_assemble_rows(W, rows, r->om, o->rows);
+            memcpy(o->rows + pad, q->size + q->hoRow[p], 4 * (size_t)W);
+            o->size = (const int *)(o->rows + pad);
+            if (rows != small) free(rows);
+            if (tmp && tmp != tmp_small) free(tmp);
+        }
+    }
+    if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
+    _mm_sfence();
+}
+
+static int pchunk_collect(pchunk *c)
+{
+    mz_ctx *X = c->X;
+    const int n = c->n, set = c->set;
+    const char *r = (const char *)PH(MZ_PH_RES)->p;
+    const mz_pre_rec *rec = (const mz_pre_rec *)(r + 64);
+    size_t *where, total = 0;
+    uint8_t *block = NULL;
+    pasm a;
+    int p;
+
+    c->t_col0 = mzi_now_s();
+    HIPCK(hipEventSynchronize(X->bdone[set]));
+    c->t_col1 = mzi_now_s();
+    c->cells = *(const int64_t *)r;
+    where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
+    if (!where) return mzi_set_err("out of memory");
+    /* ONE allocation for the chunk's rows and base counts; outs[first].block owns it (mz_free_preouts).  Every merge starts on
+     * a 64-byte line of its own (no line shared between two host threads; whole-line streaming stores) */
+    for (p = 0; p < n; ++p) {
+        const int W = c->jobs[p].K + c->jobs[p].L1 - 1;
+        where[p] = total;
+        if (rec[p].nullres || rec[p].status != MZ_OK) continue;
+        total += ((((size_t)W * (size_t)rec[p].om + 7) & ~(size_t)7) + 4 * (size_t)W + 63) & ~(size_t)63;
+    }
+    if (total) {
+        size_t mis;
+        block = (uint8_t *)mzi_block_get(total + 128);
+        if (!block) { free(where); return mzi_set_err("out of memory for the merged rows (%zu bytes)", total); }
+        mis = (size_t)(-(intptr_t)block & 63);
+        for (p = 0; p < n; ++p) where[p] += mis;
+    }
+    a.jobs = c->jobs; a.outs = c->outs; a.rec = rec;
+    a.size = (const int32_t *)(r + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
+    a.masks = (const uint8_t *)a.size + mzi_al256(4 * c->nrow);
+    a.hoRow = c->hoRow; a.hoMask = c->hoMask; a.where = where; a.block = block; a.failed = 0; a.oom = 0;
+    mzi_parallel_for(n, pre_grain(n), assemble_merges, &a);
+    c->outs[0].block = block;
+    free(where);
+    c->t_col2 = mzi_now_s();
+    if (a.oom) return mzi_set_err("out of memory for the merged rows");
+    return a.failed;
+}
+
+/* ------------------------------------------------------------------------------------------------ the pipeline */
+
+enum { ST_UP, ST_L1, ST_L2, ST_COL, ST_N };
+typedef struct ppipe {
+    mz_ctx *X;
+    pchunk ck[MZ_SETS];
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int through[ST_N];                     /* chunks through each stage */
+    int total;                             /* chunks in all; -1 until the packer has cut the last one */
+    int failed, rc, done;
+    int64_t cells, bytes_up, bytes_down;
+    double t0;
+    char err[600];
+} ppipe;
+
+static void ppipe_abort(ppipe *P)
+{
+    pthread_mutex_lock(&P->mu);
+    if (P->rc >= 0) { P->rc = -1; snprintf(P->err, sizeof P->err, "%s", mz_last_error()); }
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+
+static void pchunk_report(const ppipe *P, const pchunk *c)
+{
+    if (g_ptiming < 2) return;
+    fprintf(stderr, "{\"mz_preyama_batch_chunk\": %d, \"merges\": %d, \"two_stage\": %d, \"cells\": %lld, \"bytes_up\": %zu, \"bytes_down\": %zu, "
+                    "\"pack_ms\": [%.3f, %.3f], \"launch1_ms\": [%.3f, %.3f], \"launch2_ms\": [%.3f, %.3f], \"result_wait_ms\": [%.3f, %.3f], \"assembled_ms\": %.3f}\n",
+            c->index, c->n, c->any0, (long long)c->cells, c->in_bytes, c->res_bytes,
+            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_l1a - P->t0), 1e3 * (c->t_l1b - P->t0),
+            1e3 * (c->t_l2a - P->t0), 1e3 * (c->t_l2b - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0));
+}
+
+/* stage s = ST_L1, ST_L2, ST_COL: for chunk k = 0, 1, ...: wait until the stage before is through with it, do this one's part */
+static void stage_loop(ppipe *P, int s)
+{
+    int k;
+    hipSetDevice(P->X->device);
+    for (k = 0;; ++k) {
+        pchunk *c = &P->ck[k % MZ_SETS];
+        int rc;
+        pthread_mutex_lock(&P->mu);
+        while (P->rc >= 0 && P->through[s - 1] <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
+        pthread_mutex_unlock(&P->mu);
+        rc = s == ST_L1 ? pchunk_launch1(c) : s == ST_L2 ? pchunk_launch2(c) : pchunk_collect(c);
+        if (rc < 0) { ppipe_abort(P); break; }
+        if (s == ST_COL) pchunk_report(P, c);
+        pthread_mutex_lock(&P->mu);
+        if (s == ST_COL) { P->failed += rc; P->cells += c->cells; P->bytes_up += (int64_t)c->in_bytes; P->bytes_down += (int64_t)c->res_bytes; }
+        P->through[s] = k + 1;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+    }
+    pthread_mutex_lock(&P->mu);                          /* the last thing a stage does with the pipe */
+    P->done++;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+static void stage_l1(void *P) { stage_loop((ppipe *)P, ST_L1); }
+static void stage_l2(void *P) { stage_loop((ppipe *)P, ST_L2); }
+static void stage_col(void *P) { stage_loop((ppipe *)P, ST_COL); }
+
+static int pre_parts(void)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 12; }
+    return v;
+}
+
+#define PRE_MIN_CHUNK 1024
+static int next_pchunk(const mz_prejob *jobs, int n, int first, int limit, size_t max_bytes)
+{
+    size_t bytes = 0;
+    int m = 0;
+    while (first + m < n && m < limit && (bytes < max_bytes || (m < PRE_MIN_CHUNK && bytes < ((size_t)1 << 30)))) {
+        bytes += text_bytes(&jobs[first + m]);
+        ++m;
+    }
+    return m;
+}
+
+/* A call's share of one GPU, any size: MZ_SETS chunks at most are in flight.  stats: cells, bytes up, bytes down. */
+int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int64_t stats[3])
+{
+    ppipe *P;
+    size_t max_bytes = 0;
+    int k = 0, up = 0, rc = 0, s, threaded, max_pairs;
+    static int env_pairs = -1;
+
+    if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
+    P = (ppipe *)calloc(1, sizeof *P);
+    if (!P) return mzi_set_err("out of memory");
+    P->X = X; P->total = -1; P->t0 = mzi_now_s();
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+    for (s = 0; s < n; ++s) max_bytes += text_bytes(&jobs[s]);
+    max_bytes = max_bytes / (size_t)pre_parts() + 1;
+    if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
+    if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
+    {
+        const int per = (n + pre_parts() - 1) / pre_parts();
+        max_pairs = env_pairs ? env_pairs : per < PRE_MIN_CHUNK ? PRE_MIN_CHUNK : per > 16384 ? 16384 : per;
+    }
+    threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes) < n && mzi_workers_start(X->pworker, 3) == 0;
+    if (!threaded) {
+        while (up < n) {
+            pchunk *c = &P->ck[0];
+            const int m = next_pchunk(jobs, n, up, max_pairs, max_bytes);
+            int f;
+            if (pchunk_upload(X, c, k, 0, m, jobs + up, outs + up) < 0 || pchunk_launch1(c) < 0 || pchunk_launch2(c) < 0 || (f = pchunk_collect(c)) < 0) { rc = -1; break; }
+            pchunk_report(P, c);
+            P->cells += c->cells; P->bytes_up += (int64_t)c->in_bytes; P->bytes_down += (int64_t)c->res_bytes;
+            P->failed += f; up += m; ++k;
+        }
+        if (rc >= 0) rc = P->failed;
+    } else {
+        mzi_worker_give(&X->pworker[0], stage_l1, P);
+        mzi_worker_give(&X->pworker[1], stage_l2, P);
+        mzi_worker_give(&X->pworker[2], stage_col, P);
+        while (up < n) {
+            const int first_half = k == 0 && (max_pairs >= 2048 || max_bytes >= ((size_t)32 << 20));   /* the GPU starts that much earlier */
+            int m, bad;
+            pthread_mutex_lock(&P->mu);
+            while (P->rc >= 0 && k - P->through[ST_COL] >= MZ_SETS) pthread_cond_wait(&P->cv, &P->mu);    /* its buffer set is still in use */
+            bad = P->rc < 0;
+            pthread_mutex_unlock(&P->mu);
+            if (bad) break;
+            m = next_pchunk(jobs, n, up, first_half ? (max_pairs + 1) / 2 : max_pairs, first_half ? max_bytes / 2 : max_bytes);
+            if (pchunk_upload(X, &P->ck[k % MZ_SETS], k, k % MZ_SETS, m, jobs + up, outs + up) < 0) { ppipe_abort(P); break; }
+            up += m; ++k;
+            pthread_mutex_lock(&P->mu);
+            P->through[ST_UP] = k;
+            pthread_cond_broadcast(&P->cv);
+            pthread_mutex_unlock(&P->mu);
+        }
+        pthread_mutex_lock(&P->mu);
+        P->total = k;
+        pthread_cond_broadcast(&P->cv);
+        while (P->done < 3) pthread_cond_wait(&P->cv, &P->mu);
+        rc = P->rc < 0 ? -1 : P->failed;
+        pthread_mutex_unlock(&P->mu);
+        if (rc < 0) mzi_set_err("%s", P->err);
+    }
+    if (rc < 0) for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
+    if (stats) { stats[0] += P->cells; stats[1] += P->bytes_up; stats[2] += P->bytes_down; }
+    pthread_mutex_destroy(&P->mu);
+    pthread_cond_destroy(&P->cv);
+    free(P);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ entry point */
+
+typedef struct pre_task { mz_ctx *X; int n, rc; const mz_prejob *jobs; mz_preout *outs; int64_t st[3]; char err[600]; } pre_task;
+static void *pre_worker(void *arg)
+{
+    pre_task *t = (pre_task *)arg;
+    t->rc = mzi_pre_on_ctx(t->X, t->n, t->jobs, t->outs, t->st);
+    if (t->rc < 0) snprintf(t->err, sizeof t->err, "GPU %d: %s", t->X->device, mz_last_error());
+    return NULL;
+}
+
+static int64_t g_pre_last[3];
+
+int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
+{
+    int failed = 0, a, b, use, rc, p;
+    int64_t st[3] = { 0, 0, 0 };
+    int any0 = 0;
+    const double t_call = mzi_now_s();
+    if (n <= 0) return 0;
+    if (!jobs || !outs) return mzi_set_err("mz_preyama_batch: NULL jobs or outs");
+    if (g_ptiming < 0) g_ptiming = mzi_timing();
+    for (p = 0; p < n; ++p) {
+        const mz_prejob *j = &jobs[p];
+        if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1 || !j->rows1 || !j->rows2)
+            return mzi_set_err("mz_preyama_batch: job %d has an empty block or slice", p);
+        if (j->v != 0 && j->v != 1) return mzi_set_err("mz_preyama_batch: job %d: v = %d (0 or 1)", p, j->v);
+        if (j->v == 0) any0 = 1;
+    }
+    pthread_mutex_lock(&g_big);
+    if (mzi_ensure_init() || mzi_sync_scores()) { pthread_mutex_unlock(&g_big); return -1; }
+    for (a = 0; a < 128; ++a)                              /* k_fin's pair sums need ss[x][y] == ss[y][x] */
+        for (b = 0; b < a; ++b)
+            if (ss[a][b] != ss[b][a]) { pthread_mutex_unlock(&g_big); mzi_set_err("score table is not symmetric"); return -2; }
+    for (p = 0; p < n; ++p) { memset(&outs[p], 0, sizeof outs[p]); outs[p].status = MZ_E_DEVICE; }
+    use = g_ndev;
+    while (use > 1 && n / use < MZ_MULTI_MIN) --use;
+    if (use == 1) {
+        rc = mzi_pre_on_ctx(&G, n, jobs, outs, st);
+    } else {
+        /* several GPUs: contiguous ranges of about equal text volume, one host thread per GPU (as mz_yama_batch) */
+        pre_task task[MZ_MAX_DEV];
+        pthread_t th[MZ_MAX_DEV];
+        double total = 0.0, acc = 0.0;
+        int d = 0, start = 0, started[MZ_MAX_DEV];
+        for (p = 0; p < n; ++p) total += (double)text_bytes(&jobs[p]);
+        for (p = 0; p < n && d < use; ++p) {
+            acc += (double)text_bytes(&jobs[p]);
+            if (d == use - 1) { p = n - 1; acc = total; }
+            if (acc >= total * (d + 1) / use || p == n - 1) {
+                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
+                task[d].n = p + 1 - start; task[d].rc = 0; task[d].err[0] = 0; memset(task[d].st, 0, sizeof task[d].st);
+                start = p + 1; ++d;
+            }
+        }
+        use = d;
+        for (d = 1; d < use; ++d) {
+            started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, pre_worker, &task[d]) == 0;
+            if (!started[d] && task[d].n > 0) pre_worker(&task[d]);
+        }
+        if (task[0].n > 0) pre_worker(&task[0]);
+        rc = 0;
+        for (d = 0; d < use; ++d) {
+            if (d >= 1 && started[d]) pthread_join(th[d], NULL);
+            if (task[d].n <= 0) continue;
+            if (task[d].rc < 0) { rc = -1; mzi_set_err("%s", task[d].err); }
+            else failed += task[d].rc;
+            st[0] += task[d].st[0]; st[1] += task[d].st[1]; st[2] += task[d].st[2];
+        }
+        hipSetDevice(G.device);
+        if (rc >= 0) rc = failed;
+    }
+    g_pre_last[0] = st[0]; g_pre_last[1] = st[1]; g_pre_last[2] = st[2];
+    pthread_mutex_unlock(&g_big);
+    if (g_ptiming && rc >= 0) {
+        const double dt = mzi_now_s() - t_call;
+        fprintf(stderr, "{\"mz_preyama_batch\": {\"merges\": %d, \"two_stage\": %d, \"without_block\": %d, \"cells\": %lld, \"seconds\": %.6f, \"gcups\": %.2f, "
+                        "\"bytes_up\": %lld, \"bytes_down\": %lld, \"gpus\": %d}}\n",
+                n, any0, rc, (long long)st[0], dt, (double)st[0] / dt / 1e9, (long long)st[1], (long long)st[2], use);
+    }
+    return rc;
+}
+
+void mz_pre_link_bytes(int64_t *up, int64_t *down, int64_t *cells)
+{
+    if (cells) *cells = g_pre_last[0];
+    if (up) *up = g_pre_last[1];
+    if (down) *down = g_pre_last[2];
+}
+
+void mz_free_preouts(int n, mz_preout *outs)
+{
+    int p;
+    for (p = 0; p < n; ++p) { mzi_block_put(outs[p].block); outs[p].block = NULL; outs[p].rows = NULL; outs[p].size = NULL; }
+}

@@ -137,3 +137,71 @@ def test_assemble_matches_the_oracle(lib, K, L):
             lib.mz_assemble_cols(K, L, M, N, A.ctypes.data, B.ctypes.data, script.ctypes.data, want.OM, out.ctypes.data)
             assert np.array_equal(out[:nb].reshape(want.OM, K + L), want.cols), (K, L, M, N, phase)
             assert (out[nb:] == 0xEE).all() and (buf[:phase] == 0xEE).all()     # neighbours' bytes untouched
+
+
+# ---------------------------------------------------------------------------------------- merged rows (mz_preyama_batch)
+
+class RowSpec(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("n", C.c_int), ("squeeze", C.c_int), ("keep", C.c_void_p), ("ops", C.c_void_p), ("tmp", C.c_void_p)]
+
+
+def bits_to_words(bits: np.ndarray) -> np.ndarray:
+    """bool per column -> uint64 words, bit c & 63 of word c >> 6 (the layout k_fin writes)"""
+    pad = np.zeros((len(bits) + 63) // 64 * 64, dtype=np.uint8)
+    pad[: len(bits)] = bits
+    return np.packbits(pad.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+
+
+def make_rows(rng, om, nrows, squeeze):
+    """random source rows whose masks take exactly their bytes; returns (specs keep-alive, expected rows)"""
+    letters = np.frombuffer(b"ACGTacgtNn-", dtype=np.uint8)
+    keep, want = [], []
+    specs = (RowSpec * nrows)()
+    for r in range(nrows):
+        ops = rng.random(om) < rng.choice([0.05, 0.5, 0.95, 1.0])
+        taken = int(ops.sum())
+        mode = squeeze if squeeze != 3 else int(rng.integers(0, 3))
+        if mode == 0:
+            src = letters[rng.integers(0, len(letters), size=taken)]
+            kept, kw = src, None
+        elif mode == 1:
+            n = taken + int(rng.integers(0, 40))
+            kb = np.zeros(n, dtype=bool)
+            kb[rng.choice(n, size=taken, replace=False)] = True
+            src = letters[rng.integers(0, len(letters), size=n)]
+            kept, kw = src[kb], bits_to_words(kb)
+        else:
+            n = taken + int(rng.integers(0, 40))
+            src = np.full(n, ord("-"), dtype=np.uint8)
+            pos = np.sort(rng.choice(n, size=taken, replace=False))
+            src[pos] = letters[rng.integers(0, 10, size=taken)]          # (no dash among the bases)
+            kept, kw = src[pos], None
+        src = np.ascontiguousarray(src)
+        ow = bits_to_words(ops)
+        tmp = np.zeros(len(src) + 16, dtype=np.uint8)
+        row = np.full(om, ord("-"), dtype=np.uint8)
+        row[ops] = kept
+        want.append(row)
+        keep += [src, kw, ow, tmp]
+        specs[r].src, specs[r].n, specs[r].squeeze = src.ctypes.data, len(src), mode
+        specs[r].keep = kw.ctypes.data if kw is not None else None
+        specs[r].ops, specs[r].tmp = ow.ctypes.data, tmp.ctypes.data
+    return specs, keep, want
+
+
+@pytest.mark.parametrize("om", [1, 7, 15, 16, 17, 63, 64, 65, 1000, 2048, 2049, 5000])
+@pytest.mark.parametrize("squeeze", [0, 1, 2, 3])
+def test_assemble_rows(lib, om, squeeze):
+    """rows of a merged block from source bytes + masks (mz_assemble_rows): every spread / squeeze form against numpy, at
+    every phase of the output within a 64-byte line, nothing written outside the block"""
+    lib.mz_assemble_rows.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(om * 4 + squeeze)
+    for nrows in (1, 2, 5):
+        specs, keep, want = make_rows(rng, om, nrows, squeeze)
+        for phase in (0, 1, 31, 63):
+            out = aligned(nrows * om + 128, 64, phase)
+            out[:] = 0xEE
+            lib.mz_assemble_rows(nrows, C.cast(specs, C.c_void_p), om, out[64:].ctypes.data)
+            got = out[64: 64 + nrows * om].reshape(nrows, om)
+            assert np.array_equal(got, np.stack(want)), (om, squeeze, nrows, phase)
+            assert (out[:64] == 0xEE).all() and (out[64 + nrows * om:] == 0xEE).all()

@@ -392,3 +392,18 @@ def test_device_two_stage_merges_random_blocks(product):
     j, cb1, cb2 = _prejob(a1, a2, beg, end, 30)
     r = m.preyama_batch([j + (0,)])[0]
     assert r["null_code"] == 1 and mo.pre_yama(a1, a2, beg, end, 30, 0)[0] is None
+
+
+@pytest.mark.gpu
+def test_preyama_batch_chunk_pipeline(product):
+    # mz_preyama_batch() cuts a call into chunks that go through four stages on rotating buffer sets (mz_prebatch.c: packer, two
+    # launchers, collector).  MZ_CHUNK_PAIRS=23 (read once per process, hence the child) makes 300 merges -- one- and two-stage
+    # mixed, dash-heavy, NULL results in between -- thirteen chunks on the threaded pipeline; every block against the oracle
+    import subprocess
+    import sys
+    env = dict(os.environ, MZ_CHUNK_PAIRS="23")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "preyama_sweep.py"), "0", "2"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert last.startswith("merges 600") and last.endswith("bad 0"), p.stdout[-2000:]
