@@ -248,6 +248,105 @@ def ngpu_mode(args):
         "link_bytes_per_pair": {"up": round(link[0] / pairs, 1), "down": round(link[1] / pairs, 1)}}))
 
 
+# ------------------------------------------------------------------------------------------ block text in, block rows out
+
+def pre_check(pb, outs, idx, radius):
+    """parity gate of the text path: the sampled merges through the compiled reference's pre_yama() (oracle/_ref/libref.so;
+    the oracle's Python restatement when that is absent) -- rows, base counts and score of every block.  Checker code."""
+    import numpy as np
+    from multiz_amd import api, synth
+    from oracle import mzoracle as mo
+    ref = mo.Reference() if mo.have_reference() else None
+    bad = 0
+    for i in idx:
+        i = int(i)
+        r1, r2 = synth.pre_rows_of(pb, i)
+        v = int(pb["jobs"]["v"][i])
+
+        def blk(rows, names):
+            return mo.Block(rows=[mo.Row(src=nm, start=0, size=sum(c != 0x2D for c in t), strand="+", srcSize=1 << 24, text=t.decode("ascii"))
+                                  for nm, t in zip(names, rows)])
+        a1 = blk(r1, ["ref.c"] + [f"a{k}.c" for k in range(1, len(r1))])
+        a2 = blk(r2, ["ref.c"] + [f"b{k}.c" for k in range(1, len(r2))])
+        end = a1.rows[0].size - 1
+        want = ref.pre_yama(a1, a2, 0, end, radius, v) if ref else mo.pre_yama(a1, a2, 0, end, radius, v)[0]
+        rows, size = api.preout_rows(outs, i, len(r1) + len(r2) - 1)
+        if want is None or rows is None:
+            bad += not (want is None and rows is None)
+            continue
+        got = [(t.decode("ascii"), int(sz)) for t, sz in zip(rows, size) if sz > 0]
+        if got != [(r.text, r.size) for r in want.rows] or float(outs["score"][i]) != want.score:
+            bad += 1
+    return bad, ("reference pre_yama() (oracle/_ref/libref.so)" if ref else "oracle restatement of pre_yama()")
+
+
+def pre_column(config, pairs, check):
+    """`value_pre`: the batch as block TEXT through mz_preyama_batch() -- class nibbles up, rmColDash + band + smooth + yama()
+    (both of them for v = 0) + base counts + mafScoreRange on the GPU, a record and column bits back, the merged block's rows put
+    together on the host -- one-stage (v = 1) and two-stage (v = 0) merges; median of five calls each.  The text shapes are the
+    yama-level configuration's (synth.make_pre_batch: K rows over L rows below the shared reference row, R reference bases in the
+    config's column range, 2 runs of unshared columns per 1 000 bases)."""
+    import numpy as np
+    from multiz_amd import api, synth
+    cfg = synth.CONFIGS[config]
+    out = {}
+    for v, key in ((1, "v1"), (0, "v0")):
+        pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 2), v=v)
+        jobs, outs = pb["jobs"], pb["outs"]
+        for _ in range(2):                                       # warm-up: staging buffers and result blocks grow to size
+            rc = api.preyama_batch_records(jobs, outs)
+            api.free_preouts(outs)
+        time.sleep(0.3)
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            rc = api.preyama_batch_records(jobs, outs)
+            ts.append(time.perf_counter() - t)
+            api.free_preouts(outs)
+            time.sleep(0.05)
+        up, down, cells = api.pre_link_bytes()
+        t_med = float(np.median(ts))
+        d = {"gcups": round(cells / t_med / 1e9, 2), "ms_per_batch": round(1e3 * t_med, 2), "ms_all": [round(1e3 * x, 2) for x in ts],
+             "band_cells": cells, "merges": int(pairs), "without_block": int(rc), "two_stage_merges": int((jobs["v"] == 0).sum()),
+             "link_bytes_per_merge": {"up": round(up / pairs, 1), "down": round(down / pairs, 1)},
+             "text_bytes_per_merge": round(float((pb["K"].astype(np.int64) * pb["Ma"] + pb["L1"].astype(np.int64) * pb["Na"]).mean()), 1)}
+        if check:
+            api.preyama_batch_records(jobs, outs)                # (untimed call: the rows the checker reads)
+            idx = np.random.default_rng(777).permutation(pairs)[: min(pairs, check)]
+            bad, what = pre_check(pb, outs, idx, cfg["radius"])
+            api.free_preouts(outs)
+            if bad:
+                raise SystemExit(f"PARITY FAILURE (text path, v = {v}): {bad} of {len(idx)} sampled merges differ from the {what} -- number void")
+            d["parity"] = f"ok: {len(idx)} sampled merges (rows, base counts, score) identical to the {what}"
+        out[key] = d
+        del pb
+    return out
+
+
+def pre_mode(args):
+    """`--mode pre`: only the text path, `steps` calls of mz_preyama_batch() over one batch (what the rocprofv3 passes behind
+    profiles/r4_*pre* run: k_pre / k_mid / k_fin beside the DP kernels)"""
+    import numpy as np
+    from multiz_amd import api, synth
+    api.init(0)
+    cfg = synth.CONFIGS[args.config]
+    pairs = args.pairs or cfg["pairs"]
+    pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 2), v=args.pre_v)
+    ts = []
+    for i in range(args.warmup + args.steps):
+        t = time.perf_counter()
+        api.preyama_batch_records(pb["jobs"], pb["outs"])
+        ts.append(time.perf_counter() - t)
+        api.free_preouts(pb["outs"])
+    up, down, cells = api.pre_link_bytes()
+    t_med = float(np.median(ts[args.warmup:]))
+    print(json.dumps({"metric": "GCUPS (DP cell updates/s) on pre_yama merges, block text in, block rows out", "mode": "pre",
+                      "value": round(cells / t_med / 1e9, 2), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(1e3 * t_med, 3), "merges": pairs, "two_stage_merges": int((pb["jobs"]["v"] == 0).sum()),
+                      "band_cells": cells, "link_bytes_per_merge": {"up": round(up / pairs, 1), "down": round(down / pairs, 1)},
+                      "config": {"workload": synth.describe(args.config, pairs) + " -- as block text"}}))
+
+
 # ------------------------------------------------------------------------------------------ main
 
 def algorithmic_bytes(batch, om):
@@ -270,9 +369,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) column")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) columns")
+    ap.add_argument("--no-pre", action="store_true", help="skip the block-text column (value_pre)")
+    ap.add_argument("--pre-check", type=int, default=300, help="merges per variant the text path's parity gate samples (0: none)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 builds the whole list and deals it out (multiz_amd.shard)")
-    ap.add_argument("--mode", default="ranks", choices=["ranks", "ngpu"],
+    ap.add_argument("--pre-v", type=int, default=2, help="--mode pre: 1 one-stage merges, 0 two-stage, 2 alternating")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "ngpu", "pre"],
                     help="ranks: one process per GPU (torch.distributed, the scaling measurement); ngpu: ONE process, the C path "
                          "mz_init_multi(N) + mz_yama_batch() over a host list of N x pairs -- what mz_multiz / mz_roast use on a node")
     ap.add_argument("--cpu-leg", default="", help=argparse.SUPPRESS)
@@ -281,6 +383,8 @@ def main():
         return cpu_leg(args.cpu_leg)
     if args.mode == "ngpu":
         return ngpu_mode(args)
+    if args.mode == "pre":
+        return pre_mode(args)
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -523,6 +627,13 @@ def main():
         out["host_ms_all"] = [round(1e3 * x, 2) for x in t_host]
         link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
         out["host_link_bytes_per_pair"] = {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}
+
+    # ---- the text path: what mz_multiz / mz_roast run every merge through.  N = 1 only.
+    if rank == 0 and world == 1 and not args.no_host and not args.no_pre:
+        pre = pre_column(args.config, pairs, 0 if args.no_cpu else args.pre_check)
+        out["value_pre"] = pre["v1"]["gcups"]
+        out["value_pre_v0"] = pre["v0"]["gcups"]
+        out["pre"] = pre
 
     # ---- parity gate against the CPU leg's hashes (rank 0, N=1 only)
     if cpu is not None:

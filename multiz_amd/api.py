@@ -239,6 +239,39 @@ def preyama_batch(jobs: Sequence[tuple]):
     return out
 
 
+def preyama_batch_records(jobs: np.ndarray, outs: np.ndarray) -> int:
+    """mz_preyama_batch() on record arrays (synth.make_pre_batch); the caller reads outs and then calls free_preouts()"""
+    f = lib().mz_preyama_batch
+    f.argtypes = [C.c_int, C.POINTER(PreJob), C.POINTER(PreOut)]
+    rc = f(len(jobs), jobs.ctypes.data_as(C.POINTER(PreJob)), outs.ctypes.data_as(C.POINTER(PreOut)))
+    _check(rc, "mz_preyama_batch")
+    return rc
+
+
+def free_preouts(outs: np.ndarray):
+    f = lib().mz_free_preouts
+    f.argtypes = [C.c_int, C.POINTER(PreOut)]
+    f(len(outs), outs.ctypes.data_as(C.POINTER(PreOut)))
+
+
+def pre_link_bytes():
+    """(bytes up, bytes down, band cells) of the last mz_preyama_batch() call"""
+    up, down, cells = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    lib().mz_pre_link_bytes(C.byref(up), C.byref(down), C.byref(cells))
+    return up.value, down.value, cells.value
+
+
+def preout_rows(outs: np.ndarray, i: int, W: int):
+    """rows (list of bytes) and base counts of merge i of a finished call, None without a block"""
+    o = outs[i]
+    if not o["rows"]:
+        return None, None
+    om = int(o["OM"])
+    raw = C.string_at(int(o["rows"]), W * om)
+    size = np.ctypeslib.as_array(C.cast(int(o["size"]), C.POINTER(C.c_int)), shape=(W,)).copy()
+    return [raw[k * om:(k + 1) * om] for k in range(W)], size
+
+
 def yama_one(A, B, LB, RB) -> Result:
     return yama_batch([(A, B, LB, RB)])[0]
 

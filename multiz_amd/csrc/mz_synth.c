@@ -215,6 +215,103 @@ void mz_synth_bands_indel(int n, uint64_t seed, int64_t first_pair, int radius, 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ block TEXT
+ * Inputs of mz_preyama_batch(): two blocks topped by the same reference row, over their overlap (what the drivers hand
+ * to pre_yama(), mz_preyama.c:152-172).  Merge p: R reference bases (uniform in [rlo, rhi]); block 1 has K rows (its top
+ * row is the reference), block 2 has L rows below ITS copy of the reference row (L1 = L + 1), so that the yama() job of a
+ * one-stage merge is K x L rows -- the shapes of the yama-level configurations.  Either block has runs of columns the
+ * other lacks (the reference row holds dashes there): `events` runs per 1 000 reference bases, half in each block,
+ * lengths geometric with mean 3 -- the band pre_yama derives walks around them exactly as mz_synth_bands_indel's does.
+ * Rows below the top: the reference base, substituted with probability 0.10, a dash with 0.08; 5 columns per 1 000 are
+ * all dashes below the top row (rmColDash, mz_preyama.c:87-108, has something to drop).  Text of merge p at
+ * pool + offText[p]: K rows of Ma bytes, then L1 rows of Na bytes. */
+typedef struct { int R, Ma, Na; } pre_shape;
+static int pre_run(rng_t *w, int events) { return (int)below(w, 2000) < events ? indel_run(w) : 0; }
+static pre_shape pre_walk(uint64_t seed, int64_t p, int K, int rlo, int rhi, int events, uint8_t *ins1, uint8_t *ins2)
+{
+    rng_t r, w;
+    pre_shape s;
+    int i;
+    rng_seed(&r, seed, (uint64_t)p);
+    rng_seed(&w, seed ^ 0x2E2E2E2EULL, (uint64_t)p);
+    s.R = rlo + (int)below(&r, (unsigned)(rhi - rlo + 1));
+    s.Ma = s.Na = s.R;
+    for (i = 0; i < s.R; ++i) {                           /* runs of unshared columns in front of reference base i */
+        const int g1 = (K > 1 && i > 0) ? pre_run(&w, events) : 0, g2 = i > 0 ? pre_run(&w, events) : 0;
+        if (ins1) ins1[i] = (uint8_t)(g1 > 255 ? 255 : g1);
+        if (ins2) ins2[i] = (uint8_t)(g2 > 255 ? 255 : g2);
+        s.Ma += g1 > 255 ? 255 : g1; s.Na += g2 > 255 ? 255 : g2;
+    }
+    return s;
+}
+
+void mz_synth_pre_shapes(int n, uint64_t seed, int64_t first_pair, int K, int L, int rlo, int rhi, int events,
+                         int32_t *aK, int32_t *aL1, int32_t *aMa, int32_t *aNa, int64_t *offText, int64_t *total)
+{
+    int64_t ot = 0;
+    int p;
+    for (p = 0; p < n; ++p) {
+        pre_shape s;
+        if (K == 0 && L == 0) {                          /* (K, L) of a random node of the C4 guide tree */
+            rng_t r;
+            unsigned node;
+            rng_seed(&r, seed ^ 0x3C3C3C3CULL, (uint64_t)(first_pair + p));
+            node = below(&r, 29);
+            aK[p] = tree30[node][0]; aL1[p] = tree30[node][1] + 1;
+        } else { aK[p] = K; aL1[p] = L + 1; }
+        s = pre_walk(seed, first_pair + p, aK[p], rlo, rhi, events, NULL, NULL);
+        aMa[p] = s.Ma; aNa[p] = s.Na;
+        offText[p] = ot;
+        ot += (int64_t)aK[p] * s.Ma + (int64_t)aL1[p] * s.Na;
+    }
+    *total = ot;
+}
+
+static void pre_rows(rng_t *r, uint8_t *T, int rows, int cols, const uint8_t *ref, const uint8_t *ins, int R)
+{
+    int i, c = 0, k, g;
+    for (i = 0; i < R; ++i) {
+        for (g = 0; g < ins[i]; ++g, ++c) {              /* a column the other block lacks: a dash in the reference row */
+            int nd = 0;
+            T[c] = '-';
+            for (k = 1; k < rows; ++k) { const unsigned char ch = chance(r, 300) ? '-' : base_byte(r, 0); T[(size_t)k * cols + c] = ch; nd += ch != '-'; }
+            if (!nd) T[(size_t)(1 + below(r, (unsigned)(rows - 1))) * cols + c] = base_byte(r, 0);
+        }
+        {
+            const int odd = chance(r, 50), alldash = chance(r, 5);
+            T[c] = ref[i];
+            for (k = 1; k < rows; ++k) {
+                unsigned char ch = ref[i];
+                if (chance(r, 100)) ch = base_byte(r, odd);
+                if (alldash || chance(r, 80)) ch = '-';
+                T[(size_t)k * cols + c] = ch;
+            }
+            ++c;
+        }
+    }
+}
+
+void mz_synth_pre_fill(int n, uint64_t seed, int64_t first_pair, int rlo, int rhi, int events,
+                       const int32_t *aK, const int32_t *aL1, const int32_t *aMa, const int32_t *aNa, const int64_t *offText, uint8_t *pool)
+{
+    int p;
+#pragma omp parallel for schedule(dynamic, 64) if (n > 256)
+    for (p = 0; p < n; ++p) {
+        uint8_t *ref = (uint8_t *)malloc(3 * ((size_t)rhi + 1)), *ins1 = ref + rhi + 1, *ins2 = ins1 + rhi + 1;
+        uint8_t *T1 = pool + offText[p], *T2 = T1 + (size_t)aK[p] * aMa[p];
+        rng_t r;
+        pre_shape s;
+        int i;
+        if (!ref) continue;
+        s = pre_walk(seed, first_pair + p, aK[p], rlo, rhi, events, ins1, ins2);
+        rng_seed(&r, seed ^ 0x5A5A5A5AULL, (uint64_t)(first_pair + p));
+        for (i = 0; i < s.R; ++i) ref[i] = base_byte(&r, chance(&r, 50));
+        pre_rows(&r, T1, aK[p], aMa[p], ref, ins1, s.R);
+        pre_rows(&r, T2, aL1[p], aNa[p], ref, ins2, s.R);
+        free(ref);
+    }
+}
+
 /* src[off[i] .. off[i]+len[i]) (elements of `elem` bytes) to dst[pos[i] ..): the re-packing step of sharding a
  * batch (multiz_amd/shard.py) and of sampling one (bench.py), one memcpy per segment on the host threads.  `pos` is the
  * caller's exclusive prefix sum of len (no allocation here, nothing that can fail half-way).  Returns 0, -1 on bad

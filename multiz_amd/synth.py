@@ -118,3 +118,62 @@ def pack_pairs(pairs) -> dict:
     out.update(offA=np.array(oa, dtype=np.int64), offB=np.array(ob, dtype=np.int64), offBand=np.array(od, dtype=np.int64),
                poolA=np.concatenate(pa), poolB=np.concatenate(pb), poolLB=np.concatenate(plb), poolRB=np.concatenate(prb))
     return out
+
+
+# ------------------------------------------------------------------------------------------ block TEXT (mz_preyama_batch)
+
+PREJOB_DT = np.dtype({"names": ["K", "L1", "M_all", "N_all", "radius", "rows1", "rows2", "v"],
+                      "formats": ["<i4", "<i4", "<i4", "<i4", "<i4", "<u8", "<u8", "<i4"],
+                      "offsets": [0, 4, 8, 12, 16, 24, 32, 40], "itemsize": 48})
+PREOUT_DT = np.dtype({"names": ["status", "badrow", "null_result", "stage", "M", "N", "OM", "score", "size", "rows", "block"],
+                      "formats": ["<i4"] * 7 + ["<f8", "<u8", "<u8", "<u8"],
+                      "offsets": [0, 4, 8, 12, 16, 20, 24, 32, 40, 48, 56], "itemsize": 64})
+
+
+def make_pre_batch(n: int, K: int, L: int, rlo: int, rhi: int, radius: int = 30, events: int = 2, v: int = 1,
+                   seed: int = BASE_SEED, first_pair: int = 0) -> dict:
+    """n merges as mz_prejob records over one text pool (mz_synth_pre_shapes / mz_synth_pre_fill): block 1 of K rows, block 2 of
+    L rows below its copy of the shared reference row, R ~ U[rlo, rhi] reference bases, `events` runs of unshared columns per
+    1 000 bases.  v: 1 one-stage merges, 0 two-stage (merges whose first block has a single row stay one-stage), 2 alternating.
+    The returned dict keeps everything the records point into alive."""
+    from .api import PreJob, PreOut
+    l = lib()
+    assert PREJOB_DT.itemsize == C.sizeof(PreJob) and PREOUT_DT.itemsize == C.sizeof(PreOut)
+    aK, aL1, aMa, aNa = (np.zeros(n, dtype=np.int32) for _ in range(4))
+    off = np.zeros(n, dtype=np.int64)
+    tot = C.c_int64(0)
+    l.mz_synth_pre_shapes.argtypes = [C.c_int, C.c_uint64, C.c_int64] + [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_void_p]
+    l.mz_synth_pre_shapes(n, seed, first_pair, K, L, rlo, rhi, events, aK.ctypes.data, aL1.ctypes.data, aMa.ctypes.data, aNa.ctypes.data,
+                          off.ctypes.data, C.cast(C.byref(tot), C.c_void_p))
+    pool = np.zeros(max(tot.value, 1) + 64, dtype=np.uint8)
+    l.mz_synth_pre_fill.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    l.mz_synth_pre_fill(n, seed, first_pair, rlo, rhi, events, aK.ctypes.data, aL1.ctypes.data, aMa.ctypes.data, aNa.ctypes.data,
+                        off.ctypes.data, pool.ctypes.data)
+    # row pointers: K of block 1, then L1 of block 2, merge after merge
+    nptr = aK.astype(np.int64) + aL1
+    pstart = np.concatenate(([0], np.cumsum(nptr)))
+    ptrs = np.zeros(int(pstart[-1]), dtype=np.uint64)
+    base = pool.ctypes.data + off
+    which = np.repeat(np.arange(n), nptr)
+    k = np.arange(int(pstart[-1])) - pstart[which]
+    in1 = k < aK[which]
+    ptrs[:] = np.where(in1, base[which] + k * aMa[which].astype(np.int64),
+                       base[which] + aK[which].astype(np.int64) * aMa[which] + (k - aK[which]) * aNa[which].astype(np.int64)).astype(np.uint64)
+    jobs = np.zeros(n, dtype=PREJOB_DT)
+    jobs["K"], jobs["L1"], jobs["M_all"], jobs["N_all"], jobs["radius"] = aK, aL1, aMa, aNa, radius
+    jobs["rows1"] = ptrs.ctypes.data + 8 * pstart[:-1].astype(np.uint64)
+    jobs["rows2"] = ptrs.ctypes.data + 8 * (pstart[:-1] + aK).astype(np.uint64)
+    vv = np.full(n, 1, dtype=np.int32) if v == 1 else np.zeros(n, dtype=np.int32) if v == 0 else (np.arange(n) % 2).astype(np.int32)
+    vv[aK < 2] = 1
+    jobs["v"] = vv
+    return dict(jobs=jobs, outs=np.zeros(n, dtype=PREOUT_DT), pool=pool, ptrs=ptrs, off=off, K=aK, L1=aL1, Ma=aMa, Na=aNa)
+
+
+def pre_rows_of(pb: dict, i: int):
+    """(rows1, rows2) of merge i as lists of bytes"""
+    K, L1, Ma, Na, o = int(pb["K"][i]), int(pb["L1"][i]), int(pb["Ma"][i]), int(pb["Na"][i]), int(pb["off"][i])
+    t = pb["pool"]
+    r1 = [t[o + k * Ma: o + (k + 1) * Ma].tobytes() for k in range(K)]
+    o2 = o + K * Ma
+    r2 = [t[o2 + k * Na: o2 + (k + 1) * Na].tobytes() for k in range(L1)]
+    return r1, r2
