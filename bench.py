@@ -285,13 +285,13 @@ def pre_column(config, pairs, check):
     (both of them for v = 0) + base counts + mafScoreRange on the GPU, a record and column bits back, the merged block's rows put
     together on the host -- one-stage (v = 1) and two-stage (v = 0) merges; median of five calls each.  The text shapes are the
     yama-level configuration's (synth.make_pre_batch: K rows over L rows below the shared reference row, R reference bases in the
-    config's column range, 2 runs of unshared columns per 1 000 bases)."""
+    config's column range; the indel configurations' runs of unshared columns, none otherwise: the band is the diagonal's)."""
     import numpy as np
     from multiz_amd import api, synth
     cfg = synth.CONFIGS[config]
     out = {}
     for v, key in ((1, "v1"), (0, "v0")):
-        pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 2), v=v)
+        pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 0), v=v)
         jobs, outs = pb["jobs"], pb["outs"]
         for _ in range(2):                                       # warm-up: staging buffers and result blocks grow to size
             rc = api.preyama_batch_records(jobs, outs)
@@ -331,7 +331,7 @@ def pre_mode(args):
     api.init(0)
     cfg = synth.CONFIGS[args.config]
     pairs = args.pairs or cfg["pairs"]
-    pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 2), v=args.pre_v)
+    pb = synth.make_pre_batch(pairs, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], events=cfg.get("indel", 0), v=args.pre_v)
     ts = []
     for i in range(args.warmup + args.steps):
         t = time.perf_counter()

@@ -295,8 +295,9 @@ static int chunk_launch(chunk *c)
     if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
         return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 4, st);
-    HIPCK(hipMemcpyAsync(X->h_res[set].p, dres, res_bytes, hipMemcpyDeviceToHost, st));
-    TSTAMP(X, set, 5, st);
+    /* The copy of the results is NOT issued here: the copy engine takes its commands in order, and a copy that has to wait
+     * for this chunk's kernels holds up the uploads of the chunks behind it (round 4: the H2D of chunk k+3 started when the
+     * results of chunk k were through).  The collector issues it once the chunk's last kernel is done. */
     HIPCK(hipEventRecord(X->bdone[set], st));
     c->b = b; c->res_bytes = (int64_t)res_bytes;
     c->t_launch2 = mzi_now_s();
@@ -353,6 +354,9 @@ static int chunk_collect(chunk *c)
 
     c->t_col0 = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bdone[set]));
+    HIPCK(hipMemcpyAsync(X->h_res[set].p, X->d_res[set].p, (size_t)c->res_bytes, hipMemcpyDeviceToHost, X->bstream[set]));
+    TSTAMP(X, set, 5, X->bstream[set]);
+    HIPCK(hipStreamSynchronize(X->bstream[set]));
     c->t_col1 = mzi_now_s();
     c->cells = *(const int64_t *)r;
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);

@@ -80,6 +80,8 @@ typedef struct mz_ctx {
      * stage uses those): device buffers pd[set][PD_*], pinned host buffers ph[set][PH_*]; `pplan2`: the second stage's plan is through */
     gbuf pd[MZ_SETS][MZ_PD_N], ph[MZ_SETS][MZ_PH_N];
     hipEvent_t pplan2[MZ_SETS];
+    hipEvent_t ptime[MZ_SETS][8];          /* MZ_TIMING=2: before the upload, uploaded, k_pre done, planned, first DP done, first emit done, (second stage done,) k_fin done */
+    int ptime_ready;
     mz_worker pworker[3];                  /* first launcher, second launcher, collector of mz_preyama_batch() */
     hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
     hipStream_t ustream[MZ_SETS];          /* and one of high priority for its upload, expansion and plan: a chunk's plan must not queue

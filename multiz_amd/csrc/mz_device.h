@@ -33,7 +33,11 @@ typedef struct mz_pre_batch {
     int stride64;                              /* 1: the text rows of a slice lie (columns rounded up to 64) bytes apart -- the host-buffer path,
                                                   whose rows travel as whole 32-byte lines of class nibbles; 0: columns bytes apart */
     const int64_t *offT1;                      /* the first block's K rows; the second block's L + 1 rows follow them */
-    const uint8_t *txt;
+    const uint8_t *txt;                        /* the text as bytes, or NULL: then ... */
+    const uint8_t *nib;                        /* ... as class nibbles, two per byte (mz_pack.c; text offset i in nibble i & 1 of byte i >> 1) */
+    int lds_bytes;                             /* > 0 (with nib): k_pre keeps a pair's nibbles and scratch in this much dynamic LDS -- the host sizes it
+                                                  for the batch's largest pair (mz_pre_lds_bytes()) -- ... */
+    int lds16;                                 /* ... with int16 scratch (no slice of the batch has 32 768 columns) */
     const int64_t *offScr;
     int32_t *scr;
     int32_t *nullres;
@@ -49,8 +53,15 @@ typedef struct mz_fin_batch {
     uint8_t *masks;
     mz_pre_rec *recs;
     long long *hdr;                            /* [0]: band cells of the yama() calls that ran (zeroed by the caller) */
+    int cols;                                  /* merged columns k_fin stages per round: MZ_FIN_COLS(rows of the batch's widest merged block) */
+    int lds_bytes;                             /* its dynamic LDS: MZ_FIN_LDS(those rows) */
 } mz_fin_batch;
-int mzk_pre(const mz_pre_batch *q, const mz_dev_batch *b, void *stream);
+#define MZ_FIN_COLS(W) ((W) >= 512 ? 64 : (W) <= 128 ? 256 : (32768 / (W)) & ~63)
+#define MZ_FIN_LDS(W) (((((MZ_FIN_COLS(W) + 1) * (W) + 20 + 15) & ~15) + (W) + 15) & ~15)
+/* k_pre's dynamic LDS for one pair: its nibbles, five scratch arrays of `elem`-byte integers, a counter per row */
+#define MZ_PRE_LDS(text_bytes, Ma, Na, W, elem) (((text_bytes) / 2 + (size_t)(elem) * (2 * ((size_t)(Na) + 2) + 3 * ((size_t)(Ma) + 2)) + 4 + 4 * (size_t)(W) + 15) & ~(size_t)15)
+/* k_pre: A, B and the band of every pair where the DP kernels read them; bases per row and rmColDash's verdicts into f */
+int mzk_pre(const mz_pre_batch *q, const mz_fin_batch *f, const mz_dev_batch *b, void *stream);
 /* between the two stages of the v == 0 merges: the second yama() job of every such pair of b1 into b2 (same indices;
  * the other pairs of b2 get M = 0, which the plan refuses) */
 int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream);

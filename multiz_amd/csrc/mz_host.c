@@ -150,6 +150,7 @@ static void ctx_close(mz_ctx *X)
         for (i = 0; i < MZ_PD_N; ++i) if (X->pd[s][i].p) { hipFree(X->pd[s][i].p); X->pd[s][i].p = NULL; X->pd[s][i].cap = 0; }
         for (i = 0; i < MZ_PH_N; ++i) if (X->ph[s][i].p) { hipHostFree(X->ph[s][i].p); X->ph[s][i].p = NULL; X->ph[s][i].cap = 0; }
         hipEventDestroy(X->pplan2[s]);
+        if (X->ptime_ready) for (i = 0; i < 8; ++i) hipEventDestroy(X->ptime[s][i]);
     }
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);

@@ -15,11 +15,12 @@
  *            packer     (the calling thread)  classes into pinned memory on the pool's threads; copy, k_unnib, k_pre,
  *                                             the first plan and the copy of its totals;
  *            launcher 1 (helper thread)       waits for the totals, sizes the workspaces, issues DP / walk / emit; for
- *                                             chunks with two-stage merges k_mid and the second plan, else k_fin + copy;
+ *                                             chunks with two-stage merges k_mid and the second plan, else k_fin;
  *            launcher 2 (helper thread)       chunks with two-stage merges: waits for the second plan's totals, issues
- *                                             the second DP / walk / emit, k_fin and the copy of the results;
- *            collector  (helper thread)       waits for the results, takes ONE block for the chunk's rows and assembles
- *                                             them on the pool's threads.
+ *                                             the second DP / walk / emit and k_fin;
+ *            collector  (helper thread)       waits for k_fin, copies the results back (a copy is only ever issued when
+ *                                             what it copies is ready: the copy engine takes its commands in order), takes
+ *                                             ONE block for the chunk's rows and assembles them on the pool's threads.
  *          No stage waits for a copy or a kernel another stage could work beside.  A call of one chunk runs inline.
  */
 #include <limits.h>
@@ -44,7 +45,7 @@ typedef struct pchunk {
     const int64_t *hoRow, *hoMask;         /* host copies (inside the set's pinned staging block) */
     size_t nrow, mask_bytes, in_bytes, res_bytes;
     int64_t cells;
-    double t_pack0, t_pack1, t_l1a, t_l1b, t_l2a, t_l2b, t_col0, t_col1, t_col2;
+    double t_pack0, t_pack1, t_up, t_l1a, t_l1b, t_l2a, t_l2b, t_col0, t_col1, t_col2;
 } pchunk;
 
 static size_t row_stride(int cols) { return ((size_t)cols + 63) & ~(size_t)63; }
@@ -79,7 +80,18 @@ static void pack_text(void *ctx, int lo, int hi)
     _mm_sfence();
 }
 
+/* The chunks' streams: MZ_SETS buffer sets rotate, but their kernels go round MZ_STREAMS streams (default 4) -- the HIP runtime
+ * maps streams onto a few hardware queues, and two streams that share one run in each other's order: with a stream per set (ten,
+ * beside the DP kernels' side streams) a chunk's upload was seen waiting for the kernels of an unrelated chunk. */
+static int pre_streams(void)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MZ_STREAMS"); v = e && atoi(e) > 0 ? atoi(e) : 4; if (v > MZ_SETS) v = MZ_SETS; }
+    return v;
+}
+#define PSTREAM(X, set) ((X)->bstream[(set) % pre_streams()])
 static int g_ptiming = -1;
+#define PSTAMP(X, set, k, st) do { if (g_ptiming >= 2 && (X)->ptime_ready) HIPCK(hipEventRecord((X)->ptime[set][k], st)); } while (0)
 #define PD(i) (&X->pd[set][i])
 #define PH(i) (&X->ph[set][i])
 
@@ -87,7 +99,8 @@ static int g_ptiming = -1;
 static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const mz_prejob *jobs, mz_preout *outs)
 {
     hipStream_t st;
-    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, nmask = 0, hdr, in_bytes;
+    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, nmask = 0, hdr, in_bytes, lds16 = 0, lds32 = 0, res_bytes;
+    int wmax = 1, cmax = 0;
     int64_t *hT1, *hoA, *hoB, *hoBand, *hoScr, *hoRow, *hoA2, *hoMask;
     int32_t *hK, *hL, *hMa, *hNa, *hRad, *hV;
     uint8_t *hTxt;
@@ -96,9 +109,8 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
     int p, any0 = 0;
 
     c->t_pack0 = mzi_now_s();
-    if (mzi_lazy_stream(&X->bstream[set])) return -1;
-    st = X->bstream[set];
-    memset(&c->b, 0, sizeof c->b); memset(&c->b2, 0, sizeof c->b2); memset(&c->q, 0, sizeof c->q); memset(&c->f, 0, sizeof c->f);
+    if (mzi_lazy_stream(&PSTREAM(X, set))) return -1;
+    st = PSTREAM(X, set);
     c->X = X; c->set = set; c->index = index; c->n = n; c->jobs = jobs; c->outs = outs;
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
@@ -107,14 +119,39 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
         nband += (size_t)j->M_all + 1; nscr += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
         nrow += (size_t)j->K + j->L1 - 1; nmask += mask_block(j);
         if (j->v == 0) any0 = 1;
+        {   /* what k_pre would need of LDS for this pair (int16 / int32 scratch), the widest merged block, the longest slice */
+            const int W = j->K + j->L1 - 1;
+            const size_t a = MZ_PRE_LDS(text_bytes(j), j->M_all, j->N_all, W, 2), b32 = MZ_PRE_LDS(text_bytes(j), j->M_all, j->N_all, W, 4);
+            if (a > lds16) lds16 = a;
+            if (b32 > lds32) lds32 = b32;
+            if (W > wmax) wmax = W;
+            if (j->M_all > cmax) cmax = j->M_all;
+            if (j->N_all > cmax) cmax = j->N_all;
+        }
     }
     /* pinned staging: K L Ma Na rad v (int32 x n), offT1 offA offB offBand offScr offRow offA2 offMask (int64 x n), class nibbles */
     hdr = 6 * mzi_al256(4 * (size_t)n) + 8 * mzi_al256(8 * (size_t)n);
     in_bytes = hdr + mzi_al256(txt / 2);
-    if (mzi_host_reserve(PH(MZ_PH_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_TXT), txt + 256) ||
+    /* the text on the device: kept in LDS as nibbles by k_pre when the chunk's largest pair fits (MZ_PRE_LDS=0: never), else
+     * expanded to a byte per class in HBM first (k_unnib) */
+    {
+        static int lds_on = -1;
+        if (lds_on < 0) { const char *e = getenv("MZ_PRE_LDS"); lds_on = !(e && e[0] == '0'); }
+        c->q.lds16 = cmax < 32768;
+        c->q.lds_bytes = !lds_on ? 0 : c->q.lds16 ? (lds16 <= 65536 ? (int)lds16 : 0) : (lds32 <= 65536 ? (int)lds32 : 0);
+        if (c->q.lds16 && !c->q.lds_bytes && lds_on && lds32 <= 65536) { c->q.lds16 = 0; c->q.lds_bytes = (int)lds32; }
+    }
+    res_bytes = 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256(nmask);
+    if (mzi_host_reserve(PH(MZ_PH_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_IN), in_bytes) || (!c->q.lds_bytes && mzi_dev_reserve(PD(MZ_PD_TXT), txt + 256)) ||
+        mzi_dev_reserve(PD(MZ_PD_RES), res_bytes) || mzi_host_reserve(PH(MZ_PH_RES), res_bytes) ||
         mzi_dev_reserve(PD(MZ_PD_COLS), mzi_al256(szA) + mzi_al256(szB) + 256) || mzi_dev_reserve(PD(MZ_PD_BAND), 2 * mzi_al256(4 * nband)) ||
         mzi_dev_reserve(PD(MZ_PD_SCR), 4 * nscr + 256)) return -1;
     h = (char *)PH(MZ_PH_IN)->p; d = (char *)PD(MZ_PD_IN)->p;
+    {
+        const int keep16 = c->q.lds16, keepb = c->q.lds_bytes;            /* (decided above; the structures are cleared next) */
+        memset(&c->b, 0, sizeof c->b); memset(&c->b2, 0, sizeof c->b2); memset(&c->q, 0, sizeof c->q); memset(&c->f, 0, sizeof c->f);
+        c->q.lds16 = keep16; c->q.lds_bytes = keepb;
+    }
     c->b.n = c->b2.n = c->q.n = n;
 #define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
     SL(hK, int32_t, c->q.K, 4 * (size_t)n); SL(hL, int32_t, c->q.L, 4 * (size_t)n); SL(hMa, int32_t, c->q.Ma, 4 * (size_t)n);
@@ -147,9 +184,27 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
     }
     c->t_pack1 = mzi_now_s();
     c->hoRow = hoRow; c->hoMask = hoMask; c->nrow = nrow; c->mask_bytes = nmask; c->in_bytes = in_bytes; c->any0 = any0;
+    PSTAMP(X, set, 0, st);
     HIPCK(hipMemcpyAsync(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, in_bytes, hipMemcpyHostToDevice, st));
-    if (mzk_unnib(dNib, PD(MZ_PD_TXT)->p, (long long)txt, st)) return mzi_set_err("%s", mzk_last_error());
-    c->q.txt = (const uint8_t *)PD(MZ_PD_TXT)->p; c->q.stride64 = 1;
+    PSTAMP(X, set, 1, st);
+    c->q.nib = dNib; c->q.stride64 = 1;
+    if (!c->q.lds_bytes) {
+        if (mzk_unnib(dNib, PD(MZ_PD_TXT)->p, (long long)txt, st)) return mzi_set_err("%s", mzk_last_error());
+        c->q.txt = (const uint8_t *)PD(MZ_PD_TXT)->p;
+    }
+    {   /* the results' device image: 64-byte header, a record per merge, bases per row, the mask blocks (k_pre fills in the
+         * counts and rmColDash's verdicts, k_fin the rest) */
+        char *dres = (char *)PD(MZ_PD_RES)->p;
+        c->f.any0 = any0;
+        c->f.hdr = (long long *)dres;
+        c->f.recs = (mz_pre_rec *)(dres + 64);
+        c->f.size = (int32_t *)(dres + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
+        c->f.masks = (uint8_t *)c->f.size + mzi_al256(4 * nrow);
+        c->f.cols = MZ_FIN_COLS(wmax); c->f.lds_bytes = MZ_FIN_LDS(wmax);
+        c->res_bytes = res_bytes;
+        HIPCK(hipMemsetAsync(dres, 0, 64, st));
+        if (!c->q.lds_bytes) HIPCK(hipMemsetAsync(c->f.size, 0, 4 * nrow, st));      /* (the LDS-free k_pre adds the row counts up in place) */
+    }
     c->b.poolA = (const uint8_t *)PD(MZ_PD_COLS)->p; c->b.poolB = c->b.poolA + mzi_al256(szA);
     c->b.poolLB = (const int32_t *)PD(MZ_PD_BAND)->p; c->b.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND)->p + mzi_al256(4 * nband));
     c->q.scr = (int32_t *)PD(MZ_PD_SCR)->p;
@@ -169,18 +224,21 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
         c->b2.poolLB = (const int32_t *)PD(MZ_PD_BAND2)->p; c->b2.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND2)->p + mzi_al256(4 * nband));
         c->b2.offBand = c->b.offBand;
     }
-    if (mzk_pre(&c->q, &c->b, st)) return mzi_set_err("%s", mzk_last_error());
+    if (mzk_pre(&c->q, &c->f, &c->b, st)) return mzi_set_err("%s", mzk_last_error());
+    PSTAMP(X, set, 2, st);
     if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
     mz_dev_carve(&c->b, X->d_plan[set].p);
     c->b.capTb = c->b.capScript = c->b.capOut = c->b.capPrep = INT64_MAX;
     if (mzk_plan(&c->b, st)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipMemcpyAsync(X->h_tot[set].p, c->b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PSTAMP(X, set, 3, st);
     HIPCK(hipEventRecord(X->bplan[set], st));
+    c->t_up = mzi_now_s();
     return 0;
 }
 
 /* size one stage's workspaces from its plan's totals and issue prep / DP / walk / emit */
-static int run_stage(mz_ctx *X, hipStream_t st, mz_dev_batch *b, int n, const int64_t *totals, gbuf *tb, gbuf *script, gbuf *prep, gbuf *out)
+static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t st, mz_dev_batch *b, int n, const int64_t *totals, gbuf *tb, gbuf *script, gbuf *prep, gbuf *out)
 {
     if (mzi_dev_reserve(tb, 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(script, (size_t)totals[1] + 256) ||
         mzi_dev_reserve(out, (size_t)totals[2] + 256) || mzi_dev_reserve(prep, 4 * (size_t)totals[4] + 256)) return -1;
@@ -188,31 +246,26 @@ static int run_stage(mz_ctx *X, hipStream_t st, mz_dev_batch *b, int n, const in
     b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap; b->capPrep = (int64_t)(prep->cap / 4);
     b->walk_hint = mz_walk_choice(n, totals);
     b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
-    (void)X;
-    if (mzk_prep(b, st) || mzk_dp(b, st) || mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
+    if (mzk_prep(b, st) || mzk_dp(b, st)) return mzi_set_err("%s", mzk_last_error());
+    if (stamp >= 0) PSTAMP(X, set, stamp, st);
+    if (mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
+    if (stamp >= 0) PSTAMP(X, set, stamp + 1, st);
     return 0;
 }
 
-/* k_fin and the copy of the results: 64-byte header, a record per merge, bases per row, the mask blocks */
+/* k_fin (the results' device image was laid out at upload time: k_pre has written part of it) */
 static int pchunk_finish(pchunk *c)
 {
     mz_ctx *X = c->X;
-    const int set = c->set, n = c->n;
-    hipStream_t st = X->bstream[set];
-    const size_t res_bytes = 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n) + mzi_al256(4 * c->nrow) + mzi_al256(c->mask_bytes);
-    char *dres;
-    if (mzi_dev_reserve(PD(MZ_PD_RES), res_bytes) || mzi_host_reserve(PH(MZ_PH_RES), res_bytes)) return -1;
-    dres = (char *)PD(MZ_PD_RES)->p;
-    c->f.any0 = c->any0;
-    c->f.hdr = (long long *)dres;
-    c->f.recs = (mz_pre_rec *)(dres + 64);
-    c->f.size = (int32_t *)(dres + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
-    c->f.masks = (uint8_t *)c->f.size + mzi_al256(4 * c->nrow);
-    HIPCK(hipMemsetAsync(dres, 0, 64, st));
+    const int set = c->set;
+    hipStream_t st = PSTREAM(X, set);
+    PSTAMP(X, set, 6, st);
     if (mzk_fin(&c->q, &c->f, &c->b, &c->b2, st)) return mzi_set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(PH(MZ_PH_RES)->p, dres, res_bytes, hipMemcpyDeviceToHost, st));
+    PSTAMP(X, set, 7, st);
+    /* The copy of the results is NOT issued here: the copy engine takes its commands in order, and a copy that has to wait
+     * for this chunk's kernels would hold up the uploads of the chunks behind it (measured: the H2D of chunk k+3 started when
+     * the results of chunk k were through, the GPU idling in between).  The collector issues it once k_fin is done. */
     HIPCK(hipEventRecord(X->bdone[set], st));
-    c->res_bytes = res_bytes;
     return 0;
 }
 
@@ -221,10 +274,10 @@ static int pchunk_launch1(pchunk *c)
 {
     mz_ctx *X = c->X;
     const int set = c->set, n = c->n;
-    hipStream_t st = X->bstream[set];
+    hipStream_t st = PSTREAM(X, set);
     c->t_l1a = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bplan[set]));
-    if (run_stage(X, st, &c->b, n, (const int64_t *)X->h_tot[set].p, &X->d_tb[set], &X->d_script[set], &X->d_prep[set], PD(MZ_PD_OUT1))) return -1;
+    if (run_stage(X, set, 4, st, &c->b, n, (const int64_t *)X->h_tot[set].p, &X->d_tb[set], &X->d_script[set], &X->d_prep[set], PD(MZ_PD_OUT1))) return -1;
     if (c->any0) {
         /* the second yama() job of the two-stage merges, derived where the first one's result lies (k_mid) */
         c->b2.poolB = c->b.out;
@@ -248,7 +301,7 @@ static int pchunk_launch2(pchunk *c)
     c->t_l2a = c->t_l2b = mzi_now_s();
     if (!c->any0) return 0;
     HIPCK(hipEventSynchronize(X->pplan2[set]));
-    if (run_stage(X, X->bstream[set], &c->b2, c->n, (const int64_t *)PH(MZ_PH_TOT2)->p, PD(MZ_PD_TB2), PD(MZ_PD_SCRIPT2), PD(MZ_PD_PREP2), PD(MZ_PD_OUT2))) return -1;
+    if (run_stage(X, set, -1, PSTREAM(X, set), &c->b2, c->n, (const int64_t *)PH(MZ_PH_TOT2)->p, PD(MZ_PD_TB2), PD(MZ_PD_SCRIPT2), PD(MZ_PD_PREP2), PD(MZ_PD_OUT2))) return -1;
     if (pchunk_finish(c)) return -1;
     c->t_l2b = mzi_now_s();
     return 0;
@@ -332,6 +385,10 @@ static int pchunk_collect(pchunk *c)
 
     c->t_col0 = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bdone[set]));
+    /* (on a stream of its own: the chunk's stream already holds the kernels of later chunks) */
+    if (mzi_lazy_stream(&X->stream2)) return -1;
+    HIPCK(hipMemcpyAsync(PH(MZ_PH_RES)->p, PD(MZ_PD_RES)->p, c->res_bytes, hipMemcpyDeviceToHost, X->stream2));
+    HIPCK(hipStreamSynchronize(X->stream2));
     c->t_col1 = mzi_now_s();
     c->cells = *(const int64_t *)r;
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
@@ -376,6 +433,7 @@ typedef struct ppipe {
     int failed, rc, done;
     int64_t cells, bytes_up, bytes_down;
     double t0;
+    hipEvent_t ev0;                        /* MZ_TIMING=2: recorded on the context's stream when the call starts */
     char err[600];
 } ppipe;
 
@@ -389,12 +447,19 @@ static void ppipe_abort(ppipe *P)
 
 static void pchunk_report(const ppipe *P, const pchunk *c)
 {
+    float g[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int k;
     if (g_ptiming < 2) return;
+    /* GPU time stamps of the chunk's stream against the call's start (ms): upload begins / ends, k_pre done, planned, first DP done,
+     * first walk + emit done, k_fin begins / ends */
+    if (c->X->ptime_ready) for (k = 0; k < 8; ++k) hipEventElapsedTime(&g[k], P->ev0, c->X->ptime[c->set][k]);
     fprintf(stderr, "{\"mz_preyama_batch_chunk\": %d, \"merges\": %d, \"two_stage\": %d, \"cells\": %lld, \"bytes_up\": %zu, \"bytes_down\": %zu, "
-                    "\"pack_ms\": [%.3f, %.3f], \"launch1_ms\": [%.3f, %.3f], \"launch2_ms\": [%.3f, %.3f], \"result_wait_ms\": [%.3f, %.3f], \"assembled_ms\": %.3f}\n",
+                    "\"host_ms\": {\"pack\": [%.3f, %.3f], \"uploaded\": %.3f, \"launch1\": [%.3f, %.3f], \"launch2\": [%.3f, %.3f], \"result_wait\": [%.3f, %.3f], \"assembled\": %.3f}, "
+                    "\"gpu_ms\": {\"h2d\": [%.3f, %.3f], \"pre_done\": %.3f, \"planned\": %.3f, \"dp_done\": %.3f, \"emit_done\": %.3f, \"fin\": [%.3f, %.3f]}}\n",
             c->index, c->n, c->any0, (long long)c->cells, c->in_bytes, c->res_bytes,
-            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_l1a - P->t0), 1e3 * (c->t_l1b - P->t0),
-            1e3 * (c->t_l2a - P->t0), 1e3 * (c->t_l2b - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0));
+            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_up - P->t0), 1e3 * (c->t_l1a - P->t0), 1e3 * (c->t_l1b - P->t0),
+            1e3 * (c->t_l2a - P->t0), 1e3 * (c->t_l2b - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0),
+            g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
 }
 
 /* stage s = ST_L1, ST_L2, ST_COL: for chunk k = 0, 1, ...: wait until the stage before is through with it, do this one's part */
@@ -461,6 +526,15 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
     P->X = X; P->total = -1; P->t0 = mzi_now_s();
     pthread_mutex_init(&P->mu, NULL);
     pthread_cond_init(&P->cv, NULL);
+    if (g_ptiming >= 2) {
+        if (!X->ptime_ready) {
+            int a, e, ok = 1;
+            for (a = 0; a < MZ_SETS && ok; ++a) for (e = 0; e < 8 && ok; ++e) ok = hipEventCreate(&X->ptime[a][e]) == hipSuccess;
+            X->ptime_ready = ok;
+        }
+        if (X->ptime_ready && hipEventCreate(&P->ev0) == hipSuccess) hipEventRecord(P->ev0, X->stream);
+        else X->ptime_ready = 0;
+    }
     for (s = 0; s < n; ++s) max_bytes += text_bytes(&jobs[s]);
     max_bytes = max_bytes / (size_t)pre_parts() + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
@@ -509,8 +583,9 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
         pthread_mutex_unlock(&P->mu);
         if (rc < 0) mzi_set_err("%s", P->err);
     }
-    if (rc < 0) for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]);
+    if (rc < 0) { for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]); if (X->stream2) hipStreamSynchronize(X->stream2); }
     if (stats) { stats[0] += P->cells; stats[1] += P->bytes_up; stats[2] += P->bytes_down; }
+    if (g_ptiming >= 2 && X->ptime_ready) hipEventDestroy(P->ev0);
     pthread_mutex_destroy(&P->mu);
     pthread_cond_destroy(&P->cv);
     free(P);
