@@ -289,7 +289,6 @@ static int chunk_launch(chunk *c)
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
 
     dres = (char *)X->d_res[set].p;
-    HIPCK(hipMemsetAsync(dres, 0, 64, st));
     if (mzk_prep(&b, st) || mzk_dp(&b, st)) return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 3, st);
     if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
@@ -312,15 +311,18 @@ typedef struct asm_ctx {
     const size_t *where;
     uint8_t *block;
     int failed;
+    int64_t cells;
 } asm_ctx;
 
 static void assemble_range(void *ctx, int lo, int hi)
 {
     asm_ctx *q = (asm_ctx *)ctx;
     int p, failed = 0;
+    int64_t cells = 0;
     for (p = lo; p < hi; ++p) {
         mz_out *o = &q->outs[p];
         const mz_res_rec *r = &q->rec[p];
+        cells += r->cells;
         const mz_job *j = &q->jobs[p];
         o->status = r->status; o->badrow = r->badrow; o->OM = 0; o->cols = NULL; o->block = NULL;
         o->score[0] = o->score[1] = o->score[2] = 0;
@@ -336,6 +338,7 @@ static void assemble_range(void *ctx, int lo, int hi)
         mz_assemble_cols(j->K, j->L, j->M, j->N, j->A, j->B, q->packed + r->off, r->om, o->cols);
     }
     if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&q->cells, cells, __ATOMIC_RELAXED);
     _mm_sfence();
 }
 
@@ -358,7 +361,6 @@ static int chunk_collect(chunk *c)
     TSTAMP(X, set, 5, X->bstream[set]);
     HIPCK(hipStreamSynchronize(X->bstream[set]));
     c->t_col1 = mzi_now_s();
-    c->cells = *(const int64_t *)r;
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
     if (!where) return mzi_set_err("out of memory");
     /* ONE allocation for the chunk's merged columns; outs[first].block owns it (mz_free_outs).  Every pair's columns
@@ -380,9 +382,10 @@ static int chunk_collect(chunk *c)
     }
     {
         asm_ctx ac;
-        ac.jobs = jobs; ac.outs = outs; ac.rec = rec; ac.packed = packed; ac.where = where; ac.block = block; ac.failed = 0;
+        ac.jobs = jobs; ac.outs = outs; ac.rec = rec; ac.packed = packed; ac.where = where; ac.block = block; ac.failed = 0; ac.cells = 0;
         mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
         failed = ac.failed;
+        c->cells = ac.cells;
     }
     outs[0].block = block;
     free(where);

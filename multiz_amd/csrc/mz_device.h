@@ -13,9 +13,9 @@ int mzk_unband(int n, const int32_t *bandLen, const int32_t *lb0, const int32_t 
                const uint8_t *packed, const uint8_t *exceptions, int32_t *poolLB, int32_t *poolRB, void *stream);
 /* class nibbles (mz_pack.c) -> one canonical byte per class; nbytes_out a multiple of 8 */
 int mzk_unnib(const void *nibbles, void *bytes, long long nbytes_out, void *stream);
-/* what mz_yama_batch() copies back: hdr (64 B: [0] = band cells of the valid pairs, zeroed by the caller), one record
+/* what mz_yama_batch() copies back: hdr (64 B, spare), one record
  * per pair, the edit scripts at two bits per merged column (pair p at byte recs[p].off of `packed`) */
-typedef struct mz_res_rec { int32_t status, badrow, om, f[3]; int64_t off; } mz_res_rec;
+typedef struct mz_res_rec { int32_t status, badrow, om, f[3]; int64_t off; int64_t cells; /* band cells of the pair (0 unless status is MZ_OK): the host adds them up -- 50 000 atomic adds on one address were 0.7 ms of a batch */ } mz_res_rec;
 int mzk_script_pack(const mz_dev_batch *b, void *hdr, void *recs, void *packed, void *stream);
 int mzk_prep(const mz_dev_batch *b, void *stream);
 int mzk_dp(const mz_dev_batch *b, void *stream);
@@ -44,7 +44,7 @@ typedef struct mz_pre_batch {
 } mz_pre_batch;
 /* what mz_preyama_batch() copies back instead of rows (k_fin, kernels/prepost.inc): a record per merge, bases per row,
  * and per merged column / slice column the bits from which the host puts the rows together out of the caller's own text */
-typedef struct mz_pre_rec { int32_t status, badrow, nullres, stage, M, N, om, om1; int64_t score; } mz_pre_rec;
+typedef struct mz_pre_rec { int32_t status, badrow, nullres, stage, M, N, om, om1; int64_t score; int64_t cells; /* band cells of the yama() calls that ran for this merge: the host adds them up */ } mz_pre_rec;
 typedef struct mz_fin_batch {
     int any0;                                  /* the batch has two-stage merges (b2 is valid) */
     const int64_t *offRow;                     /* first of merge p's K + L entries of `size` */
@@ -52,7 +52,6 @@ typedef struct mz_fin_batch {
     const int64_t *offMask;                    /* byte offset (a multiple of 8) of merge p's mask block in `masks` */
     uint8_t *masks;
     mz_pre_rec *recs;
-    long long *hdr;                            /* [0]: band cells of the yama() calls that ran (zeroed by the caller) */
     int cols;                                  /* merged columns k_fin stages per round: MZ_FIN_COLS(rows of the batch's widest merged block) */
     int lds_bytes;                             /* its dynamic LDS: MZ_FIN_LDS(those rows) */
 } mz_fin_batch;

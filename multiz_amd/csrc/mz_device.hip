@@ -450,8 +450,6 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     if (dyn_lds_lag < 0) { const char *e = getenv("MZ_DYN_LDS_LAG"); dyn_lds_lag = e ? atoi(e) : 0; }
     static int lat_max = -1;                      // MZ_LAT_MAX=<waves>: launches that leave the GPU at most that many row-parallel waves take k_dp_row_lat (0: never)
     if (lat_max < 0) { const char *e = getenv("MZ_LAT_MAX"); lat_max = e ? atoi(e) : 2048; }
-    static int four = -1;                         // MZ_DP_FOUR=1: the row kernel held to four waves per SIMD (experiment)
-    if (four < 0) { const char *e = getenv("MZ_DP_FOUR"); four = e && e[0] == '1'; }
     static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
     if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
     hipStream_t main_s = (hipStream_t)stream;
@@ -492,8 +490,6 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
             const int blocks = rows_listed ? b->dp_rows : count;
             if ((long long)blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
                 hipLaunchKernelGGL(k_dp_row_lat, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
-            else if (four)
-                hipLaunchKernelGGL(k_dp_row4, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
             else
                 hipLaunchKernelGGL(k_dp_row, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
         }
@@ -577,12 +573,19 @@ extern "C" int mzk_script_pack(const mz_dev_batch *b, void *hdr, void *recs, voi
     CK(hipGetLastError(), "script pack launch");
     return 0;
 }
+static int helper_grid(void)              // waves of k_pre_lds / k_fin (each takes its pairs in turn); MZ_HELPER_GRID overrides
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MZ_HELPER_GRID"); v = e && atoi(e) > 0 ? atoi(e) : 65536; }
+    return v;
+}
 extern "C" int mzk_pre(const mz_pre_batch *q, const mz_fin_batch *f, const mz_dev_batch *b, void *stream)
 {
     if (q->n <= 0) return 0;
     if (q->nib && !q->txt && q->lds_bytes > 0 && q->lds_bytes <= 64 * 1024) {
-        if (q->lds16) hipLaunchKernelGGL(k_pre_lds<int16_t>, dim3(q->n), dim3(WAVE), (size_t)q->lds_bytes, (hipStream_t)stream, *q, *f, *b);
-        else hipLaunchKernelGGL(k_pre_lds<int32_t>, dim3(q->n), dim3(WAVE), (size_t)q->lds_bytes, (hipStream_t)stream, *q, *f, *b);
+        const int grid = q->n < helper_grid() ? q->n : helper_grid();
+        if (q->lds16) hipLaunchKernelGGL(k_pre_lds<int16_t>, dim3(grid), dim3(WAVE), (size_t)q->lds_bytes, (hipStream_t)stream, *q, *f, *b);
+        else hipLaunchKernelGGL(k_pre_lds<int32_t>, dim3(grid), dim3(WAVE), (size_t)q->lds_bytes, (hipStream_t)stream, *q, *f, *b);
     } else hipLaunchKernelGGL(k_pre, dim3(q->n), dim3(WAVE), 0, (hipStream_t)stream, *q, *f, *b);
     CK(hipGetLastError(), "pre launch");
     return 0;
@@ -597,7 +600,7 @@ extern "C" int mzk_mid(const mz_pre_batch *q, const mz_dev_batch *b1, const mz_d
 extern "C" int mzk_fin(const mz_pre_batch *q, const mz_fin_batch *f, const mz_dev_batch *b1, const mz_dev_batch *b2, void *stream)
 {
     if (b1->n <= 0) return 0;
-    hipLaunchKernelGGL(k_fin, dim3(b1->n), dim3(WAVE), (size_t)f->lds_bytes, (hipStream_t)stream, *q, *f, *b1, f->any0 ? *b2 : *b1);
+    hipLaunchKernelGGL(k_fin, dim3(b1->n < helper_grid() ? b1->n : helper_grid()), dim3(WAVE), (size_t)f->lds_bytes, (hipStream_t)stream, *q, *f, *b1, f->any0 ? *b2 : *b1);
     CK(hipGetLastError(), "fin launch");
     return 0;
 }

@@ -196,13 +196,11 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
          * counts and rmColDash's verdicts, k_fin the rest) */
         char *dres = (char *)PD(MZ_PD_RES)->p;
         c->f.any0 = any0;
-        c->f.hdr = (long long *)dres;
         c->f.recs = (mz_pre_rec *)(dres + 64);
         c->f.size = (int32_t *)(dres + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
         c->f.masks = (uint8_t *)c->f.size + mzi_al256(4 * nrow);
         c->f.cols = MZ_FIN_COLS(wmax); c->f.lds_bytes = MZ_FIN_LDS(wmax);
         c->res_bytes = res_bytes;
-        HIPCK(hipMemsetAsync(dres, 0, 64, st));
         if (!c->q.lds_bytes) HIPCK(hipMemsetAsync(c->f.size, 0, 4 * nrow, st));      /* (the LDS-free k_pre adds the row counts up in place) */
     }
     c->b.poolA = (const uint8_t *)PD(MZ_PD_COLS)->p; c->b.poolB = c->b.poolA + mzi_al256(szA);
@@ -318,6 +316,7 @@ typedef struct pasm {
     const size_t *where;
     uint8_t *block;
     int failed, oom;
+    int64_t cells;
 } pasm;
 
 #define PASM_ROWS 32
@@ -325,9 +324,11 @@ static void assemble_merges(void *ctx, int lo, int hi)
 {
     pasm *q = (pasm *)ctx;
     int p, failed = 0;
+    int64_t cells = 0;
     for (p = lo; p < hi; ++p) {
         const mz_prejob *j = &q->jobs[p];
         const mz_pre_rec *r = &q->rec[p];
+        cells += r->cells;
         mz_preout *o = &q->outs[p];
         const int W = j->K + j->L1 - 1, two = j->v == 0;
         memset(o, 0, sizeof *o);
@@ -369,6 +370,7 @@ static void assemble_merges(void *ctx, int lo, int hi)
         }
     }
     if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&q->cells, cells, __ATOMIC_RELAXED);
     _mm_sfence();
 }
 
@@ -390,7 +392,6 @@ static int pchunk_collect(pchunk *c)
     HIPCK(hipMemcpyAsync(PH(MZ_PH_RES)->p, PD(MZ_PD_RES)->p, c->res_bytes, hipMemcpyDeviceToHost, X->stream2));
     HIPCK(hipStreamSynchronize(X->stream2));
     c->t_col1 = mzi_now_s();
-    c->cells = *(const int64_t *)r;
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
     if (!where) return mzi_set_err("out of memory");
     /* ONE allocation for the chunk's rows and base counts; outs[first].block owns it (mz_free_preouts).  Every merge starts on
@@ -411,8 +412,9 @@ static int pchunk_collect(pchunk *c)
     a.jobs = c->jobs; a.outs = c->outs; a.rec = rec;
     a.size = (const int32_t *)(r + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
     a.masks = (const uint8_t *)a.size + mzi_al256(4 * c->nrow);
-    a.hoRow = c->hoRow; a.hoMask = c->hoMask; a.where = where; a.block = block; a.failed = 0; a.oom = 0;
+    a.hoRow = c->hoRow; a.hoMask = c->hoMask; a.where = where; a.block = block; a.failed = 0; a.oom = 0; a.cells = 0;
     mzi_parallel_for(n, pre_grain(n), assemble_merges, &a);
+    c->cells = a.cells;
     c->outs[0].block = block;
     free(where);
     c->t_col2 = mzi_now_s();
@@ -619,6 +621,7 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
         if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1 || !j->rows1 || !j->rows2)
             return mzi_set_err("mz_preyama_batch: job %d has an empty block or slice", p);
         if (j->v != 0 && j->v != 1) return mzi_set_err("mz_preyama_batch: job %d: v = %d (0 or 1)", p, j->v);
+        if (text_bytes(j) >= ((size_t)1 << 31)) return mzi_set_err("mz_preyama_batch: job %d: the two slices hold %zu bytes (2^31 at most)", p, text_bytes(j));
         if (j->v == 0) any0 = 1;
     }
     pthread_mutex_lock(&g_big);
