@@ -35,10 +35,37 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# VALU issue: integer max / dot2 / cndmask / DPP wave-instructions occupy a SIMD for 4 shader cycles on gfx950
-# (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt; v_add/v_sub/v_and: 2-3); 1024 SIMDs.
-VALU_CYCLES = 4.0
+# VALU issue (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt): at two or more waves per SIMD v_add_u32 / v_sub_u32 /
+# v_and_b32 occupy a SIMD for 2.3-2.5 shader cycles per wave-instruction, every other integer operation of this path (max, max3,
+# and_or, alignbit, dot2 / dot4, DPP forms, perm, bfe, mad24, compares) for 4.0-4.2.  A launch is priced by the static mix of its
+# kernel's loops (profiles/r*_isa_hist.json, tests/tools/isa_hist.py: from the compiler's own assembly); without that record every
+# instruction is priced at VALU_CYCLES_REST -- an overestimate of the issue time, never an underestimate.  1024 SIMDs.
+VALU_CYCLES_FAST, VALU_CYCLES_REST = 2.35, 4.1
 SIMDS = 1024
+
+
+def isa_mix(kernel):
+    """cycles per VALU wave-instruction of `kernel` from the newest profiles/r*_isa_hist.json; (cycles, source, stale)"""
+    import glob
+    import re
+
+    def round_of(f):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        return (int(m.group(1)) if m else -1, os.path.basename(f))
+    cur, found = sources_hash(), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_hist.json")), key=round_of, reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        k = d.get("kernels", {}).get(kernel, {}).get("in_loops")
+        if not k or not k.get("valu"):
+            continue
+        rec = (float(k["cycles_per_inst"]), os.path.relpath(f, ROOT), d.get("sources_hash") != cur, {"valu": k["valu"], "fast": k["fast"]})
+        if not rec[2]:
+            return rec
+        found = found or rec
+    return found or (VALU_CYCLES_REST, None, False, None)
 
 
 def sources_hash():
@@ -538,7 +565,10 @@ def main():
     # the DP kernel that took most of the batch's pairs: the row-parallel one (k_dp_row_big when the batch has blocks of four
     # rows or more), the lagged one, or the wavefront fallbacks
     big = bool((np.maximum(batch["K"], batch["L"]) >= 4).any())
-    dominant_kernel = max((int(modes[5:9].sum()), "k_dp_row_big" if big else "k_dp_row"), (int(modes[11]), "k_dp_lag"),
+    nrow = int(modes[5:9].sum())
+    # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat: C5 as one batch)
+    row_kernel = "k_dp_row_big" if big else "k_dp_row_lat" if 0 < nrow <= 2048 else "k_dp_row"
+    dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
                           (int(modes[:4].sum()), "k_dp"), (int(modes[9:11].sum()), "k_dp_wide"))[1]
 
     out = {
@@ -566,10 +596,25 @@ def main():
     }
     pmc = pmc_record(args.config, pairs, dominant_kernel) if not args.scatter else None
     if pmc:
-        clock = pmc.get("clock_ghz") or 2.35
+        # The issue roof of the dominant DP launch: its VALU wave-instructions (SQ_INSTS_VALU), priced by opcode class, against the
+        # SIMD cycles of THE SAME launch -- GRBM_GUI_ACTIVE of that kernel in the counter passes, summed over the 8 XCDs, hence / 8
+        # -- so no clock estimate enters: frac = instructions x cycles each / (1024 SIMDs x the launch's own cycles) <= 1.
+        cpi, mix_src, mix_stale, mix = isa_mix(dominant_kernel)
+        clock = pmc.get("clock_ghz")
         out["roofline"]["traffic"] = pmc.get("traffic_bytes")
-        out["roofline"]["valu"] = {"insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": VALU_CYCLES, "simds": SIMDS, "clock_ghz": clock,
-                                   "frac": round(pmc["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * clock * 1e9 * dp_ms * 1e-3), 4)}
+        v = {"insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": round(cpi, 4), "simds": SIMDS,
+             "priced_by": ({"source": mix_src, "stale": mix_stale, "loop_valu": mix["valu"], "loop_fast": mix["fast"],
+                            "cycles": {"add_sub_and": VALU_CYCLES_FAST, "rest": VALU_CYCLES_REST}} if mix_src else
+                           f"no profiles/r*_isa_hist.json record: every instruction at {VALU_CYCLES_REST} cycles")}
+        if pmc.get("GRBM_GUI_ACTIVE"):
+            cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0
+            v["launch_cycles"] = round(cyc)
+            v["clock_ghz"] = clock
+            v["frac"] = round(pmc["SQ_INSTS_VALU"] * cpi / (SIMDS * cyc), 4)
+            assert v["frac"] <= 1.0, f"roofline.valu.frac {v['frac']} > 1: the opcode pricing is wrong"
+            if clock:
+                v["frac_at_this_runs_dp_time"] = round(pmc["SQ_INSTS_VALU"] * cpi / (SIMDS * clock * 1e9 * dp_ms * 1e-3), 4)
+        out["roofline"]["valu"] = v
         out["roofline"]["pmc"] = {"source": pmc["source"], "stale": pmc["stale"], "kernel_avg_ms_in_stats_run": round(pmc.get("avg_ns", 0) / 1e6, 3)}
     if exchange:
         out["exchange"] = exchange

@@ -51,4 +51,4 @@ print(f"stock roast + mz_multiz on its PATH:       {t_path:7.2f} s   identical: 
 got_host = [l for l in open(os.path.join(td, "ours_host.maf")).read().split("\n") if not l.startswith("#")]
 print(f"mz_roast, host pre_yama stages (MZ_HOST_PREP=1): {t_host:7.2f} s   identical: {got_host == want}   (best of 3)")
 print(f"mz_roast, device pre_yama stages (v = 0 too):   {t_in:7.2f} s   identical: {got == want}   (best of 3)")
-print("\n".join(l for l in p.stderr.decode().split("\n") if l.startswith("mz_") and "chunk(" not in l))
+print("\n".join(l for l in p.stderr.decode().split("\n") if (l.startswith("mz_") or l.startswith("{\"mz_")) and "chunk" not in l))
