@@ -80,7 +80,8 @@ enum {
  *           below 2^29 -- where guards that can only touch unreachable (sentinel) states are
  *           dropped; outputs are identical ("fast path equivalence") */
 enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 /* FAST with tag-encoded picks */,
-       MZ_MODE_RESERVED4 = 4 /* (was an experimental four-pairs-per-wave kernel; removed) */,
+       MZ_MODE_TSTRIP = 4 /* STRIP for well-formed pairs: 64-row strips with FASTT's guard-dropping tagged arithmetic (bands wider AND
+                               higher than the rolling wavefront and the row-parallel kernels take; kernels/strip.inc) */,
        MZ_MODE_ROW = 5 /* FASTT arithmetic, lane = column, one band row per iteration (bands <= 63 wide) */,
        MZ_MODE_COL = 6 /* MZ_MODE_ROW on the transposed problem (bands <= 63 high) */,
        MZ_MODE_ROWR = 7, MZ_MODE_COLR = 8 /* ROW / COL for scores too large for the 2^30 ring lift: the prefix

@@ -45,7 +45,7 @@
 #define MODE_IS_COLFAM(m) ((m) == MZ_MODE_COL || (m) == MZ_MODE_COLR)
 #define MODE_IS_TAGGED(m) ((m) == MZ_MODE_FASTT || MODE_IS_ROWFAM(m) || (m) == MZ_MODE_LAG)
 
-struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; };
+struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; int tstrip_on; };
 __constant__ ScoreConst c_sc;
 
 // byte -> class {A/a:0, C/c:1, G/g:2, T/t:3, '-':4, other:5}; the six classes on which the
@@ -238,7 +238,8 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     h.maxS = 0;
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
     h.row_on = m->row;
-    { const char *e = getenv("MZ_NO_LAG"); h.lag_on = !(e && e[0] == '1'); }      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
+    { const char *e = getenv("MZ_NO_LAG"); h.lag_on = !(e && e[0] == '1'); }
+    { const char *e = getenv("MZ_NO_TSTRIP"); h.tstrip_on = !(e && e[0] == '1'); }       // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements)      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");

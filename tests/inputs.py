@@ -198,3 +198,55 @@ def random_walk_band(rng, M):
         if hi - lo > 120: lo = hi - 120
     N = int(RB[M])
     return LB.astype(np.int32), RB.astype(np.int32), N
+
+
+def long_indel_band(rng, M, rate, radius, long_frac=0.02, short_mean=3.0, long_lo=70, long_hi=300):
+    """indel_band() with heavy-tailed run lengths: most runs geometric with mean `short_mean`, a fraction `long_frac` of them
+    uniform in [long_lo, long_hi] columns -- one such run makes the rows around it too wide for the row-parallel kernels and the
+    anti-diagonals too high for the rolling wavefront"""
+    from oracle import mzoracle as mo
+
+    def run():
+        return int(rng.integers(long_lo, long_hi + 1)) if rng.random() < long_frac else int(rng.geometric(1.0 / short_mean))
+    centre = np.zeros(M + 1, dtype=np.int64)
+    c, i = 0, 1
+    while i <= M:
+        u = rng.random()
+        if u < rate / 2 and i > 1:
+            for _ in range(min(run(), M - i + 1)):
+                centre[i] = c; i += 1
+            continue
+        if u < rate:
+            c += run()
+        c += 1
+        centre[i] = c; i += 1
+    N = int(max(c, 11))
+    LB = np.minimum(centre, N).astype(np.int32); RB = LB.copy(); LB[0] = 0; RB[M] = N
+    LB, RB = mo.smooth(LB, RB, M, N, radius)
+    return LB, RB, N
+
+
+def random_wide_pair(rng, max_rows=6):
+    """a block pair whose band is wide AND high: a large radius around the diagonal, a long indel, a drifting wide band, or the
+    full matrix; 1-max_rows rows a block, 20-900 columns"""
+    from oracle import mzoracle as mo
+    kind = rng.choice(["radius", "radius", "indel", "indel", "wander", "full"])
+    K, L = int(rng.integers(1, max_rows + 1)), int(rng.integers(1, max_rows + 1))
+    if kind == "indel":
+        M = int(rng.integers(100, 900))
+        LB, RB, N = long_indel_band(rng, M, float(rng.choice([0.01, 0.03])), int(rng.integers(10, 40)), long_frac=float(rng.choice([0.1, 0.4])))
+    else:
+        M = int(rng.choice([int(rng.integers(20, 900)), 63, 64, 65, 127, 128, 129]))
+        N = max(11, M + int(rng.integers(-M // 3, M // 3 + 1)))
+        if kind == "full" and M * N > 60000:
+            kind = "radius"
+        if kind == "radius":
+            LB, RB = diag_band(M, N)
+            LB, RB = mo.smooth(LB, RB, M, N, int(rng.integers(64, 160)))
+        elif kind == "wander":
+            LB, RB = wander_band(rng, M, N, step=int(rng.integers(2, 6)))
+            LB, RB = mo.smooth(LB, RB, M, N, int(rng.integers(40, 120)))
+        else:
+            LB = np.zeros(M + 1, dtype=np.int32); RB = np.full(M + 1, N, dtype=np.int32)
+    A = random_block(rng, M, K, dash=float(rng.choice([0.0, 0.1, 0.4])), odd=0.05)
+    return A, noisy_copy(rng, A, N, L, dash=float(rng.choice([0.0, 0.1, 0.4]))), LB, RB

@@ -616,6 +616,39 @@ def test_lagged_kernel_random_blocks(mz):
         assert r.status == 0 and r.OM == om[i] and _hash(np.ascontiguousarray(r.cols).reshape(-1), r.OM) == int(hs[i]), i
 
 
+def test_tagged_strips_random_wide_bands(mz):
+    # bands wide AND high -- radii 64-160, long indels (70-300 unshared columns), drifting wide bands, full matrices -- go to the
+    # 64-row strips: with the tagged wavefront's arithmetic where the pair is well-formed (MZ_MODE_TSTRIP = 4), exact otherwise
+    # (MZ_MODE_STRIP = 1).  Strip boundaries at 63 / 64 / 65 / 127 / 128 / 129 rows; every pair against the oracle by hash, with
+    # the default kernels, the wavefront family alone, and the exact kernels.
+    from multiz_amd import synth
+    rng = np.random.default_rng(44)
+    pairs = []
+    while len(pairs) < 1500:
+        A, B, LB, RB = inputs.random_wide_pair(rng)
+        if mo.check(A.shape[0], B.shape[0], LB, RB)[0] == 0:
+            pairs.append((A, B, LB, RB))
+    batch = synth.pack_pairs(pairs)
+    om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=min(64, os.cpu_count() or 8))
+    assert bad == 0
+    for which in (2, 1, 0):
+        _kernels(mz, which)
+        db = mz.DevBatch(batch)
+        db.run()
+        res = db.results()
+        assert (res["status"] == 0).all() and cells == int(res["cells"].sum())
+        hist = np.bincount(res["mode"], minlength=13)
+        if which:
+            assert hist[4] > 300, hist                               # the tagged strips took their share
+        else:
+            assert hist[4] == 0 and hist[1] > 300, hist             # exact kernels only
+        out = db.out.cpu().numpy()
+        for i, (A, B, _, _) in enumerate(pairs):
+            m_, o0, W = int(res["om"][i]), int(res["offOut"][i]), A.shape[1] + B.shape[1]
+            assert m_ == om[i] and _hash(out[o0: o0 + m_ * W], m_) == int(hs[i]), (which, i, int(res["mode"][i]))
+    _kernels(mz, 2)
+
+
 def test_pipelined_form_from_a_cold_start():
     # mz_dev_run_async() as the FIRST call of a process (its helper streams are created on first use) and again after
     # mz_finalize(): results equal the serial form's
