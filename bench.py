@@ -392,7 +392,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)   # (a c2 step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i", "c4i", "c2w", "c2s"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i", "c4i", "c2w", "c2s", "c2g"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -569,7 +569,7 @@ def main():
     # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat: C5 as one batch)
     row_kernel = "k_dp_row_big" if big else "k_dp_row_lat" if 0 < nrow <= 2048 else "k_dp_row"
     dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
-                          (int(modes[:5].sum()), "k_dp"), (int(modes[9:11].sum()), "k_dp_wide"))[1]
+                          (int(modes[:5].sum()), "k_dp"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
 
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",

@@ -31,6 +31,7 @@
 #include "mz_device.h"
 
 #define WAVE   64
+#define ROLL_VMAX 90            // kernels/roll.inc: the longest wait (in steps) of a row the rolling form with late starts admits
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
 // row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then (COL
@@ -189,7 +190,7 @@ __device__ __forceinline__ void for_my_pairs(const mz_dev_batch &b, unsigned lon
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= limit) break;
         int p;
-        if (whole) { p = __builtin_amdgcn_readfirstlane(b.packList[list_first + k]); if (b.status[p] != MZ_OK) continue; }   // (k_fit may have failed it since)
+        if (whole) { p = __builtin_amdgcn_readfirstlane(b.packList[list_first + k]); if (b.status[p] != MZ_OK || !mine_is(p)) continue; }   // (k_fit may have failed it since; two kernels share the second list)
         else { p = first + k; if (!mine_is(p)) continue; }
         run(p);
         __syncthreads();                               // the next pair restages the same LDS
@@ -210,6 +211,7 @@ __device__ __forceinline__ int listed_pair(const mz_dev_batch &b, int first, int
 #include "kernels/row.inc"
 #include "kernels/lag.inc"
 #include "kernels/strip.inc"
+#include "kernels/roll.inc"
 #include "kernels/dispatch.inc"
 #include "kernels/walk.inc"
 #include "kernels/emit.inc"
@@ -239,7 +241,9 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     for (int i = 0; i < 36; ++i) { const int a = m->S6[i] < 0 ? -m->S6[i] : m->S6[i]; if (a > h.maxS) h.maxS = a; }
     h.row_on = m->row;
     { const char *e = getenv("MZ_NO_LAG"); h.lag_on = !(e && e[0] == '1'); }
-    { const char *e = getenv("MZ_NO_TSTRIP"); h.tstrip_on = !(e && e[0] == '1'); }       // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements)      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
+    // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements); MZ_TROLL=1: the rolling form with late starts
+    // (kernels/roll.inc) where its rings hold the band -- off by default: measured no faster than the tagged strips
+    { const char *e = getenv("MZ_NO_TSTRIP"), *r = getenv("MZ_TROLL"); h.tstrip_on = (e && e[0] == '1') ? 0 : (r && r[0] == '1') ? 2 : 1; }       // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements)      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
@@ -472,7 +476,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     int nk = 0, last = 0;
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
-        CK(hipMemsetAsync(&b->totals[16], 0, 3 * sizeof(int64_t), main_s), "dp counters");
+        CK(hipMemsetAsync(&b->totals[16], 0, 4 * sizeof(int64_t), main_s), "dp counters");
     DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
     // (one set of side streams and events per DEVICE: two host threads on one device -- the tests' MZ_ALLOW_DUP_DEVICES --
     // must not interleave their record / wait sequences; what a wait refers to is fixed when it is enqueued)
@@ -500,8 +504,10 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         //  its 9-13 KB of LDS beside the other kernels' waves, and the launch is over only when the last one has)
         else if (kinds[i] == MZ_DP_WAVEFRONT)
             hipLaunchKernelGGL(k_dp, dim3(grid_of(count, 6144, b->dp_grid & 1023)), dim3(WAVE), dyn_lds, s, *b, first, count);
-        else if (kinds[i] == MZ_DP_WIDE)
+        else if (kinds[i] == MZ_DP_WIDE) {                // the second list: blocks of 128+ rows, and the rolling form with late starts
             hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_roll, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
+        }
         else
             hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), dyn_lds_lag, s, *b, first, count);
         if (side) { CK(hipEventRecord(S->join[used], s), "dp join"); ++used; }

@@ -156,19 +156,28 @@ void mz_synth_fill(int n, uint64_t seed, int64_t first_pair, int radius,
  * smooth): the band's centre walks down the diagonal, stands still over a run of columns only the first block has
  * and jumps over a run only the second block has -- `events` such runs per 1 000 columns, half of each kind, lengths
  * geometric with mean 3.  The pair's own stream decides, so shapes (N = where the walk ends) and bands agree. */
-static int indel_run(rng_t *r) { int g = 1; while (below(r, 3) != 0) ++g; return g; }
-static int indel_walk(rng_t *r, int M, int events, int32_t *centre)      /* centre: M+1 entries or NULL; returns N */
+/* `events`: runs per 1 000 columns in the low 16 bits; bits 16..: how many of 1 000 runs are LONG -- 70 to 300 columns, uniform -- instead
+ * of geometric with mean 3 (the heavy tail of real blocks: one such run makes the rows around it 100-330 columns wide) */
+static int indel_run(rng_t *r, int tail)
 {
+    int g = 1;
+    if (tail && (int)below(r, 1000) < tail) return 70 + (int)below(r, 231);
+    while (below(r, 3) != 0) ++g;
+    return g;
+}
+static int indel_walk(rng_t *r, int M, int events_tail, int32_t *centre)      /* centre: M+1 entries or NULL; returns N */
+{
+    const int events = events_tail & 0xffff, tail = events_tail >> 16;
     int i = 1, c = 0;
     if (centre) centre[0] = 0;
     while (i <= M) {
         const int u = (int)below(r, 1000);
         if (2 * u < events && i > 1) {
-            int g = indel_run(r);
+            int g = indel_run(r, tail);
             for (; g > 0 && i <= M; --g, ++i) if (centre) centre[i] = c;
             continue;
         }
-        if (u < events) c += indel_run(r);
+        if (u < events) c += indel_run(r, tail);
         ++c;
         if (centre) centre[i] = c;
         ++i;
@@ -226,7 +235,7 @@ void mz_synth_bands_indel(int n, uint64_t seed, int64_t first_pair, int radius, 
  * all dashes below the top row (rmColDash, mz_preyama.c:87-108, has something to drop).  Text of merge p at
  * pool + offText[p]: K rows of Ma bytes, then L1 rows of Na bytes. */
 typedef struct { int R, Ma, Na; } pre_shape;
-static int pre_run(rng_t *w, int events) { return (int)below(w, 2000) < events ? indel_run(w) : 0; }
+static int pre_run(rng_t *w, int events) { return (int)below(w, 2000) < (events & 0xffff) ? indel_run(w, events >> 16) : 0; }
 static pre_shape pre_walk(uint64_t seed, int64_t p, int K, int rlo, int rhi, int events, uint8_t *ins1, uint8_t *ins2)
 {
     rng_t r, w;

@@ -639,14 +639,29 @@ def test_tagged_strips_random_wide_bands(mz):
         assert (res["status"] == 0).all() and cells == int(res["cells"].sum())
         hist = np.bincount(res["mode"], minlength=13)
         if which:
-            assert hist[4] > 300, hist                               # the tagged strips took their share
+            assert hist[4] > 300 and hist[12] == 0, hist               # the tagged strips took their share (the rolling form is opt-in)
         else:
-            assert hist[4] == 0 and hist[1] > 300, hist             # exact kernels only
+            assert hist[4] == 0 and hist[12] == 0 and hist[1] > 300, hist     # exact kernels only
         out = db.out.cpu().numpy()
         for i, (A, B, _, _) in enumerate(pairs):
             m_, o0, W = int(res["om"][i]), int(res["offOut"][i]), A.shape[1] + B.shape[1]
             assert m_ == om[i] and _hash(out[o0: o0 + m_ * W], m_) == int(hs[i]), (which, i, int(res["mode"][i]))
     _kernels(mz, 2)
+
+
+def test_rolling_form_with_late_starts_opt_in():
+    # MZ_TROLL=1 (read when the score model is uploaded, hence the child): well-formed wide-and-high bands whose rows never wait more
+    # than the rings hold run on the tagged wavefront with late starts (MZ_MODE_TROLL = 12, kernels/roll.inc) instead of the strips;
+    # 2 000 random wide pairs against the oracle by hash (tests/tools/strip_stress.py)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "strip_stress.py"), "2000", "7"], cwd=root,
+                       env=dict(os.environ, MZ_TROLL="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    last = p.stdout.strip().splitlines()[-1]
+    hist = [int(x) for x in last[last.index("[") + 1: last.index("]")].split()]
+    assert hist[12] > 500 and "mismatches 0" in last, last
 
 
 def test_pipelined_form_from_a_cold_start():

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for d in 0 1 2 4 8 15; do echo "MZ_DBG=$d"; MZ_DBG=$d MZ_CHUNKS=1 MZ_CHUNK_PAIRS=1000000 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dbg$d -- $(python3 -c 'import os,sys; print(os.path.realpath(sys.executable))') bench.py --mode pre --config c2 --pre-v 1 --steps 4 --warmup 1 > /dev/null 2>&1; grep "k_pre" $(find /tmp/dbg$d -name "*kernel_stats.csv") | cut -c1-120; done
+run() { timeout 300 python bench.py --config $1 --steps 20 --no-cpu --no-host 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d[\"config\"][\"workload\"][:4], d[\"value\"], d[\"kernel_gcups\"], d[\"kernel_ms\"], d[\"dp_modes\"])"; }
+echo default; run c2g; echo MZ_NO_TROLL=1; MZ_NO_TROLL=1 run c2g; echo MZ_NO_TSTRIP=1; MZ_NO_TSTRIP=1 run c2g
