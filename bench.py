@@ -145,6 +145,16 @@ def one_socket_cores():
         return sorted(os.sched_getaffinity(0)), model
 
 
+def cpu_throttle():
+    """(nr_throttled, throttled_usec) of this container's cgroup, or None: the CPU quota at work -- when the job has used its
+    quota of a 100 ms period every thread of it is parked until the next one, the threads that feed the GPU included"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_budget():
     """CPUs' worth of time the container may use: the affinity mask capped by the cgroup quota (cpu.max); the quota text"""
     n = len(os.sched_getaffinity(0))
@@ -325,15 +335,18 @@ def pre_column(config, pairs, check):
             api.free_preouts(outs)
         time.sleep(0.3)
         ts = []
-        for _ in range(5):
+        thr0 = cpu_throttle()
+        for _ in range(9):
             t = time.perf_counter()
             rc = api.preyama_batch_records(jobs, outs)
             ts.append(time.perf_counter() - t)
             api.free_preouts(outs)
             time.sleep(0.05)
+        thr1 = cpu_throttle()
         up, down, cells = api.pre_link_bytes()
         t_med = float(np.median(ts))
         d = {"gcups": round(cells / t_med / 1e9, 2), "ms_per_batch": round(1e3 * t_med, 2), "ms_all": [round(1e3 * x, 2) for x in ts],
+             "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None),
              "band_cells": cells, "merges": int(pairs), "without_block": int(rc), "two_stage_merges": int((jobs["v"] == 0).sum()),
              "link_bytes_per_merge": {"up": round(up / pairs, 1), "down": round(down / pairs, 1)},
              "text_bytes_per_merge": round(float((pb["K"].astype(np.int64) * pb["Ma"] + pb["L1"].astype(np.int64) * pb["Na"]).mean()), 1)}
@@ -651,14 +664,16 @@ def main():
         # (the container's CPU quota is per 100 ms period: let the period the harness's own threads -- generator, checker --
         #  have drawn on run out before the library's host threads are timed)
         time.sleep(0.3)
-        reps, t_host = 5, []
+        reps, t_host = 9, []
         os.environ["MZ_TIMING"] = "0"
+        thr0 = cpu_throttle()
         for _ in range(reps):
             t = time.perf_counter()
             api.yama_batch_records(jobs, outs)
             t_host.append(time.perf_counter() - t)
             api.free_outs(outs)
             time.sleep(0.05)
+        thr1 = cpu_throttle()
         if cpu is not None:                                      # the host path's BYTES, hashed like the CPU leg's (checker code; untimed call)
             from oracle import mzoracle as mo
             api.yama_batch_records(jobs, outs)
@@ -670,6 +685,8 @@ def main():
         out["value_host"] = round(cells / t_med / 1e9, 2)
         out["host_ms_per_batch"] = round(1e3 * t_med, 2)
         out["host_ms_all"] = [round(1e3 * x, 2) for x in t_host]
+        out["host_spread"] = {"max_over_median": round(max(t_host) / t_med, 3), "min_over_median": round(min(t_host) / t_med, 3),
+                              "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None)}
         link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
         out["host_link_bytes_per_pair"] = {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}
 

@@ -19,6 +19,7 @@
  * through their streams.  A call of one chunk (the drop-in yama(): a batch of one) runs the three steps inline.
  */
 #include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -674,27 +675,51 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
         G.copy_threads = MZ_COPY_THREADS;
         rc = batch_on_ctx(&G, n, jobs, outs, max_pairs, &st);
     } else {
-        /* Contiguous ranges of about equal weight, one per GPU, each driven by its own host thread through its own
-         * context (streams, staging buffers, helper threads); results land in outs[] at the jobs' own positions, so there
-         * is nothing to gather.  No data-path collective: the work list lives in host memory and every GPU pulls its
-         * share over its own PCIe link. */
+        /* Dealt by cost, one share per GPU, each driven by its own host thread through its own context (streams, staging
+         * buffers, helper threads).  The pairs are classed by weight in half octaves (a counting sort: no comparison sort of a
+         * million-pair list) and dealt out from the heaviest class down in a snake over the GPUs (0..G-1, G-1..0, ...), as
+         * multiz_amd/shard.py deals a list over ranks: every GPU gets the same MIX -- a list that arrives long-pairs-first no
+         * longer gives the first GPU the few long pairs and the last all the short ones (contiguous ranges balanced the total
+         * weight only).  Each GPU's jobs are copied into a list of its own (48 bytes a job), its results copied back to the
+         * jobs' own positions.  No data-path collective: the work list lives in host memory and every GPU pulls its share
+         * over its own PCIe link. */
         dev_task task[MZ_MAX_DEV];
         pthread_t th[MZ_MAX_DEV];
-        double total = 0.0, acc = 0.0;
-        int d = 0, start = 0, started[MZ_MAX_DEV];
-        for (p = 0; p < n; ++p) total += job_weight(&jobs[p]);
-        for (p = 0; p < n && d < use; ++p) {
-            acc += job_weight(&jobs[p]);
-            if (d == use - 1) { p = n - 1; acc = total; }
-            if (acc >= total * (d + 1) / use || p == n - 1) {
-                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
-                task[d].n = p + 1 - start; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0; memset(&task[d].st, 0, sizeof task[d].st);
-                g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
-                start = p + 1;
-                ++d;
-            }
+        int d, started[MZ_MAX_DEV], cnt[MZ_MAX_DEV], fill[MZ_MAX_DEV];
+        int *owner = (int *)malloc((size_t)n * sizeof *owner), *where = (int *)malloc((size_t)n * sizeof *where);
+        unsigned char *cls = (unsigned char *)malloc((size_t)n);
+        mz_job *jbuf = (mz_job *)malloc((size_t)n * sizeof *jbuf);
+        mz_out *obuf = (mz_out *)malloc((size_t)n * sizeof *obuf);
+        int ccount[64], cstart[64], pos, c;
+        if (!owner || !where || !cls || !jbuf || !obuf) {
+            free(owner); free(where); free(cls); free(jbuf); free(obuf);
+            pthread_mutex_unlock(&g_big);
+            return mzi_set_err("out of memory");
         }
-        use = d;
+        memset(ccount, 0, sizeof ccount);
+        for (p = 0; p < n; ++p) {                            /* half-octave class of the weight: 2 * log2 */
+            const double w = job_weight(&jobs[p]);
+            int e = 0;
+            const double m = frexp(w > 1.0 ? w : 1.0, &e);   /* w = m * 2^e, m in [0.5, 1) */
+            c = 2 * e + (m >= 0.70710678 ? 1 : 0);
+            cls[p] = (unsigned char)(c < 0 ? 0 : c > 63 ? 63 : c);
+            ccount[cls[p]]++;
+        }
+        for (c = 63, pos = 0; c >= 0; --c) { cstart[c] = pos; pos += ccount[c]; }     /* heaviest class first */
+        memset(cnt, 0, sizeof cnt);
+        for (p = 0; p < n; ++p) {                            /* rank of the pair in the sorted order -> its GPU, in a snake */
+            const int rank = cstart[cls[p]]++, rnd = rank / use, k = rank % use;
+            owner[p] = (rnd & 1) ? use - 1 - k : k;
+            cnt[owner[p]]++;
+        }
+        for (d = 0, pos = 0; d < use; ++d) { fill[d] = pos; pos += cnt[d]; }
+        for (d = 0, pos = 0; d < use; ++d) {
+            task[d].X = &g_dev[d]; task[d].jobs = jbuf + pos; task[d].outs = obuf + pos;
+            task[d].n = cnt[d]; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0; memset(&task[d].st, 0, sizeof task[d].st);
+            g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
+            pos += cnt[d];
+        }
+        for (p = 0; p < n; ++p) { where[p] = fill[owner[p]]++; jbuf[where[p]] = jobs[p]; obuf[where[p]] = outs[p]; }
         for (d = 1; d < use; ++d) {
             started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, dev_worker, &task[d]) == 0;
             if (!started[d] && task[d].n > 0) dev_worker(&task[d]);         /* no thread: do it here, after the others started */
@@ -709,6 +734,8 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
             st.cells += task[d].st.cells; st.bytes_up += task[d].st.bytes_up; st.bytes_down += task[d].st.bytes_down;
             g_dev[d].copy_threads = MZ_COPY_THREADS;
         }
+        for (p = 0; p < n; ++p) outs[p] = obuf[where[p]];    /* (a chunk's result block hangs on its first pair: mz_free_outs() walks all n) */
+        free(owner); free(where); free(cls); free(jbuf); free(obuf);
         hipSetDevice(G.device);
         if (rc >= 0) rc = failed;
     }

@@ -113,6 +113,26 @@ def test_invalid_bands_are_reported(mz):
     assert mz.yama_batch([big])[0].status == 16
 
 
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
+def test_exported_yama_dies_like_the_reference(case):
+    # the exported yama() itself (mz_yama.h:22) on each invalid band of mz_yama.c:58-71, in a child process: the message on
+    # stderr (util.c:21-30: "<argv0 basename>: ..." through fatalf) and the exit code, against the compiled reference's own yama()
+    # on the same arrays (oracle/_ref/libref.so) -- byte for byte
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = os.path.join(root, "oracle", "_ref", "libref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/libref.so not built")
+    child = os.path.join(root, "tests", "tools", "yama_fatal_child.py")
+    ours = subprocess.run([sys.executable, child, os.path.join(root, "multiz_amd", "libmzamd.so"), str(case)], capture_output=True, text=True, timeout=300)
+    want = subprocess.run([sys.executable, child, ref, str(case)], capture_output=True, text=True, timeout=300)
+    assert want.returncode == 1 and want.stderr.startswith("multiz: "), (want.returncode, want.stderr)
+    assert ours.returncode == want.returncode
+    assert [l for l in ours.stderr.splitlines() if l.startswith("multiz: ")] == [l for l in want.stderr.splitlines() if l.startswith("multiz: ")], (ours.stderr, want.stderr)
+    assert ours.stdout == want.stdout == ""
+
+
 def test_yama_dropin_signature(mz):
     # the reference-signature entry point itself: 1-based column pointer arrays in, two malloc blocks out
     lib = mz.lib()
