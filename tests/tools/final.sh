@@ -1,4 +1,4 @@
-# end-of-round measurements: tests, bench lines of every configuration, PMC records   (tests/tools/final.sh <tag>)
+# end-of-round measurements: tests, PMC records, bench lines of every configuration, the text path's profiles   (tests/tools/final.sh <tag>)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r4}
@@ -10,16 +10,25 @@ if timeout 2400 python tests/tools/pmc_collect.py ${TAG} ${PMC_CONFIGS:-c2 c3 c4
     cp gpurun_out/${TAG}/${TAG}_pmc.json profiles/${TAG}_pmc.json
 else
     echo "pmc_collect.py failed or was incomplete: profiles/${TAG}_pmc.json NOT updated"
+    cp gpurun_out/${TAG}/${TAG}_pmc.json $O/${TAG}_pmc_partial.json 2>/dev/null
 fi
-tail -6 $O/pmc_collect.txt
+tail -10 $O/pmc_collect.txt
+cp gpurun_out/${TAG}/${TAG}_kernel_stats_*.csv $O/ 2>/dev/null
 python bench.py > $O/${TAG}_bench_c2.json 2> $O/bench_c2.err
-for c in c3 c4 c5 c2i c4i c2w c2s; do python bench.py --config $c --steps 30 > $O/${TAG}_bench_$c.json 2> $O/bench_$c.err; done
+for c in c3 c4 c5 c2i c4i c2w c2s c2g; do python bench.py --config $c --steps 30 > $O/${TAG}_bench_$c.json 2> $O/bench_$c.err; done
+# the text path (mz_preyama_batch): kernel stats + counters of k_pre / k_mid / k_fin beside the DP kernels, chunked as shipped and each kernel alone
+bash tests/tools/profile_pre.sh c2 ${TAG}_pre > $O/${TAG}_pre_profile_c2.txt 2>&1
+MZ_CHUNKS=1 MZ_CHUNK_PAIRS=1000000 bash tests/tools/profile_pre.sh c2 ${TAG}_pre_alone > $O/${TAG}_pre_alone_profile_c2.txt 2>&1
+cp gpurun_out/${TAG}_pre_kernel_stats_c2_v*.csv gpurun_out/${TAG}_pre_alone_kernel_stats_c2_v*.csv $O/ 2>/dev/null
+python tests/tools/roast_bench.py > $O/${TAG}_roast_bench.txt 2>&1
 python - "$O" "$TAG" <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json"))):
     try:
         d = json.load(open(f))
-        print(os.path.basename(f), d["value"], "host", d.get("value_host"), d.get("host_ms_per_batch"), "serial", d["kernel_gcups"], d["kernel_ms"], "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("socket_linear"), d.get("vs_cpu"))
+        r = d["roofline"]
+        print(os.path.basename(f), d["value"], "host", d.get("value_host"), d.get("host_ms_per_batch"), "pre", d.get("value_pre"), d.get("value_pre_v0"), "serial", d["kernel_gcups"], d["kernel_ms"],
+              "roof", r["frac"], "valu", (r.get("valu") or {}).get("frac"), "traffic", r.get("traffic"), "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("socket_linear"), d.get("vs_cpu"))
     except Exception as e:
         print(f, "unreadable", e)
 PY
