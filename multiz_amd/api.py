@@ -48,6 +48,7 @@ class DevBatchC(C.Structure):
 
 
 _lib = None
+MZ_AMD_ABI = 3          # include/mz_amd.h
 
 
 def lib():
@@ -63,6 +64,10 @@ def lib():
             except ImportError:
                 pass
         _lib = C.CDLL(LIB_PATH)
+        got = _lib.mz_abi_version() if hasattr(_lib, "mz_abi_version") else 0
+        if got != MZ_AMD_ABI:                           # (the structures below are laid out for exactly this revision)
+            _lib = None
+            raise RuntimeError(f"{LIB_PATH} has ABI {got}, these bindings are for {MZ_AMD_ABI}: rebuild (__graft_entry__.build())")
         _lib.mz_last_error.restype = C.c_char_p
         _lib.mz_init.argtypes = [C.c_int]
         _lib.mz_stream.restype = C.c_void_p

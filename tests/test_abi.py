@@ -84,3 +84,16 @@ def test_product_does_not_reference_the_oracle():
                 assert "mzoracle" not in text and "liboracle" not in text and "mzo_" not in text, os.path.join(dirpath, f)
     out = subprocess.check_output(["ldd", LIB]).decode()
     assert "oracle" not in out
+
+
+def test_abi_revision_and_struct_sizes_agree(lib, tmp_path):
+    # the header's MZ_AMD_ABI, the library's mz_abi_version() and the ctypes mirrors in multiz_amd/api.py describe ONE layout
+    from multiz_amd import api
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "mz_amd.h"\nint main(void){printf("%d %zu %zu %zu %zu\\n", MZ_AMD_ABI,'
+                   'sizeof(mz_job),sizeof(mz_out),sizeof(mz_prejob),sizeof(mz_preout));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == lib.mz_abi_version() == api.MZ_AMD_ABI
+    assert got[1:] == [C.sizeof(api.Job), C.sizeof(api.Out), C.sizeof(api.PreJob), C.sizeof(api.PreOut)]
