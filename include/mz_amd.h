@@ -238,6 +238,39 @@ void mz_link_bytes(int64_t *up, int64_t *down);
 /* free the result blocks of a finished call (all n entries of it) and reset cols / block to NULL */
 void mz_free_outs(int n, mz_out *outs);
 
+/* ---------------------------------------------------------------- link images: the same traffic, moved by the caller
+ *
+ * What mz_yama_batch() moves over PCIe, for a caller that moves it itself -- multiz_amd/shard.py: the list exists on rank 0,
+ * every other rank's share reaches ITS GPU over RCCL / xGMI (ncclSend / ncclRecv of independent shards).
+ * The sender packs its jobs into an IMAGE (byte classes two per byte, band bounds as steps: DESIGN.md section 3), the rank that
+ * aligns runs the image where it lies in HBM and fills a RESULT image (a record per pair + the edit scripts at two bits per
+ * merged column), the sender assembles the merged columns from its own A and B.  Per C2 pair 3.1 KB out and 0.53 KB back instead
+ * of the pools' 6.0 + 4.3 KB.
+ *   mz_link_pack      host only (no GPU is touched): image and exception block from the library (256-byte aligned,
+ *                     release with mz_link_free()); d describes them and travels beside them as it is (8 x int64)
+ *   mz_link_plan      dev_image / dev_exc: the same bytes in device memory (dev_exc may be NULL when d->exc_bytes is 0).
+ *                     Expands and plans on `stream`, waits for the plan, sets d->res_bytes: the result image's size
+ *   mz_link_finish    DP, walk, script packing on `stream` into dev_result (d->res_bytes bytes of device memory); returns
+ *                     without waiting.  One image at a time per process: plan and finish use the primary context's buffers
+ *                     (not beside a running mz_yama_batch()); `stream` NULL = the library's own
+ *   mz_link_assemble  host only: outs[] from the result image (in host memory) and the jobs it was packed from, exactly
+ *                     what mz_yama_batch() would have returned; release with mz_free_outs()
+ *   mz_link_parts     byte offsets of the image's parts: K L M N (int32 x n) offA offB offBand (int64 x n: offsets into the
+ *                     EXPANDED pools) bandLen LB0 RB0 offC fmt, band steps, nibbles of A, nibbles of B, total -- at[16]
+ *   mz_link_expand    only the expansion, into the caller's device buffers: dev_cols takes the byte pools (A at 0, B at
+ *                     2 * al256(colsA / 2); 2 * (al256(colsA / 2) + al256(colsB / 2)) bytes, al256 = up to a multiple of 256), dev_LB / dev_RB
+ *                     `band` int32 each -- with the image's own K..offBand a device-resident batch (mz_dev_batch) of its own
+ * All return 0, or -1 with mz_last_error() (mz_link_assemble: the number of failed pairs, or -1 for an image that does not
+ * belong to these jobs). */
+typedef struct mz_link_desc { int64_t n, image_bytes, exc_bytes, colsA, colsB, band, steps, res_bytes; } mz_link_desc;
+int mz_link_pack(int n, const mz_job *jobs, mz_link_desc *d, void **image, void **exc);
+void mz_link_free(void *p);
+int mz_link_plan(mz_link_desc *d, const void *dev_image, const void *dev_exc, void *stream);
+int mz_link_finish(const mz_link_desc *d, void *dev_result, void *stream);
+int mz_link_assemble(int n, const mz_job *jobs, const void *result, int64_t res_bytes, mz_out *outs);
+int mz_link_parts(const mz_link_desc *d, int64_t at[16]);
+int mz_link_expand(const mz_link_desc *d, const void *dev_image, const void *dev_exc, void *dev_cols, void *dev_LB, void *dev_RB, void *stream);
+
 /* ---------------------------------------------------------------- pre_yama() batches: block text in, block text out
  *
  * N independent merges -- pre_yama(a1, a2, beg, end, radius, v, ...) of reference mz_preyama.c:152-359: one stage

@@ -200,6 +200,112 @@ def free_outs(outs: np.ndarray):
     f(len(outs), outs.ctypes.data)
 
 
+# ---------------------------------------------------------------- link images (include/mz_amd.h: mz_link_*)
+class LinkDesc(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n", "image_bytes", "exc_bytes", "colsA", "colsB", "band", "steps", "res_bytes")]
+
+
+RES_DT = np.dtype([("status", "<i4"), ("badrow", "<i4"), ("om", "<i4"), ("f", "<i4", (3,)), ("off", "<i8"), ("cells", "<i8")])    # mz_res_rec
+LINK_PARTS = ("K", "L", "M", "N", "offA", "offB", "offBand", "len", "lb0", "rb0", "offC", "fmt", "steps", "nibA", "nibB", "bytes")
+
+
+def _al256(x: int) -> int:
+    return (x + 255) & ~255
+
+
+def link_pack(jobs: np.ndarray):
+    """mz_link_pack(): the jobs (records from host_jobs(), any subset in any order) as a link image.  Host only.
+    Returns (desc int64[8], image uint8[...], exceptions uint8[...]) -- numpy copies, the library's buffers are released."""
+    L = lib()
+    d, img, exc = LinkDesc(), C.c_void_p(), C.c_void_p()
+    jobs = np.ascontiguousarray(jobs)
+    L.mz_link_pack.argtypes = [C.c_int, C.c_void_p, C.POINTER(LinkDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.mz_link_free.argtypes = [C.c_void_p]
+    _check(L.mz_link_pack(len(jobs), jobs.ctypes.data, C.byref(d), C.byref(img), C.byref(exc)), "mz_link_pack")
+    try:
+        image = np.ctypeslib.as_array((C.c_uint8 * d.image_bytes).from_address(img.value)).copy() if d.image_bytes else np.zeros(0, np.uint8)
+        excs = np.ctypeslib.as_array((C.c_uint8 * d.exc_bytes).from_address(exc.value)).copy() if d.exc_bytes else np.zeros(0, np.uint8)
+    finally:
+        L.mz_link_free(img)
+        L.mz_link_free(exc)
+    return np.array([getattr(d, k) for k, _ in LinkDesc._fields_], dtype=np.int64), image, excs
+
+
+def _desc(desc: np.ndarray) -> LinkDesc:
+    d = LinkDesc()
+    for (k, _), v in zip(LinkDesc._fields_, np.asarray(desc, dtype=np.int64).tolist()):
+        setattr(d, k, int(v))
+    return d
+
+
+def link_parts(desc: np.ndarray) -> dict:
+    """byte offsets of the image's parts (mz_link_parts)"""
+    at = (C.c_int64 * 16)()
+    d = _desc(desc)
+    if lib().mz_link_parts(C.byref(d), at) != 0:
+        raise RuntimeError("mz_link_parts: " + lib().mz_last_error().decode())
+    return dict(zip(LINK_PARTS, list(at)))
+
+
+def link_run(desc: np.ndarray, image, exc):
+    """The rank that aligns: image / exc are uint8 tensors ON THE GPU (as they arrived over RCCL).  Plans and runs the image on
+    torch's current stream and returns the result image as a device tensor (records + 2-bit scripts: what goes back)."""
+    import torch
+    if image.device.type != "cuda":
+        raise RuntimeError("link_run needs HIP device tensors (there is no CPU path in the product)")
+    torch.cuda.set_device(image.device)
+    L = lib()
+    d = _desc(desc)
+    st = torch.cuda.current_stream(image.device).cuda_stream
+    L.mz_link_plan.argtypes = [C.POINTER(LinkDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mz_link_finish.argtypes = [C.POINTER(LinkDesc), C.c_void_p, C.c_void_p]
+    _check(L.mz_link_plan(C.byref(d), image.data_ptr() if image.numel() else None, exc.data_ptr() if exc.numel() else None, st), "mz_link_plan")
+    res = torch.zeros(int(d.res_bytes), dtype=torch.uint8, device=image.device)
+    _check(L.mz_link_finish(C.byref(d), res.data_ptr(), st), "mz_link_finish")
+    return res
+
+
+def link_records(result, n: int):
+    """the n records of a result image (numpy uint8 array or torch tensor on any device): a structured view / copy"""
+    raw = result[64: 64 + RES_DT.itemsize * n]
+    if not isinstance(raw, np.ndarray):
+        raw = raw.cpu().numpy()
+    return np.ascontiguousarray(raw).view(RES_DT)
+
+
+def link_assemble(jobs: np.ndarray, result: np.ndarray) -> np.ndarray:
+    """mz_link_assemble(): outs (OUT_DT records) for these jobs from their result image; release with free_outs().  Host only."""
+    jobs = np.ascontiguousarray(jobs)
+    result = np.ascontiguousarray(result, dtype=np.uint8)
+    outs = np.zeros(len(jobs), dtype=OUT_DT)
+    f = lib().mz_link_assemble
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    _check(f(len(jobs), jobs.ctypes.data, result.ctypes.data, result.size, outs.ctypes.data), "mz_link_assemble")
+    return outs
+
+
+def link_expand(desc: np.ndarray, image, exc) -> dict:
+    """mz_link_expand(): the image as a device-resident batch's tensors (DevBatch.from_tensors takes them): the header arrays are
+    views into the image, the pools are expanded beside it (byte classes as canonical letters, int32 bounds)."""
+    import torch
+    torch.cuda.set_device(image.device)
+    d, at = _desc(desc), link_parts(desc)
+    n, dev = int(d.n), image.device
+    na, nb = _al256(d.colsA // 2), _al256(d.colsB // 2)
+    cols = torch.empty(2 * (na + nb) + 256, dtype=torch.uint8, device=dev)
+    LB = torch.empty(max(int(d.band), 1), dtype=torch.int32, device=dev)
+    RB = torch.empty(max(int(d.band), 1), dtype=torch.int32, device=dev)
+    f = lib().mz_link_expand
+    f.argtypes = [C.POINTER(LinkDesc)] + [C.c_void_p] * 6
+    _check(f(C.byref(d), image.data_ptr(), exc.data_ptr() if exc.numel() else None, cols.data_ptr(), LB.data_ptr(), RB.data_ptr(),
+             torch.cuda.current_stream(dev).cuda_stream), "mz_link_expand")
+    v = lambda k, dt, sz: image[at[k]: at[k] + sz * n].view(dt)  # noqa: E731
+    t = {k: v(k, torch.int32, 4) for k in ("K", "L", "M", "N")}
+    t.update({k: v(k, torch.int64, 8) for k in ("offA", "offB", "offBand")})
+    t.update(poolA=cols[: 2 * na], poolB=cols[2 * na:], poolLB=LB, poolRB=RB)
+    return t
+
+
 class PreJob(C.Structure):
     _fields_ = [("K", C.c_int), ("L1", C.c_int), ("M_all", C.c_int), ("N_all", C.c_int), ("radius", C.c_int),
                 ("rows1", C.POINTER(C.c_char_p)), ("rows2", C.POINTER(C.c_char_p)), ("v", C.c_int)]

@@ -343,25 +343,28 @@ static void assemble_range(void *ctx, int lo, int hi)
     _mm_sfence();
 }
 
-static int chunk_collect(chunk *c)
+/* outs[] of n jobs from their result image in host memory (64-byte header, a record per pair, the packed scripts): ONE block for the
+ * merged columns, assembled on the pool threads from the caller's own A and B.  `limit`: bytes of the image when it came from
+ * somewhere else (a link image: every record is checked against it), 0 for the pipeline's own. */
+static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, int64_t *cells)
 {
-    mz_ctx *X = c->X;
-    const int n = c->n, set = c->set;
-    const mz_job *jobs = c->jobs;
-    mz_out *outs = c->outs;
-    const char *r = (const char *)X->h_res[set].p;
     const mz_res_rec *rec = (const mz_res_rec *)(r + 64);
-    const uint8_t *packed = (const uint8_t *)r + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n);
+    const size_t scripts_at = 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n);
+    const uint8_t *packed = (const uint8_t *)r + scripts_at;
     size_t *where, total = 0;
     uint8_t *block = NULL;
     int p, failed = 0;
 
-    c->t_col0 = mzi_now_s();
-    HIPCK(hipEventSynchronize(X->bdone[set]));
-    HIPCK(hipMemcpyAsync(X->h_res[set].p, X->d_res[set].p, (size_t)c->res_bytes, hipMemcpyDeviceToHost, X->bstream[set]));
-    TSTAMP(X, set, 5, X->bstream[set]);
-    HIPCK(hipStreamSynchronize(X->bstream[set]));
-    c->t_col1 = mzi_now_s();
+    if (limit) {
+        if (limit < scripts_at) return mzi_set_err("result image of %zu bytes is too short for %d pairs", limit, n);
+        for (p = 0; p < n; ++p) {
+            const mz_res_rec *q = &rec[p];
+            if (q->status != MZ_OK) continue;
+            if (q->om < 0 || (int64_t)q->om > (int64_t)jobs[p].M + jobs[p].N || q->off < 0 ||
+                scripts_at + (size_t)q->off + ((size_t)q->om + 3) / 4 > limit)
+                return mzi_set_err("result image does not belong to these jobs (pair %d: %d columns at %lld)", p, q->om, (long long)q->off);
+        }
+    }
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
     if (!where) return mzi_set_err("out of memory");
     /* ONE allocation for the chunk's merged columns; outs[first].block owns it (mz_free_outs).  Every pair's columns
@@ -386,10 +389,26 @@ static int chunk_collect(chunk *c)
         ac.jobs = jobs; ac.outs = outs; ac.rec = rec; ac.packed = packed; ac.where = where; ac.block = block; ac.failed = 0; ac.cells = 0;
         mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
         failed = ac.failed;
-        c->cells = ac.cells;
+        *cells = ac.cells;
     }
     outs[0].block = block;
     free(where);
+    return failed;
+}
+
+static int chunk_collect(chunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set;
+    int failed;
+
+    c->t_col0 = mzi_now_s();
+    HIPCK(hipEventSynchronize(X->bdone[set]));
+    HIPCK(hipMemcpyAsync(X->h_res[set].p, X->d_res[set].p, (size_t)c->res_bytes, hipMemcpyDeviceToHost, X->bstream[set]));
+    TSTAMP(X, set, 5, X->bstream[set]);
+    HIPCK(hipStreamSynchronize(X->bstream[set]));
+    c->t_col1 = mzi_now_s();
+    failed = results_assemble(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, &c->cells);
     c->t_col2 = mzi_now_s();
     return failed;
 }
@@ -748,6 +767,225 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
                         "\"gpus\": %d, \"chunk_pairs\": %d}}\n", n, rc, (long long)st.cells, dt, (double)st.cells / dt / 1e9, (long long)st.bytes_up, (long long)st.bytes_down, use, max_pairs);
     }
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ link images
+ * (include/mz_amd.h: the traffic of a chunk as something the caller moves -- multiz_amd/shard.py sends it over RCCL).  The image is
+ * the staging block of chunk_upload(): [K L M N](int32 x n) [offA offB offBand](int64 x n) [bandLen LB0 RB0](int32 x n) offC(int64 x n)
+ * fmt(n) band steps, class nibbles of A, class nibbles of B -- every part at a multiple of 256 bytes. */
+typedef struct link_parts { size_t K, L, M, N, offA, offB, offBand, len, lb0, rb0, offC, fmt, steps, nibA, nibB, bytes; } link_parts;
+
+static int link_lay(const mz_link_desc *d, link_parts *y)
+{
+    size_t at = 0;
+    const size_t n = (size_t)d->n;
+    if (d->n < 0 || d->n > INT32_MAX || d->colsA < 0 || d->colsB < 0 || d->band < 0 || d->steps < 0 || d->exc_bytes < 0 || (d->colsA & 63) || (d->colsB & 63))
+        return mzi_set_err("not a link descriptor");
+#define PART(f, bytes) do { y->f = at; at += mzi_al256(bytes); } while (0)
+    PART(K, 4 * n); PART(L, 4 * n); PART(M, 4 * n); PART(N, 4 * n);
+    PART(offA, 8 * n); PART(offB, 8 * n); PART(offBand, 8 * n);
+    PART(len, 4 * n); PART(lb0, 4 * n); PART(rb0, 4 * n); PART(offC, 8 * n); PART(fmt, n);
+    PART(steps, (size_t)d->steps); PART(nibA, (size_t)d->colsA / 2); PART(nibB, (size_t)d->colsB / 2);
+#undef PART
+    y->bytes = at;
+    return 0;
+}
+
+static void *link_alloc(size_t bytes)
+{
+    void *p = NULL;
+    return posix_memalign(&p, 256, bytes ? mzi_al256(bytes) : 256) ? NULL : p;
+}
+void mz_link_free(void *p) { free(p); }
+
+int mz_link_pack(int n, const mz_job *jobs, mz_link_desc *d, void **image, void **exc)
+{
+    link_parts y;
+    size_t eA = 0, eB = 0, nband = 0, bytesC = 0, oa = 0, ob = 0, oband = 0, oc = 0, bytesE = 0;
+    int32_t *hK, *hL, *hM, *hN, *hLen, *hLB0, *hRB0;
+    int64_t *hoA, *hoB, *hoBand, *hoC;
+    uint32_t *esz;
+    char *h;
+    pack_ctx pc;
+    int p;
+
+    if (image) *image = NULL;
+    if (exc) *exc = NULL;
+    if (n < 0 || (n && !jobs) || !d || !image || !exc) return mzi_set_err("mz_link_pack: bad arguments");
+    for (p = 0; p < n; ++p) {
+        const mz_job *j = &jobs[p];
+        if (job_ok(j)) { eA += cols_padded(j->K, j->M); eB += cols_padded(j->L, j->N); nband += (size_t)j->M + 1; bytesC += band_slot(j->M); }
+        else nband += 1;
+    }
+    memset(d, 0, sizeof *d);
+    d->n = n; d->colsA = (int64_t)eA; d->colsB = (int64_t)eB; d->band = (int64_t)nband; d->steps = (int64_t)bytesC;
+    if (link_lay(d, &y)) return -1;
+    h = (char *)link_alloc(y.bytes);
+    esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *esz);
+    if (!h || !esz) { free(h); free(esz); return mzi_set_err("out of memory"); }
+    memset(h, 0, y.steps);                                   /* (the gaps between the header's parts travel too) */
+    hK = (int32_t *)(h + y.K); hL = (int32_t *)(h + y.L); hM = (int32_t *)(h + y.M); hN = (int32_t *)(h + y.N);
+    hoA = (int64_t *)(h + y.offA); hoB = (int64_t *)(h + y.offB); hoBand = (int64_t *)(h + y.offBand);
+    hLen = (int32_t *)(h + y.len); hLB0 = (int32_t *)(h + y.lb0); hRB0 = (int32_t *)(h + y.rb0); hoC = (int64_t *)(h + y.offC);
+    for (p = 0; p < n; ++p) {
+        const mz_job *j = &jobs[p];
+        const int ok = job_ok(j);
+        const int nul = !j->A || !j->B || !j->LB || !j->RB;
+        hK[p] = j->K; hL[p] = j->L; hM[p] = nul ? 0 : j->M; hN[p] = nul ? 0 : j->N;
+        hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
+        hLen[p] = ok ? j->M + 1 : 1;
+        hLB0[p] = ok ? j->LB[0] : 0; hRB0[p] = ok ? j->RB[0] : 0;
+        if (ok) { oa += cols_padded(j->K, j->M); ob += cols_padded(j->L, j->N); oband += (size_t)j->M + 1; oc += band_slot(j->M); }
+        else oband += 1;
+    }
+    pc.jobs = jobs; pc.hoA = hoA; pc.hoB = hoB; pc.hoC = hoC; pc.hA = (uint8_t *)h + y.nibA; pc.hB = (uint8_t *)h + y.nibB;
+    pc.hC = (uint8_t *)h + y.steps; pc.hFmt = (uint8_t *)h + y.fmt; pc.esz = esz; pc.hE = NULL;
+    mzi_parallel_for(n, pack_grain(n), pack_range, &pc);
+    for (p = 0; p < n; ++p) if (esz[p]) { hoC[p] = (int64_t)bytesE; bytesE += esz[p]; }
+    if (bytesE) {
+        uint8_t *hE = (uint8_t *)link_alloc(bytesE);
+        if (!hE) { free(h); free(esz); return mzi_set_err("out of memory"); }
+        pc.hE = hE;
+        mzi_parallel_for(n, pack_grain(n), pack_exceptions, &pc);
+        *exc = hE;
+    }
+    free(esz);
+    d->image_bytes = (int64_t)y.bytes; d->exc_bytes = (int64_t)bytesE;
+    *image = h;
+    return 0;
+}
+
+int mz_link_parts(const mz_link_desc *d, int64_t at[16])
+{
+    link_parts y;
+    if (!d || !at || link_lay(d, &y)) return -1;
+    at[0] = (int64_t)y.K; at[1] = (int64_t)y.L; at[2] = (int64_t)y.M; at[3] = (int64_t)y.N; at[4] = (int64_t)y.offA; at[5] = (int64_t)y.offB;
+    at[6] = (int64_t)y.offBand; at[7] = (int64_t)y.len; at[8] = (int64_t)y.lb0; at[9] = (int64_t)y.rb0; at[10] = (int64_t)y.offC; at[11] = (int64_t)y.fmt;
+    at[12] = (int64_t)y.steps; at[13] = (int64_t)y.nibA; at[14] = (int64_t)y.nibB; at[15] = (int64_t)y.bytes;
+    return 0;
+}
+
+int mz_link_expand(const mz_link_desc *d, const void *dev_image, const void *dev_exc, void *dev_cols, void *dev_LB, void *dev_RB, void *stream)
+{
+    link_parts y;
+    const char *di = (const char *)dev_image;
+    hipStream_t st;
+    if (!d || !dev_image || !dev_cols || !dev_LB || !dev_RB || (d->exc_bytes && !dev_exc)) return mzi_set_err("mz_link_expand: bad arguments");
+    if (link_lay(d, &y)) return -1;
+    if ((int64_t)y.bytes != d->image_bytes) return mzi_set_err("mz_link_expand: not this image's descriptor");
+    pthread_mutex_lock(&g_big);
+    if (mzi_ensure_init()) { pthread_mutex_unlock(&g_big); return -1; }
+    st = stream ? (hipStream_t)stream : G.stream;
+    if (mzk_unband((int)d->n, (const int32_t *)(di + y.len), (const int32_t *)(di + y.lb0), (const int32_t *)(di + y.rb0), (const int64_t *)(di + y.offBand),
+                   (const int64_t *)(di + y.offC), (const uint8_t *)(di + y.fmt), (const uint8_t *)(di + y.steps), (const uint8_t *)dev_exc,
+                   (int32_t *)dev_LB, (int32_t *)dev_RB, st) ||
+        mzk_unnib(di + y.nibA, dev_cols, (long long)(2 * (mzi_al256((size_t)d->colsA / 2) + mzi_al256((size_t)d->colsB / 2))), st)) {
+        mzi_set_err("%s", mzk_last_error()); pthread_mutex_unlock(&g_big); return -1;
+    }
+    pthread_mutex_unlock(&g_big);
+    return 0;
+}
+
+/* the planned image between mz_link_plan() and mz_link_finish() */
+static struct { mz_dev_batch b; int64_t n, res_bytes; int planned; } g_link;
+
+int mz_link_plan(mz_link_desc *d, const void *dev_image, const void *dev_exc, void *stream)
+{
+    mz_ctx *X = &G;
+    link_parts y;
+    mz_dev_batch b;
+    hipStream_t st;
+    const char *di = (const char *)dev_image;
+    const int64_t *totals;
+    int n;
+
+    if (!d || (d->n && !dev_image) || (d->exc_bytes && !dev_exc)) return mzi_set_err("mz_link_plan: bad arguments");
+    if (link_lay(d, &y)) return -1;
+    if ((int64_t)y.bytes != d->image_bytes) return mzi_set_err("mz_link_plan: the descriptor says %lld bytes, its parts add up to %zu", (long long)d->image_bytes, y.bytes);
+    pthread_mutex_lock(&g_big);
+#define LFAIL(x) do { if (x) { pthread_mutex_unlock(&g_big); return -1; } } while (0)
+    LFAIL(mzi_ensure_init() || mzi_sync_scores());
+    g_link.planned = 0;
+    n = (int)d->n;
+    d->res_bytes = 64 + (int64_t)mzi_al256(sizeof(mz_res_rec) * (size_t)n) + 64;
+    if (n == 0) { g_link.n = 0; g_link.res_bytes = d->res_bytes; g_link.planned = 1; pthread_mutex_unlock(&g_big); return 0; }
+    st = stream ? (hipStream_t)stream : X->stream;
+    LFAIL(mzi_dev_reserve(&X->d_cols[0], 2 * (mzi_al256((size_t)d->colsA / 2) + mzi_al256((size_t)d->colsB / 2)) + 256) ||
+          mzi_dev_reserve(&X->d_band[0], 2 * mzi_al256(4 * (size_t)d->band)) ||
+          mzi_dev_reserve(&X->d_plan[0], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[0], 16 * sizeof(int64_t)));
+    memset(&b, 0, sizeof b);
+    b.n = n;
+    b.K = (const int32_t *)(di + y.K); b.L = (const int32_t *)(di + y.L); b.M = (const int32_t *)(di + y.M); b.N = (const int32_t *)(di + y.N);
+    b.offA = (const int64_t *)(di + y.offA); b.offB = (const int64_t *)(di + y.offB); b.offBand = (const int64_t *)(di + y.offBand);
+    b.poolA = (const uint8_t *)X->d_cols[0].p;
+    b.poolB = b.poolA + 2 * mzi_al256((size_t)d->colsA / 2);
+    b.poolLB = (const int32_t *)X->d_band[0].p;
+    b.poolRB = (const int32_t *)((char *)X->d_band[0].p + mzi_al256(4 * (size_t)d->band));
+    if (mzk_unband(n, (const int32_t *)(di + y.len), (const int32_t *)(di + y.lb0), (const int32_t *)(di + y.rb0), b.offBand, (const int64_t *)(di + y.offC),
+                   (const uint8_t *)(di + y.fmt), (const uint8_t *)(di + y.steps), (const uint8_t *)dev_exc, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st) ||
+        mzk_unnib(di + y.nibA, (void *)b.poolA, (long long)(2 * (mzi_al256((size_t)d->colsA / 2) + mzi_al256((size_t)d->colsB / 2))), st)) {
+        mzi_set_err("%s", mzk_last_error()); pthread_mutex_unlock(&g_big); return -1;
+    }
+    mz_dev_carve(&b, X->d_plan[0].p);
+    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;
+    if (mzk_plan(&b, st)) { mzi_set_err("%s", mzk_last_error()); pthread_mutex_unlock(&g_big); return -1; }
+    if (hipMemcpyAsync(X->h_tot[0].p, b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        mzi_set_err("mz_link_plan: the plan did not come back: %s", hipGetErrorString(hipGetLastError())); pthread_mutex_unlock(&g_big); return -1;
+    }
+    totals = (const int64_t *)X->h_tot[0].p;
+    d->res_bytes = 64 + (int64_t)mzi_al256(sizeof(mz_res_rec) * (size_t)n) + totals[1] / 4 + 64;
+    g_link.b = b; g_link.n = n; g_link.res_bytes = d->res_bytes; g_link.planned = 1;
+    pthread_mutex_unlock(&g_big);
+    return 0;
+}
+
+int mz_link_finish(const mz_link_desc *d, void *dev_result, void *stream)
+{
+    mz_ctx *X = &G;
+    mz_dev_batch b;
+    const int64_t *totals;
+    hipStream_t st;
+    char *dres = (char *)dev_result;
+    int n;
+
+    pthread_mutex_lock(&g_big);
+    if (!d || !g_link.planned || d->n != g_link.n || d->res_bytes != g_link.res_bytes || !dev_result) {
+        pthread_mutex_unlock(&g_big);
+        return mzi_set_err("mz_link_finish: not the image mz_link_plan() planned last");
+    }
+    g_link.planned = 0;
+    n = (int)d->n;
+    st = stream ? (hipStream_t)stream : X->stream;
+    if (n == 0) { pthread_mutex_unlock(&g_big); return 0; }
+    b = g_link.b;
+    totals = (const int64_t *)X->h_tot[0].p;
+    LFAIL(mzi_dev_reserve(&X->d_tb[0], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[0], (size_t)totals[1] + 256) ||
+          mzi_dev_reserve(&X->d_prep[0], 4 * (size_t)totals[4] + 256));
+    b.tbw = (uint32_t *)X->d_tb[0].p; b.script = (uint8_t *)X->d_script[0].p; b.out = NULL;
+    b.prep = (uint32_t *)X->d_prep[0].p; b.capPrep = (int64_t)(X->d_prep[0].cap / 4);
+    b.walk_hint = mz_walk_choice(n, totals); b.dp_hint = mz_dp_hint(n, totals);
+    b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
+    b.capTb = (int64_t)(X->d_tb[0].cap / 4); b.capScript = (int64_t)X->d_script[0].cap; b.capOut = INT64_MAX;
+    if (mzk_prep(&b, st) || mzk_dp(&b, st) || mzk_walk(&b, st, 0) ||
+        mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st)) {
+        mzi_set_err("%s", mzk_last_error()); pthread_mutex_unlock(&g_big); return -1;
+    }
+#undef LFAIL
+    pthread_mutex_unlock(&g_big);
+    return 0;
+}
+
+int mz_link_assemble(int n, const mz_job *jobs, const void *result, int64_t res_bytes, mz_out *outs)
+{
+    int64_t cells = 0;
+    int p;
+    if (n < 0 || (n && (!jobs || !outs || !result)) || res_bytes < 0) return mzi_set_err("mz_link_assemble: bad arguments");
+    if (n == 0) return 0;
+    for (p = 0; p < n; ++p) {
+        outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL;
+        outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
+    }
+    return results_assemble(n, jobs, outs, (const char *)result, (size_t)res_bytes, &cells);
 }
 
 void mz_link_bytes(int64_t *up, int64_t *down) { if (up) *up = g_last_up; if (down) *down = g_last_down; }
