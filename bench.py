@@ -491,26 +491,64 @@ def main():
         # the list exists on rank 0 only: partition by band cells, one grouped RCCL send per peer, the shard's
         # tensors become the device batch where they land; the aligned shard goes back the same way (checked below)
         whole = synth.make_batch(pairs * world, cfg["K"], cfg["L"], cfg["mlo"], cfg["mhi"], cfg["radius"], indel=cfg.get("indel", 0)) if rank == 0 else None
+        # on LINK IMAGES (include/mz_amd.h, mz_link_*): class nibbles + band steps out, a record per pair + 2-bit edit scripts back,
+        # the root assembles the merged columns from its own pools; MZ_SCATTER_POOLS=1 sends the pools and brings the columns back
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        tens, my_idx = shard.scatter_batch(whole, 0, red)
-        torch.cuda.synchronize(dev)
-        t_scatter = time.perf_counter() - t0
+        if os.environ.get("MZ_SCATTER_POOLS") == "1":
+            t0 = time.perf_counter()
+            tens, my_idx = shard.scatter_batch(whole, 0, red)
+            torch.cuda.synchronize(dev)
+            t_scatter = time.perf_counter() - t0
+            db = mz.DevBatch.from_tensors(tens, device=dev)
+            db.run()
+            r = db.results_device()
+            res_t = dict(om=r["om"], status=r["status"], off=r["offOut"], out=db.out[: int(r["totals"][2].item())])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            sh = shard.gather_results(res_t, my_idx, pairs * world,
+                                      (whole["K"].astype(np.int64) + whole["L"]) if rank == 0 else None, 0, red)
+            torch.cuda.synchronize(dev)
+            t_gather = time.perf_counter() - t0
+            exchange = {"format": "pools", "scatter_s": round(t_scatter, 4), "gather_s": round(t_gather, 4), "pairs_this_rank": int(len(my_idx))}
+        else:
+            t0 = time.perf_counter()
+            (desc, image, exc), my_idx = shard.scatter_link(whole, 0, red)
+            torch.cuda.synchronize(dev)
+            t_scatter = time.perf_counter() - t0
+            image, exc = image.to(dev), exc.to(dev)
+            t0 = time.perf_counter()
+            res_l = shard.link_compute((desc, image, exc), device=dev)
+            torch.cuda.synchronize(dev)
+            t_align = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            sh = shard.gather_link(res_l, my_idx, whole, 0, red)
+            torch.cuda.synchronize(dev)
+            t_gather = time.perf_counter() - t0
+            exchange = {"format": "link images", "scatter_s": round(t_scatter, 4), "align_s": round(t_align, 4), "gather_s": round(t_gather, 4),
+                        "pairs_this_rank": int(len(my_idx))}
+            if rank == 0:
+                ex = shard.last_exchange
+                exchange["bytes_per_pair"] = {"out": round(ex["up_bytes"] / ex["pairs"], 1), "back": round(ex["down_bytes"] / ex["pairs"], 1),
+                                              "pools_out": round(sum(whole[k].nbytes for k in ("poolA", "poolB", "poolLB", "poolRB")) / ex["pairs"], 1),
+                                              "columns_back": round(float((sh.om.astype(np.int64) * sh.widths).sum()) / ex["pairs"], 1)}
+                # every pair's merged columns against the compiled reference on a sample (the bytes the root assembled from ITS pools)
+                if not args.no_cpu:
+                    from oracle import mzoracle as mo
+                    idx = np.linspace(0, pairs * world - 1, num=min(400, pairs * world)).astype(np.int64)
+                    sub = shard.take(whole, idx)
+                    om_r, hs_r, _, bad_r = mo.ref_batch(sub, threads=8) if mo.have_reference() else mo.yama_batch(sub, variant=1, threads=8)
+                    mism = sum(int(sh.om[i]) != int(om_r[k]) or
+                               mo.fnv1a_np(sh.cols(int(i)), mo.fnv1a_np(np.array([sh.om[i]], dtype=np.int32).view(np.uint8))) != int(hs_r[k]) for k, i in enumerate(idx))
+                    assert bad_r == 0 and mism == 0, f"{mism} of {len(idx)} gathered pairs differ from the reference"
+                    exchange["checked_pairs"] = int(len(idx))
+            tens = api.link_expand(desc, image, exc)              # the timed steps run on the shard as it arrived: the image, expanded in HBM
+            db = mz.DevBatch.from_tensors(tens, device=dev)
         batch = {k: v.cpu().numpy() for k, v in tens.items()}                 # host copy for the byte accounting below
-        db = mz.DevBatch.from_tensors(tens, device=dev)
-        db.run()
-        r = db.results_device()
-        res_t = dict(om=r["om"], status=r["status"], off=r["offOut"], out=db.out[: int(r["totals"][2].item())])
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        sh = shard.gather_results(res_t, my_idx, pairs * world,
-                                  (whole["K"].astype(np.int64) + whole["L"]) if rank == 0 else None, 0, red)
-        torch.cuda.synchronize(dev)
-        t_gather = time.perf_counter() - t0
-        exchange = {"scatter_s": round(t_scatter, 4), "gather_s": round(t_gather, 4), "pairs_this_rank": int(len(my_idx))}
         if rank == 0:
             assert (sh.status == 0).all() and (sh.owner >= 0).all(), "a pair came back without a result"
             exchange["ranks_used"] = int(len(set(sh.owner.tolist())))
+            if hasattr(sh, "release"):
+                sh.release()
         del whole
         pairs_here = int(len(my_idx))
     else:

@@ -51,7 +51,7 @@ static struct {
 
 /* ------------------------------------------------------------------------------------------------ text "files" */
 
-static double g_t[8];                                      /* MZ_TIMING: read, project, parse, walk, align, replay + render, line filters */
+static double g_t[8];                                      /* MZ_TIMING: read, project, parse, walk, align, replay + render + line filters, start-up wait */
 #define TIMED(slot, stmt) do { const double t_ = mz_now_s(); stmt; g_t[slot] += mz_now_s() - t_; } while (0)
 
 static void buf_free(buf *b) { free(b->p); b->p = NULL; b->n = 0; b->cap = 0; }
@@ -396,7 +396,12 @@ int mz_roast_main(int argc, char **argv)
               g_t[3] += mz_now_s() - t_; }
             for (k = 0; k < ntodo; ++k) if (T.nd[todo[k]].run) runs[nruns++] = T.nd[todo[k]].run;
         }
-        if (nruns) { TIMED(4, mz_multiz_align(runs, nruns)); ++batches; }
+        if (nruns) {
+            /* what is left of the GPU's start-up (mz_warm_start() above: runtime, context, code object -- ~0.2 s beside a parser that
+             * contends for the same page-table lock) is waited for HERE, under its own name, not inside the first batch's time */
+            if (!batches) TIMED(6, mz_warm_wait());
+            TIMED(4, mz_multiz_align(runs, nruns)); ++batches;
+        }
         /* replay and rendering of every node of the round, side by side (multic nodes: one after the other -- its driver
          * keeps state of its own) */
         { const double t_ = mz_now_s();
@@ -423,8 +428,8 @@ int mz_roast_main(int argc, char **argv)
     fclose(dst);
     if (mzi_timing())
         fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s (reading leaves %.3f, final projection %.3f, parsing + projecting the inputs %.3f, "
-                "list walks %.3f, alignment batches with their host stages %.3f, replay + rendering + line filters %.3f)\n",
-                T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0, g_t[0], g_t[1], g_t[2], g_t[3], g_t[4], g_t[5]);
+                "list walks %.3f, waiting for the GPU's start-up %.3f, alignment batches with their host stages %.3f, replay + rendering + line filters %.3f)\n",
+                T.nn ? T.nd[root].id + 1 : 0, rounds, batches, mz_now_s() - t0, g_t[0], g_t[1], g_t[2], g_t[3], g_t[6], g_t[4], g_t[5]);
     free(cmdline);
     return 0;
 }

@@ -71,18 +71,46 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
+def _link_worker(rank, world, port, n, q):
+    """the same exchange on link images (shard.run_sharded_link): class nibbles + band steps out, records + 2-bit scripts back, the
+    root assembles from its own pools; tests/linkfmt.py decodes / encodes where the product runs its kernels"""
+    import torch.distributed as dist
+    import linkfmt
+    from multiz_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, pairs = _batch(11, n) if rank == 0 else (None, None)
+        sh, totals = shard.run_sharded_link(batch, linkfmt.oracle_compute)
+        if rank == 0:
+            ok = bool((sh.status == 0).all()) and sorted(set(sh.owner.tolist())) == list(range(min(world, n)))
+            for i, (A, B, LB, RB) in enumerate(pairs):
+                want = mo.yama(A, B, LB, RB)
+                ok &= int(sh.om[i]) == want.OM and np.array_equal(sh.cols(i), want.cols.ravel())
+            cells = sum(mo.band_cells(p[2], p[3]) for p in pairs)
+            pools = sum(batch[k].nbytes for k in ("poolA", "poolB", "poolLB", "poolRB"))
+            merged = int(sum(int(sh.om[i]) * (p[0].shape[1] + p[1].shape[1]) for i, p in enumerate(pairs)))
+            ex = dict(shard.last_exchange)
+            ok &= ex["pairs"] == n and ex["down_bytes"] < merged + 200 * n + 1024 * world
+            ok &= n < 20 or ex["up_bytes"] < pools             # (every part of an image is padded to 256 bytes: a handful of tiny pairs is all padding)
+            sh.release()
+            q.put((ok, totals, (n, cells, 0)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-@pytest.mark.parametrize("world,n", [(2, 23), (3, 10), (2, 1)])
-def test_scatter_compute_gather(world, n):
+@pytest.mark.parametrize("world,n,worker", [(2, 23, "pools"), (3, 10, "pools"), (2, 1, "pools"), (2, 23, "link"), (3, 10, "link"), (2, 1, "link")])
+def test_scatter_compute_gather(world, n, worker):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker if worker == "pools" else _link_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _q

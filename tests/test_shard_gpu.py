@@ -41,18 +41,54 @@ def _worker(rank, world, port, n, cfg, q):
         dist.destroy_process_group()
 
 
+def _link_worker(rank, world, port, n, cfg, q):
+    """link images: nibbles + band steps to the rank, mz_link_plan / mz_link_finish where they land, records + 2-bit scripts back,
+    merged columns assembled by the root from its own pools"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import multiz_amd as mz
+        from multiz_amd import shard, synth
+        from oracle import mzoracle as mo
+        mz.api.init(0)
+        batch = None
+        if rank == 0:
+            c = synth.CONFIGS[cfg]
+            batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=77, indel=c.get("indel", 0))
+        sh, totals = shard.run_sharded_link(batch, lambda s: shard.link_compute(s, device="cuda:0"))
+        if rank == 0:
+            om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=8)
+            ok = bad == 0 and bool((sh.status == 0).all()) and set(sh.owner.tolist()) == set(range(world))
+            mism = 0
+            for i in range(n):
+                m_ = int(sh.om[i])
+                h = mo.fnv1a_np(sh.cols(i), mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8)))
+                mism += (m_ != om[i]) or (h != int(hs[i]))
+            ex = dict(shard.last_exchange)
+            pools = sum(batch[k].nbytes for k in ("poolA", "poolB", "poolLB", "poolRB"))
+            merged = int((sh.om.astype(np.int64) * sh.widths).sum())
+            ok &= ex["up_bytes"] < 0.6 * pools and ex["down_bytes"] < 0.25 * merged + 100 * n
+            sh.release()
+            q.put((ok, mism, totals, (n, cells, 0)))
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-@pytest.mark.parametrize("cfg,n", [("c4", 600), ("c2", 300)])
-def test_scatter_device_compute_gather_two_ranks(cfg, n):
+@pytest.mark.parametrize("cfg,n,worker", [("c4", 600, "pools"), ("c2", 300, "pools"), ("c4", 3000, "link"), ("c2i", 1500, "link")])
+def test_scatter_device_compute_gather_two_ranks(cfg, n, worker):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker if worker == "pools" else _link_worker, args=(r, 2, port, n, cfg, q)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _q
@@ -69,3 +105,64 @@ def test_scatter_device_compute_gather_two_ranks(cfg, n):
         assert p.exitcode == 0
     assert ok and mism == 0, (ok, mism)
     assert totals == want
+
+
+def test_result_image_is_the_oracles():
+    """one process: the product's result image for a link image (mz_link_plan / mz_link_finish) holds the records and the edit
+    scripts the oracle's traceback gives (tests/linkfmt.py), refused pairs included; mz_link_expand gives the batch the image decodes to"""
+    import torch
+    import inputs
+    import linkfmt
+    import multiz_amd as mz
+    from multiz_amd import api
+    from oracle import mzoracle as mo
+    from test_link_image import _jobs, _pairs
+    mz.api.init(0)
+    pairs = _pairs(21, 120)
+    A, B, LB, RB = pairs[5]
+    LB = LB.copy(); LB[3] = LB[2] - 1 if LB[2] > 0 else 0; RB = RB.copy(); RB[len(RB) // 2] = RB[len(RB) // 2 - 1] - 1     # a band the reference refuses
+    pairs[5] = (A, B, LB, RB)
+    jobs = _jobs(pairs)
+    desc, image, exc = api.link_pack(jobs)
+    want, cells, failed = linkfmt.oracle_result_image(desc, image, exc)
+    t_im, t_ex = torch.from_numpy(image).cuda(), torch.from_numpy(exc).cuda()
+    res = api.link_run(desc, t_im, t_ex)
+    torch.cuda.synchronize()
+    got = res.cpu().numpy()
+    n = len(pairs)
+    rg, rw = api.link_records(got, n), api.link_records(want, n)
+    assert failed >= 1 and (rg["status"] != 0).sum() == failed
+    for k in ("status", "om", "cells"):
+        assert np.array_equal(rg[k], rw[k]), k
+    okp = rg["status"] == 0
+    assert np.array_equal(rg["f"][okp], rw["f"][okp]) and np.array_equal(rg["badrow"][~okp], rw["badrow"][~okp])
+    sg, sw = 64 + linkfmt.al256(40 * n), 64 + linkfmt.al256(40 * n)
+    for p in np.flatnonzero(okp):
+        nb = (int(rg["om"][p]) + 3) // 4
+        assert np.array_equal(got[sg + rg["off"][p]: sg + rg["off"][p] + nb], want[sw + rw["off"][p]: sw + rw["off"][p] + nb]), p
+    from multiz_amd import shard
+    tot = shard.link_totals(res, n)
+    assert tot["cells"] == cells and tot["failed"] == failed
+    # the expansion as a device-resident batch of its own
+    t = api.link_expand(desc, t_im, t_ex)
+    torch.cuda.synchronize()
+    dec = linkfmt.decode_image(desc, image, exc)
+    for k in ("K", "L", "M", "N", "offA", "offB", "offBand"):
+        assert np.array_equal(t[k].cpu().numpy(), dec[k]), k
+    assert np.array_equal(t["poolLB"].cpu().numpy()[: len(dec["poolLB"])], dec["poolLB"]) and np.array_equal(t["poolRB"].cpu().numpy()[: len(dec["poolRB"])], dec["poolRB"])
+    for p in range(n):
+        K, L, M, N = (int(dec[k][p]) for k in ("K", "L", "M", "N"))
+        a0, b0 = int(dec["offA"][p]), int(dec["offB"][p])
+        assert np.array_equal(t["poolA"][a0: a0 + K * M].cpu().numpy(), dec["poolA"][a0: a0 + K * M])
+        assert np.array_equal(t["poolB"][b0: b0 + L * N].cpu().numpy(), dec["poolB"][b0: b0 + L * N])
+    db = mz.DevBatch.from_tensors(t, device="cuda:0")
+    db.run()
+    r = db.results()
+    assert np.array_equal(r["status"], rg["status"]) and np.array_equal(r["om"][okp], rg["om"][okp])
+    outs = api.link_assemble(jobs, got)
+    for p in np.flatnonzero(okp):
+        A, B, LB, RB = pairs[p]
+        w = mo.yama(A, B, LB, RB)
+        c = np.ctypeslib.as_array((api.C.c_uint8 * (w.OM * (A.shape[1] + B.shape[1]))).from_address(int(outs["cols"][p])))
+        assert outs["OM"][p] == w.OM and np.array_equal(c, w.cols.ravel()), p
+    api.free_outs(outs)
