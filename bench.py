@@ -632,6 +632,9 @@ def main():
                    "parallelism": f"pairs sharded x{world}" + (" (list built on rank 0, RCCL scatter/gather)" if exchange else "")},
         # the second column of SURVEY 8(d): the phases one after the other (HIP events, serial form)
         "kernel_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
+        # the same figure under the name VERDICT r3 asked for: ONE batch, plan -> DP -> walk -> emit one after the other, nothing of a
+        # neighbouring batch beside it (`value` is the pipelined form: at C5 five batches abreast)
+        "single_batch_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
         "kernel_ms": {"plan": round(float(kern_ms[0]), 3), "dp": round(dp_ms, 3),
                       "walk": round(float(kern_ms[2]), 3), "emit": round(float(kern_ms[3]), 3)},
         "dp_modes": {str(m): int(c) for m, c in enumerate(modes) if c},
