@@ -28,6 +28,11 @@ struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2,
                                    int has_out1, int has_out2);
 void mz_multiz_align(struct mz_mzrun **runs, int n);
 void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2);
+/* A run whose output goes on to another step of the same process ends in LISTS instead: keep_blocks() between prepare() and align()
+ * (nothing is rendered as text then), finish_lists() instead of finish().  Every block is what a reader of the text would hold: the
+ * score with one decimal, a source "x.x" as "x" (what mafWrite() prints and the MAF reader makes of it). */
+void mz_multiz_keep_blocks(struct mz_mzrun *run);
+void mz_multiz_finish_lists(struct mz_mzrun *run, struct mafAli **out, struct mafAli **out1, struct mafAli **out2);
 
 /* the multiz command line: [R=?] [M=?] file1 file2 v [out1 out2] [nohead] [all] */
 int mz_multiz_main(int argc, char **argv);

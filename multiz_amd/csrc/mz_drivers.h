@@ -30,6 +30,8 @@ static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MON
 /* mz_mafio.c */
 struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE *echo);
 struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name);
+void mz_ali_as_reread(struct mafAli *a);                 /* the block as the reader would see it after mafWrite() */
+struct mafAli *mz_ali_copy(const struct mafAli *a);      /* deep heap copy */
 /* mz_project.c */
 struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others);
 /* mz_multic.c */

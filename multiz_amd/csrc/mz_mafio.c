@@ -180,6 +180,54 @@ struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name)
     return list;
 }
 
+/* ------------------------------------------------------------------------------------------------ blocks handed on without text
+ * What a block IS after mafWrite() printed it and the reader above read it again -- the tree driver hands blocks from one step to the
+ * next as lists (mz_roast.c), and the next step must see what it would have parsed: the score with one decimal ("%3.1f", then atof), a
+ * source "x.x" printed as "x" (mafWrite's printable_src, reference maf.c:283-288) and split again.  Everything else a row line carries
+ * (start, size, strand, srcSize, text, the amplifier / copy marks of the 'a' line) survives the round trip as it is. */
+void mz_ali_as_reread(struct mafAli *a)
+{
+    struct mafComp *c;
+    /* (a whole number of moderate size prints as itself and ".0": most scores are sums of integer column scores) */
+    if (a->score != (double)MIN_INT && !(a->score == (double)(long long)a->score && a->score > -1e15 && a->score < 1e15 && a->score != 0.0)) {
+        char t[400]; snprintf(t, sizeof t, "%3.1f", a->score); a->score = atof(t);
+    }
+    a->chain_len = 0;
+    for (c = a->components; c; c = c->next) {
+        const char *dot = strchr(c->src, '.');
+        int changed = 0;
+        if (dot && dot[1] && (size_t)(dot - c->src) == strlen(dot + 1) && strncmp(c->src, dot + 1, (size_t)(dot - c->src)) == 0) {
+            c->src[dot - c->src] = 0; changed = 1;                               /* "x.x" comes back as "x" */
+        } else if (dot && !dot[1]) {
+            c->src[dot - c->src] = 0; changed = 1;                               /* "x." is printed as "x" */
+        }
+        if (changed || !c->name || !c->contig) {                                 /* (otherwise name and contig are this src's already: they are
+                                                                                  * copied with it from rows the reader split) */
+            free(c->name); free(c->contig);
+            split_src(c);
+        }
+        if (c->mafPosMap) { free(c->mafPosMap); c->mafPosMap = NULL; }
+        c->nameID = 0;
+    }
+}
+
+/* a deep copy on the heap (mafAliFree() releases it), whatever owns the original */
+struct mafAli *mz_ali_copy(const struct mafAli *a)
+{
+    struct mafAli *d = (struct mafAli *)mz_xmalloc(sizeof *d);
+    struct mafComp *c, *tail = NULL;
+    memset(d, 0, sizeof *d);
+    d->score = a->score; d->textSize = a->textSize;
+    for (c = a->components; c; c = c->next) {
+        struct mafComp *nc = mafCpyComp(c);
+        nc->text = (char *)mz_xmalloc((size_t)a->textSize + 1);
+        memcpy(nc->text, c->text, (size_t)a->textSize); nc->text[a->textSize] = 0;
+        if (tail) tail->next = nc; else d->components = nc;
+        tail = nc;
+    }
+    return d;
+}
+
 /* ------------------------------------------------------------------------------------------------ list helpers */
 
 struct mafAli *mz_pop_first(struct mafAli **head)

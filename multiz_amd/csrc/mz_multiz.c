@@ -102,6 +102,7 @@ typedef struct {
     int job;                  /* index into the merge list, or -1 */
     struct mafAli *src;       /* text still to be rendered (render_events): this block (arena copy) ... */
     int cbeg, cend;           /* ... columns cbeg..cend of it, or the whole block when cbeg < 0 */
+    struct mafAli *blk;       /* record.keep_blocks: the block itself instead of its text (heap; NULL where nothing would be printed) */
 } event;
 typedef struct {
     mz_py py;
@@ -117,6 +118,7 @@ typedef struct {
     event *ev; int nev, capev;
     merge *mg; int nmg, capmg;
     int has1, has2;           /* out1 / out2 sinks exist */
+    int keep_blocks;          /* the run ends in mz_multiz_finish_lists(): blocks are kept as blocks, nothing is rendered */
     arena_chunk *arena;       /* the private block copies of this run's events and merges */
 } record;
 
@@ -150,6 +152,17 @@ static void render_events(record *R)
         event *e = &R->ev[i];
         FILE *m;
         if (!e->src) continue;
+        if (R->keep_blocks) {                               /* what the text path prints, as a block */
+            if (e->cbeg < 0) e->blk = mz_ali_copy(e->src);
+            else {
+                struct mafAli *part = make_part_ali_col(e->src, e->cbeg, e->cend);
+                if (part && (row2 == 0 || part->components->next != NULL)) e->blk = part;      /* (print_part_ali_col's condition) */
+                else mafAliFree(&part);
+            }
+            if (e->blk) mz_ali_as_reread(e->blk);
+            e->src = NULL;
+            continue;
+        }
         m = open_memstream(&e->text, &e->len);
         if (e->cbeg < 0) mafWrite(m, e->src);
         else print_part_ali_col(e->src, e->cbeg, e->cend, m);
@@ -355,6 +368,11 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
         }
         g->result = block_from_rows(o, g->a1, cb1[i], g->a2, cb2[i]);
         g->state = MZ_PY_DONE;
+        if (all[who[i]].R->keep_blocks) {                   /* the block goes on as it is, if it would have been printed */
+            if (g->result && g->result->components->size < minw) mafAliFree(&g->result);
+            if (g->result) mz_ali_as_reread(g->result);
+            continue;
+        }
         if (g->result && g->result->components->size >= minw) {
             FILE *m = open_memstream(&g->text, &g->len);
             mafWrite(m, g->result);
@@ -431,7 +449,10 @@ static void run_merges(record **RR, int nrec, int minw)
                 g->py.borrowed = 1;
                 g->state = mz_py_step(&g->py, outs[i].cols, outs[i].OM, &g->result);
             }
-            if (g->state != MZ_PY_JOB && g->state != MERGE_FAILED) {    /* finished: render and release here */
+            if (g->state != MZ_PY_JOB && g->state != MERGE_FAILED && all[who[i]].R->keep_blocks) {
+                if (g->result && g->result->components->size < minw) mafAliFree(&g->result);
+                if (g->result) mz_ali_as_reread(g->result);
+            } else if (g->state != MZ_PY_JOB && g->state != MERGE_FAILED) {    /* finished: render and release here */
                 if (g->result && g->result->components->size >= minw) {
                     FILE *m = open_memstream(&g->text, &g->len);
                     mafWrite(m, g->result);
@@ -473,6 +494,52 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
     memset(R, 0, sizeof *R);
 }
 
+/* the same replay into three LISTS (record.keep_blocks): every block as the next program of the stock chain would read it from the text
+ * this replay does not write (mz_ali_as_reread).  The one piece of text a kept-blocks run still holds -- pre_yama()'s side write to out2
+ * when nothing of the first block is left to align (mz_preyama.c:193-196: host stage 1) -- is read back here. */
+typedef struct { struct mafAli *head, *tail; } alist;
+static void alist_add(alist *l, struct mafAli *a)          /* (a: one block, or a chain; already as their reader would hold them) */
+{
+    if (!a) return;
+    if (l->tail) l->tail->next = a; else l->head = a;
+    while (a->next) a = a->next;
+    l->tail = a;
+}
+static void replay_lists(record *R, struct mafAli **out, struct mafAli **f1, struct mafAli **f2)
+{
+    alist L[3] = { { NULL, NULL }, { NULL, NULL }, { NULL, NULL } };
+    int i;
+    for (i = 0; i < R->nev; ++i) {
+        event *e = &R->ev[i];
+        if (e->job >= 0) {
+            merge *g = &R->mg[e->job];
+            if (g->state == MERGE_FAILED) mz_fatal_status(&g->bad_job, &g->bad_out);
+            if (g->result) { alist_add(&L[SINK_OUT], g->result); g->result = NULL; }
+            free(g->text);
+            g->a1 = g->a2 = NULL;                           /* (arena) */
+        } else if (e->blk) {
+            if ((e->sink == SINK_1 && !R->has1) || (e->sink == SINK_2 && !R->has2)) mafAliFree(&e->blk);
+            else alist_add(&L[e->sink], e->blk);
+            e->blk = NULL;
+        } else if (e->text) {
+            if (e->len && !((e->sink == SINK_1 && !R->has1) || (e->sink == SINK_2 && !R->has2))) {
+                static const char head[] = "##maf version=1\n";
+                char *t = (char *)mz_xmalloc(sizeof head + e->len);
+                memcpy(t, head, sizeof head - 1); memcpy(t + sizeof head - 1, e->text, e->len);
+                alist_add(&L[e->sink], mz_maf_read_mem(t, sizeof head - 1 + e->len, "a side write"));
+                free(t);
+            }
+            free(e->text);
+        }
+    }
+    free(R->ev); free(R->mg);
+    arena_release(&R->arena);
+    memset(R, 0, sizeof *R);
+    *out = L[SINK_OUT].head;
+    if (f1) *f1 = L[SINK_1].head; else { struct mafAli *a = L[SINK_1].head; while (a) { struct mafAli *n = a->next; a->next = NULL; mafAliFree(&a); a = n; } }
+    if (f2) *f2 = L[SINK_2].head; else { struct mafAli *a = L[SINK_2].head; while (a) { struct mafAli *n = a->next; a->next = NULL; mafAliFree(&a); a = n; } }
+}
+
 /* A multiz run in three steps, so that several independent runs can share their GPU batches:
  *   mz_multiz_prepare()  walks the two lists (reference multiz.c:60-177) and records the output events and merges;
  *   mz_multiz_align()    runs every pending merge of the given runs: stage 1 on the host threads, the yama() calls
@@ -510,6 +577,16 @@ void mz_multiz_align(struct mz_mzrun **runs, int n)
 void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2)
 {
     replay(&run->R, out, out1, out2, run->minw);
+    free(run);
+}
+
+/* the run's output as block lists instead of text: call mz_multiz_keep_blocks() between prepare and align, then this instead of
+ * mz_multiz_finish().  The lists hold what a reader of the three text streams would hold (mz_ali_as_reread), in their order. */
+void mz_multiz_keep_blocks(struct mz_mzrun *run) { run->R.keep_blocks = 1; }
+void mz_multiz_finish_lists(struct mz_mzrun *run, struct mafAli **out, struct mafAli **out1, struct mafAli **out2)
+{
+    if (!run->R.keep_blocks) mz_fatalf("mz_multiz_finish_lists: the run was aligned for text");
+    replay_lists(&run->R, out, out1, out2);
     free(run);
 }
 

@@ -8,10 +8,14 @@
  *
  * Here the same chain runs inside one process on MAF text held in memory: the tree is parsed into explicit nodes with
  * the stock driver's stack discipline and node numbering; a node's "files" are buffers; projection is
- * mz_project_lists(), the merge is the batched driver of mz_multiz.c / mz_multic.c.  Blocks pass from step to step as
- * MAF text exactly as they do between the stock programs (what a reader re-derives from the text -- scores printed
- * with one decimal, sizes, the species/contig split of a source name -- is re-derived here too), but no file is
- * written and no process started.  Nodes whose children are finished are evaluated together: their multiz runs are
+ * mz_project_lists(), the merge is the batched driver of mz_multiz.c / mz_multic.c.  Between the steps the blocks go on as
+ * LISTS (round 4; MAF text only at the ends: the leaf files and the destination): a node's multiz run ends in block lists
+ * (mz_multiz_finish_lists) whose blocks are what a reader of the stock chain's intermediate files would hold (the score with
+ * one decimal, a source "x.x" as "x": mz_ali_as_reread), and the next node projects those lists.  The stock chain's line
+ * filters (grep -v maf / grep -v eof on the intermediate files) only ever remove header and trailer lines -- unless a
+ * species name contains "maf" or "eof", or a row holds an 'f': a leaf file with such a line marks every node above it, and
+ * those nodes run on MAF text as round 3 did (MZ_ROAST_TEXT=1 forces that everywhere; multic nodes always do), line filters
+ * included.  No file is written and no process started.  Nodes whose children are finished are evaluated together: their multiz runs are
  * prepared (mz_multiz_prepare), then ALL their pending block-pair alignments go to the GPU as one batch per wave
  * (mz_multiz_align) -- the per-tree-level batch of BASELINE config 4 -- and each run is replayed into its node.
  *
@@ -34,7 +38,13 @@ typedef struct rnode {
     int id;                      /* -1 for a leaf, else the stock driver's node number (creation order) */
     int left, right;             /* children (indices into the node table), -1 for a leaf */
     char **names; int nnames;    /* leaf species below this node, in the stock driver's order */
-    buf mz;                      /* the node's result: the file <prefix>MZ<id> of the stock driver */
+    buf mz;                      /* the node's result: the file <prefix>MZ<id> of the stock driver -- as text ... */
+    struct mafAli *mzl;          /* ... or (mz_list) as the list of its blocks */
+    int mz_list;
+    int taint;                   /* a leaf file below has a line the stock chain's line filters would remove: text all the way up */
+    int as_lists;                /* this node's multiz run ends in lists */
+    struct mafAli *left_l, *right_l;       /* inputs that came as lists (left_is_l / right_is_l) */
+    int left_is_l, right_is_l;
     int done;
     /* a multiz step in flight */
     struct mz_mzrun *run;
@@ -47,6 +57,7 @@ static struct {
     rnode nd[MAX_NODES]; int nn;
     const char *ref, *suffix;
     int use_multic, radius, minw, verbose, execute;
+    int lists;                   /* blocks go from node to node as lists where the line filters allow it */
 } T;
 
 /* ------------------------------------------------------------------------------------------------ text "files" */
@@ -109,26 +120,89 @@ static buf leaf_file(const char *species)
 
 static void free_list(struct mafAli *l) { while (l) { struct mafAli *a = mz_pop_first(&l); mafAliFree(&a); } }
 
-/* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
-static buf project_text(const buf *in, const char *what)
+/* Would `grep -v maf` / `grep -v eof` remove a block line somewhere above this leaf?  A line of the file itself that contains one of
+ * the words (a species or contig name), or a row with an 'f' in it: rows are cut, squeezed and reverse-complemented on the way up,
+ * and both words need an 'f' ('f' is no nucleotide code and nothing complements to it). */
+static int leaf_taints(const buf *b, const char *species)
+{
+    const char *p = b->p, *end = b->p + b->n, *hook = getenv("MZ_ROAST_TAINT");
+    if (hook && strcmp(hook, species) == 0) return 1;       /* (test hook: the nodes above this leaf run on text, fed by lists from below) */
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const size_t len = nl ? (size_t)(nl - p) : (size_t)(end - p);
+        if (len && *p != '#') {
+            if (memmem(p, len, "maf", 3) || memmem(p, len, "eof", 3)) return 1;
+            if (*p == 's') {
+                const char *t = p + len;
+                while (t > p && t[-1] != ' ' && t[-1] != '\t') --t;
+                if (memchr(t, 'f', (size_t)(p + len - t))) return 1;
+            }
+        }
+        p += len + 1;
+    }
+    return 0;
+}
+
+static void list_append(struct mafAli **head, struct mafAli *more)
+{
+    while (*head) head = &(*head)->next;
+    *head = more;
+}
+
+/* a list as the text of the file it stands for (a node that runs on text above one that ran on lists) */
+static buf list_to_text(struct mafAli *list)
 {
     buf out = { NULL, 0, 0 };
-    struct mafAli *list, *a;
-    char *text; size_t len;
-    FILE *m;
-    if (!in->p) mz_fatalf("Cannot open %s.", what);
-    TIMED(2, list = mz_maf_read_mem(in->p, in->n, what));
+    struct mafAli *a;
+    FILE *m = open_memstream(&out.p, &out.n);
+    fprintf(m, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION);
+    for (a = list; a; a = a->next) mafWrite(m, a);
+    fclose(m);
+    out.cap = out.n + 1;
+    free_list(list);
+    return out;
+}
+
+/* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
+static buf project_list_text(struct mafAli *list, const char *what)
+{
+    buf out = { NULL, 0, 0 };
+    struct mafAli *a, **blocks;
+    char head[1400];
+    int n = 0, i, pieces, k;
+    buf *part;
     { const double t_ = mz_now_s(); list = mz_project_lists(list, T.ref, NULL); g_t[1] += mz_now_s() - t_; }
     { const double t_ = mz_now_s();
-    m = open_memstream(&text, &len);
-    fprintf(m, "##maf version=1 scoring=maf_project.v12\n# maf_project.v12 %s %s (in process)\n", what, T.ref);
-    for (a = list; a; a = a->next) mafWrite(m, a);
-    fprintf(m, "##eof maf\n");
-    fclose(m);
+    /* the blocks rendered in pieces side by side (the destination of a guide-tree run is hundreds of thousands of blocks) */
+    for (a = list; a; a = a->next) ++n;
+    blocks = (struct mafAli **)mz_xmalloc(((size_t)n + 1) * sizeof *blocks);
+    for (a = list, n = 0; a; a = a->next) blocks[n++] = a;
+    pieces = n < 4096 ? 1 : MZ_STAGE_THREADS;
+    part = (buf *)mz_xmalloc((size_t)pieces * sizeof *part);
+#pragma omp parallel for schedule(static, 1) num_threads(MZ_STAGE_THREADS) if (pieces > 1)
+    for (k = 0; k < pieces; ++k) {
+        const int lo = (int)((long long)n * k / pieces), hi = (int)((long long)n * (k + 1) / pieces);
+        FILE *m = open_memstream(&part[k].p, &part[k].n);
+        int j;
+        for (j = lo; j < hi; ++j) mafWrite(m, blocks[j]);
+        fclose(m);
+    }
+    snprintf(head, sizeof head, "##maf version=1 scoring=maf_project.v12\n# maf_project.v12 %s %s (in process)\n", what, T.ref);
+    buf_puts(&out, head);
+    for (k = 0; k < pieces; ++k) { buf_append(&out, part[k].p, part[k].n); free(part[k].p); }
+    buf_puts(&out, "##eof maf\n");
+    free(part); free(blocks);
     free_list(list);
     g_t[5] += mz_now_s() - t_; }
-    out.p = text; out.n = len; out.cap = len + 1;
+    (void)i;
     return out;
+}
+static buf project_text(const buf *in, const char *what)
+{
+    struct mafAli *list;
+    if (!in->p) mz_fatalf("Cannot open %s.", what);
+    TIMED(2, list = mz_maf_read_mem(in->p, in->n, what));
+    return project_list_text(list, what);
 }
 
 /* ------------------------------------------------------------------------------------------------ the tree */
@@ -207,12 +281,16 @@ static void node_inputs(rnode *nd)
 {
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
     buf left = { NULL, 0, 0 }, right = { NULL, 0, 0 };
+    struct mafAli *left_l = NULL, *right_l = NULL;
+    int left_is_l = 0, right_is_l = 0;
 
-    if (x->id >= 0) { left = x->mz; x->mz.p = NULL; x->mz.n = x->mz.cap = 0; }          /* mv MZ<i> left.maf<id> */
-    if (y->id >= 0) { right = y->mz; y->mz.p = NULL; y->mz.n = y->mz.cap = 0; }
+    /* mv MZ<i> left.maf<id>: the child's result, text or list */
+    if (x->id >= 0) { left = x->mz; left_l = x->mzl; left_is_l = x->mz_list; memset(&x->mz, 0, sizeof x->mz); x->mzl = NULL; x->mz_list = 0; }
+    if (y->id >= 0) { right = y->mz; right_l = y->mzl; right_is_l = y->mz_list; memset(&y->mz, 0, sizeof y->mz); y->mzl = NULL; y->mz_list = 0; }
     buf_free(&nd->mz);
-    { char head[64]; snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head); }
-    nd->run = NULL; nd->l1 = nd->l2 = NULL; nd->both_leaves = 0;
+    nd->mzl = NULL; nd->mz_list = 0;
+    nd->run = NULL; nd->l1 = nd->l2 = NULL; nd->both_leaves = 0; nd->as_lists = 0;
+    nd->left_l = nd->right_l = NULL; nd->left_is_l = nd->right_is_l = 0;
     memset(&nd->left_in, 0, sizeof nd->left_in); memset(&nd->right_in, 0, sizeof nd->right_in);
 
     if (T.verbose) printf("node %d: %d + %d species\n", nd->id, x->nnames, y->nnames);
@@ -221,17 +299,39 @@ static void node_inputs(rnode *nd)
         const int ref_left = is_single(x, T.ref);
         rnode *other = ref_left ? y : x;
         buf *ob = ref_left ? &right : &left;
-        if (other->nnames == 1) { buf f = leaf_file(other->names[0]); append_lines_without(&nd->mz, &f, "eof"); buf_free(&f); }
-        else append_lines_without(&nd->mz, ob, "eof");
+        if (other->nnames == 1) {
+            buf f = leaf_file(other->names[0]);
+            char head[64];
+            nd->taint = leaf_taints(&f, other->names[0]);
+            snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head);
+            append_lines_without(&nd->mz, &f, "eof"); buf_free(&f);
+        } else if (ref_left ? right_is_l : left_is_l) {
+            nd->mzl = ref_left ? right_l : left_l; nd->mz_list = 1;       /* (grep -v eof finds the trailer only) */
+            if (ref_left) right_l = NULL; else left_l = NULL;
+            nd->taint = other->taint;
+        } else {
+            char head[64];
+            snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head);
+            append_lines_without(&nd->mz, ob, "eof");
+            nd->taint = other->taint;
+        }
         buf_free(&left); buf_free(&right);               /* rm -f: the closing greps of the parser find nothing */
+        free_list(left_l); free_list(right_l);
         nd->done = 1;
         return;
     }
-    if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); }
-    if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); }
-    if (!left.p) mz_fatalf("Cannot open %s.", "left.maf");
-    if (!right.p) mz_fatalf("Cannot open %s.", "right.maf");
+    if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); x->taint = leaf_taints(&left, x->names[0]); }
+    if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); y->taint = leaf_taints(&right, y->names[0]); }
+    if (!left.p && !left_is_l) mz_fatalf("Cannot open %s.", "left.maf");
+    if (!right.p && !right_is_l) mz_fatalf("Cannot open %s.", "right.maf");
+    nd->taint = x->taint || y->taint;
+    nd->as_lists = T.lists && !nd->taint;
+    if (!nd->as_lists) {                                 /* a node on text takes text */
+        if (left_is_l) { left = list_to_text(left_l); left_l = NULL; left_is_l = 0; }
+        if (right_is_l) { right = list_to_text(right_l); right_l = NULL; right_is_l = 0; }
+    }
     nd->left_in = left; nd->right_in = right;
+    nd->left_l = left_l; nd->right_l = right_l; nd->left_is_l = left_is_l; nd->right_is_l = right_is_l;
 }
 
 /* maf_project left REF > U1; mv U1 left (and the same on the right), then the aligner reads both: the projected
@@ -240,7 +340,11 @@ static void node_inputs(rnode *nd)
 static void node_parse(rnode *nd, int side)
 {
     buf *in = side ? &nd->right_in : &nd->left_in;
-    struct mafAli *l = mz_project_lists(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
+    struct mafAli *l;
+    if (side ? nd->right_is_l : nd->left_is_l) {
+        l = mz_project_lists(side ? nd->right_l : nd->left_l, T.ref, NULL);
+        if (side) nd->right_l = NULL; else nd->left_l = NULL;
+    } else l = mz_project_lists(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
     if (side) nd->l2 = l; else nd->l1 = l;
     buf_free(in);
 }
@@ -251,8 +355,39 @@ static void node_prepare(rnode *nd)
     const int l = has_ref(x), r = has_ref(y);
     if (!l && !r) nd->both_leaves = x->nnames == 1 && y->nnames == 1;
     else if (r) { struct mafAli *t = nd->l1; nd->l1 = nd->l2; nd->l2 = t; }
-    if (!T.use_multic)
+    if (!T.use_multic) {
         nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
+        if (nd->as_lists) mz_multiz_keep_blocks(nd->run);
+    }
+}
+
+/* the blocks of a list the stock driver would print (contigs only one side has), as their reader would hold them; the rest freed */
+static struct mafAli *printed_blocks(struct mafAli *l)
+{
+    struct mafAli *keep = NULL, **tail = &keep;
+    while (l) {
+        struct mafAli *a = mz_pop_first(&l);
+        if (row2 == 0 || a->components->next) { mz_ali_as_reread(a); *tail = a; tail = &a->next; }
+        else mafAliFree(&a);
+    }
+    return keep;
+}
+
+static void end_node_lists(rnode *nd)
+{
+    rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
+    struct mafAli *out = NULL, *u1 = NULL, *u2 = NULL;
+    mz_multiz_finish_lists(nd->run, &out, &u1, &u2);     /* stdout, U1, U2 of `multiz M=.. left right v U1 U2` */
+    nd->run = NULL;
+    list_append(&u1, printed_blocks(nd->l1));            /* contigs only one side has */
+    list_append(&u2, printed_blocks(nd->l2));
+    nd->l1 = nd->l2 = NULL;
+    if (nd->both_leaves || x->id >= 0 || y->id >= 0) {   /* >> MZ<id>: the unused parts follow (the line filters find nothing in them) */
+        list_append(&out, u1);
+        list_append(&out, u2);
+    } else { free_list(u1); free_list(u2); }
+    nd->mzl = out; nd->mz_list = 1;
+    nd->done = 1;
 }
 
 static void end_node(rnode *nd)
@@ -264,6 +399,8 @@ static void end_node(rnode *nd)
     struct mafAli *a;
 
     if (nd->done) return;
+    if (nd->as_lists) { end_node_lists(nd); return; }
+    { char head[64]; snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head); }
     mo = open_memstream(&out.p, &out.n); m1 = open_memstream(&u1.p, &u1.n); m2 = open_memstream(&u2.p, &u2.n);
     /* what `multiz M=.. left right v U1 U2` puts on stdout and into U1 / U2 (multiz.c:251-291) */
     fprintf(mo, "##maf version=1 scoring=%s\n# %s (in process, node %d)\n", T.use_multic ? "multih.c" : "multiz",
@@ -359,6 +496,7 @@ int mz_roast_main(int argc, char **argv)
     if (!T.ref) mz_fatalf("fatal -- reference is not specified.\n%s", usage);
     if (argc < 3) mz_fatalf("roast -- reference guided multiple alignment.\n%s", usage);
 
+    { const char *e = getenv("MZ_ROAST_TEXT"); T.lists = !T.use_multic && !(e && atoi(e) != 0); }
     mz_tune_malloc();
     init_scores70();
     mz_warm_start();                                     /* the GPU starts up while the inputs are read */
@@ -419,7 +557,7 @@ int mz_roast_main(int argc, char **argv)
     if (!dst) mz_fatalf("Cannot open %s.", destination);
     fprintf(dst, "##maf version=1 scoring=%s.%d\n%s\n", cmd, ROAST_VERSION, cmdline);
     {
-        buf fin = project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
+        buf fin = T.nd[root].mz_list ? project_list_text(T.nd[root].mzl, "MZ") : project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
         append_lines_without(&body, &fin, "eof");
         if (body.n) fwrite(body.p, 1, body.n, dst);
         buf_free(&fin); buf_free(&body);

@@ -125,8 +125,13 @@ def _stock_roast(tmp_path, tree, files, extra):
 @pytest.mark.parametrize("tree,extra", [("((ref mouse1) (rat1 dog1))", []), ("((ref mouse1) (rat1 dog1))", ["P=multic"]),
                                         ("((ref mouse1) (rat1 dog1))", ["R=12", "M=20"]),
                                         ("(((ref mouse1) (rat1 dog1)) ((cow1 pig1) (cat1 (bat1 fox1))))", []),
-                                        ("(mouse1 (rat1 (dog1 (cow1 ref))))", [])])
+                                        ("(mouse1 (rat1 (dog1 (cow1 ref))))", []),
+                                        ("(((ref mouse1) (rat1 dog1)) ((cow1 pig1) (cat1 (bat1 fox1))))", ["taint=cat1"])])
 def test_whole_alignment_matches_the_stock_roast(tmp_path, tree, extra):
+    # ("taint=<species>": MZ_ROAST_TAINT, the driver's test hook -- the nodes above that leaf run on MAF text with the stock chain's line
+    # filters, as they would for a species named "...maf...", and are handed lists by the subtrees below them)
+    env_extra = {"MZ_ROAST_TAINT": e[6:] for e in extra if e.startswith("taint=")}
+    extra = [e for e in extra if not e.startswith("taint=")]
     rng = np.random.default_rng(7 + len(tree) + len(extra))
     n = 25
     ref = inputs.ACGT[rng.integers(0, 4, size=n * 260 + 300)]
@@ -138,9 +143,14 @@ def test_whole_alignment_matches_the_stock_roast(tmp_path, tree, extra):
         files.append(f)
     want = _stock_roast(tmp_path, tree, files, extra)
     p = subprocess.run([ROAST] + extra + ["E=ref", tree] + files + [str(tmp_path / "ours.maf")], cwd=str(tmp_path),
-                       capture_output=True, timeout=900, env=dict(os.environ, MZ_TIMING="1"))
+                       capture_output=True, timeout=900, env=dict(os.environ, MZ_TIMING="1", **env_extra))
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     got = [l for l in open(str(tmp_path / "ours.maf")).read().split("\n") if not l.startswith("#")]
     assert sum(l.startswith("a score=") for l in want) >= 20
     assert got == want
     assert not any(f.startswith("_MZ_") for f in os.listdir(str(tmp_path)))          # no temporary files
+    # blocks go from node to node as lists (the default); MAF text between the nodes, as round 3 did, gives the same file
+    p = subprocess.run([ROAST] + extra + ["E=ref", tree] + files + [str(tmp_path / "ours_text.maf")], cwd=str(tmp_path),
+                       capture_output=True, timeout=900, env=dict(os.environ, MZ_ROAST_TEXT="1"))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert open(str(tmp_path / "ours_text.maf")).read().replace("ours_text.maf", "ours.maf") == open(str(tmp_path / "ours.maf")).read()
