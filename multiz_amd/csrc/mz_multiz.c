@@ -257,6 +257,81 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
 #undef WANTED
 }
 
+/* The walk of one contig in pieces, side by side.  Both lists are sorted by their start in the reference and cover it once, so
+ * wherever the next block of either list starts behind everything that came before in BOTH lists, the walk's state is "nothing in
+ * hand": what it records for the blocks in front of such a point does not depend on the blocks behind it (every comparison the loop
+ * makes with a block behind the point comes out as it does with no block at all), and the other way round.  The lists are cut at such
+ * points into a few dozen pieces of about equal size, every piece is walked into a record of its own (OpenMP; inside the tree driver's
+ * per-node loop this region is a nested one and runs on the calling thread), and the records are joined in order.  A list that is
+ * not sorted by start is walked in one piece, as ever. */
+#define WALK_PIECE_MIN 2048                                 /* blocks (both lists) below which a contig is not worth cutting */
+static void walk_contig(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int radius, int minw)
+{
+#define BEG(a) ((a)->components->start)
+#define END(a) ((a)->components->start + (a)->components->size - 1)
+    struct mafAli *a, **arr1, **arr2;
+    int n1 = 0, n2 = 0, i1, i2, npieces = 0, want, k, sorted = 1;
+    int *cut1, *cut2;
+    long long reach;
+    record *piece;
+    static int piece_min = 0;
+    if (!piece_min) { const char *e = getenv("MZ_WALK_PIECE_MIN"); piece_min = e && atoi(e) > 1 ? atoi(e) : WALK_PIECE_MIN; }   /* (tests: pieces of a few blocks) */
+    for (a = *wk1; a; a = a->next) ++n1;
+    for (a = *wk2; a; a = a->next) ++n2;
+    if (n1 + n2 < piece_min) { walk(R, wk1, wk2, v, radius, minw); return; }
+    arr1 = (struct mafAli **)mz_xmalloc(((size_t)n1 + 1) * sizeof *arr1);
+    arr2 = (struct mafAli **)mz_xmalloc(((size_t)n2 + 1) * sizeof *arr2);
+    for (a = *wk1, n1 = 0; a; a = a->next) { if (n1 && BEG(a) < BEG(arr1[n1 - 1])) sorted = 0; arr1[n1++] = a; }
+    for (a = *wk2, n2 = 0; a; a = a->next) { if (n2 && BEG(a) < BEG(arr2[n2 - 1])) sorted = 0; arr2[n2++] = a; }
+    want = (n1 + n2) / (piece_min / 2 > 0 ? piece_min / 2 : 1);
+    if (want > 4 * MZ_STAGE_THREADS) want = 4 * MZ_STAGE_THREADS;
+    if (!sorted || want < 2) { free(arr1); free(arr2); walk(R, wk1, wk2, v, radius, minw); return; }
+    cut1 = (int *)mz_xmalloc(((size_t)want + 2) * sizeof(int)); cut2 = (int *)mz_xmalloc(((size_t)want + 2) * sizeof(int));
+    /* the two lists in merged order; a piece may end in front of a block that starts behind `reach` */
+    cut1[0] = cut2[0] = 0; npieces = 1;
+    reach = -1;
+    for (i1 = i2 = 0; i1 < n1 || i2 < n2; ) {
+        const int take1 = i2 >= n2 || (i1 < n1 && BEG(arr1[i1]) <= BEG(arr2[i2]));
+        struct mafAli *b = take1 ? arr1[i1] : arr2[i2];
+        if ((i1 || i2) && (long long)BEG(b) > reach && npieces < want &&
+            (long long)(i1 + i2) * want >= (long long)npieces * (n1 + n2)) { cut1[npieces] = i1; cut2[npieces] = i2; ++npieces; }
+        if ((long long)END(b) > reach) reach = END(b);
+        if (take1) ++i1; else ++i2;
+    }
+    cut1[npieces] = n1; cut2[npieces] = n2;
+    if (npieces < 2) { free(arr1); free(arr2); free(cut1); free(cut2); walk(R, wk1, wk2, v, radius, minw); return; }
+    for (k = 1; k < npieces; ++k) {                         /* the lists, severed at the cuts */
+        if (cut1[k] > 0) arr1[cut1[k] - 1]->next = NULL;
+        if (cut2[k] > 0) arr2[cut2[k] - 1]->next = NULL;
+    }
+    piece = (record *)mz_xmalloc((size_t)npieces * sizeof *piece);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS)
+    for (k = 0; k < npieces; ++k) {
+        struct mafAli *l1 = cut1[k] < cut1[k + 1] ? arr1[cut1[k]] : NULL, *l2 = cut2[k] < cut2[k + 1] ? arr2[cut2[k]] : NULL;
+        memset(&piece[k], 0, sizeof piece[k]);
+        piece[k].has1 = R->has1; piece[k].has2 = R->has2; piece[k].keep_blocks = R->keep_blocks;
+        walk(&piece[k], &l1, &l2, v, radius, minw);
+    }
+    *wk1 = *wk2 = NULL;                                     /* (a walk takes every block of its lists) */
+    for (k = 0; k < npieces; ++k) {                         /* joined in order: event and merge numbers shift */
+        record *P = &piece[k];
+        const int ev0 = R->nev, mg0 = R->nmg;
+        int i;
+        if (R->nev + P->nev > R->capev) { R->capev = 2 * (R->nev + P->nev) + 256; R->ev = (event *)realloc(R->ev, (size_t)R->capev * sizeof(event)); if (!R->ev) mz_fatalf("out of memory"); }
+        if (R->nmg + P->nmg > R->capmg) { R->capmg = 2 * (R->nmg + P->nmg) + 256; R->mg = (merge *)realloc(R->mg, (size_t)R->capmg * sizeof(merge)); if (!R->mg) mz_fatalf("out of memory"); }
+        if (P->nev) memcpy(R->ev + ev0, P->ev, (size_t)P->nev * sizeof(event));
+        if (P->nmg) memcpy(R->mg + mg0, P->mg, (size_t)P->nmg * sizeof(merge));
+        for (i = 0; i < P->nev; ++i) if (R->ev[ev0 + i].job >= 0) R->ev[ev0 + i].job += mg0;
+        for (i = 0; i < P->nmg; ++i) R->mg[mg0 + i].side_ev += ev0;
+        R->nev += P->nev; R->nmg += P->nmg;
+        if (P->arena) { arena_chunk *t = P->arena; while (t->next) t = t->next; t->next = R->arena; R->arena = P->arena; }
+        free(P->ev); free(P->mg);
+    }
+    free(piece); free(arr1); free(arr2); free(cut1); free(cut2);
+#undef BEG
+#undef END
+}
+
 /* Stage 1 of every merge, then the pending yama() calls of all of them wave after wave.  The merges are
  * independent of one another, so everything on the host side of the yama() batches -- column packing,
  * rmColDash, the band walk and smooth() before, mafBuild() and mafScoreRange() after -- runs one merge per
@@ -313,41 +388,44 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
     mz_preout *outs;
     const char **ptrs;
     int *who, *cb1, *cb2, n = 0, i, rc;
-    size_t nptr = 0, at = 0;
+    size_t nptr = 0, *first;
     double t0 = mz_now_s(), t1;
-    for (i = 0; i < nmg; ++i) {
+    who = (int *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(int));
+    first = (size_t *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof *first);
+    for (i = 0; i < nmg; ++i) {                             /* the merges of this path, and where each one's row pointers start */
         merge *g = &all[i].R->mg[all[i].i];
         struct mafComp *c;
         if (!on_device(g)) continue;
-        ++n;
+        first[n] = nptr;
+        who[n++] = i;
         for (c = g->a1->components; c; c = c->next) ++nptr;
         for (c = g->a2->components; c; c = c->next) ++nptr;
     }
-    if (n == 0) return 1;
+    if (n == 0) { free(who); free(first); return 1; }
     jobs = (mz_prejob *)mz_xmalloc((size_t)n * sizeof *jobs);
     outs = (mz_preout *)mz_xmalloc((size_t)n * sizeof *outs);
-    who = (int *)mz_xmalloc((size_t)n * sizeof(int));
     cb1 = (int *)mz_xmalloc((size_t)n * sizeof(int)); cb2 = (int *)mz_xmalloc((size_t)n * sizeof(int));
     ptrs = (const char **)mz_xmalloc((nptr ? nptr : 1) * sizeof *ptrs);
-    for (i = 0, n = 0; i < nmg; ++i) {
-        merge *g = &all[i].R->mg[all[i].i];
+    /* the overlap's columns in both blocks (four scans of a top row each), a merge per thread */
+#pragma omp parallel for schedule(dynamic, 256) num_threads(MZ_STAGE_THREADS) if (n > 1024)
+    for (i = 0; i < n; ++i) {
+        merge *g = &all[who[i]].R->mg[all[who[i]].i];
         struct mafComp *c;
-        mz_prejob *j;
+        mz_prejob *j = &jobs[i];
+        size_t at = first[i];
         int ce1, ce2;
-        if (!on_device(g)) continue;
-        j = &jobs[n];
         j->v = g->v;
-        cb1[n] = mafPos2Col(g->a1->components, g->beg, g->a1->textSize);
+        cb1[i] = mafPos2Col(g->a1->components, g->beg, g->a1->textSize);
         ce1 = mafPos2Col(g->a1->components, g->end, g->a1->textSize);
-        cb2[n] = mafPos2Col(g->a2->components, g->beg, g->a2->textSize);
+        cb2[i] = mafPos2Col(g->a2->components, g->beg, g->a2->textSize);
         ce2 = mafPos2Col(g->a2->components, g->end, g->a2->textSize);
-        j->M_all = ce1 - cb1[n] + 1; j->N_all = ce2 - cb2[n] + 1; j->radius = g->radius;
+        j->M_all = ce1 - cb1[i] + 1; j->N_all = ce2 - cb2[i] + 1; j->radius = g->radius;
         j->rows1 = ptrs + at;
-        for (c = g->a1->components, j->K = 0; c; c = c->next, ++j->K) ptrs[at++] = c->text + cb1[n];
+        for (c = g->a1->components, j->K = 0; c; c = c->next, ++j->K) ptrs[at++] = c->text + cb1[i];
         j->rows2 = ptrs + at;
-        for (c = g->a2->components, j->L1 = 0; c; c = c->next, ++j->L1) ptrs[at++] = c->text + cb2[n];
-        who[n++] = i;
+        for (c = g->a2->components, j->L1 = 0; c; c = c->next, ++j->L1) ptrs[at++] = c->text + cb2[i];
     }
+    free(first);
     rc = mz_preyama_batch(n, jobs, outs);
     if (rc == -2) { free(jobs); free(outs); free(who); free(cb1); free(cb2); free(ptrs); return 0; }
     if (rc < 0) mz_fatalf("yama(gfx950): %s", mz_last_error());
@@ -560,7 +638,7 @@ struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2,
         mz_take_chr(list1, &wk1, chr);
         mz_take_chr(list2, &wk2, chr);
         free(chr);
-        walk(&run->R, &wk1, &wk2, v, radius, min_output_wid);
+        walk_contig(&run->R, &wk1, &wk2, v, radius, min_output_wid);
     }
     return run;
 }

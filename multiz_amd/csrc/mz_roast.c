@@ -164,7 +164,7 @@ static buf list_to_text(struct mafAli *list)
 }
 
 /* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
-static buf project_list_text(struct mafAli *list, const char *what)
+static buf project_list_text(struct mafAli *list, const char *what, int last)
 {
     buf out = { NULL, 0, 0 };
     struct mafAli *a, **blocks;
@@ -192,7 +192,7 @@ static buf project_list_text(struct mafAli *list, const char *what)
     for (k = 0; k < pieces; ++k) { buf_append(&out, part[k].p, part[k].n); free(part[k].p); }
     buf_puts(&out, "##eof maf\n");
     free(part); free(blocks);
-    free_list(list);
+    if (!last) free_list(list);                          /* (the destination's blocks: the process ends with them -- 13 M frees of a guide-tree run) */
     g_t[5] += mz_now_s() - t_; }
     (void)i;
     return out;
@@ -202,7 +202,7 @@ static buf project_text(const buf *in, const char *what)
     struct mafAli *list;
     if (!in->p) mz_fatalf("Cannot open %s.", what);
     TIMED(2, list = mz_maf_read_mem(in->p, in->n, what));
-    return project_list_text(list, what);
+    return project_list_text(list, what, 0);
 }
 
 /* ------------------------------------------------------------------------------------------------ the tree */
@@ -529,7 +529,8 @@ int mz_roast_main(int argc, char **argv)
               for (k = 0; k < 2 * ntodo; ++k) node_parse(&T.nd[todo[k >> 1]], k & 1);
               g_t[2] += mz_now_s() - t_; }
             { const double t_ = mz_now_s();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 1)
+              /* (a round of few nodes: one after the other, each walk cut into pieces that run side by side -- mz_multiz.c, walk_contig) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 4)
               for (k = 0; k < ntodo; ++k) node_prepare(&T.nd[todo[k]]);
               g_t[3] += mz_now_s() - t_; }
             for (k = 0; k < ntodo; ++k) if (T.nd[todo[k]].run) runs[nruns++] = T.nd[todo[k]].run;
@@ -557,7 +558,7 @@ int mz_roast_main(int argc, char **argv)
     if (!dst) mz_fatalf("Cannot open %s.", destination);
     fprintf(dst, "##maf version=1 scoring=%s.%d\n%s\n", cmd, ROAST_VERSION, cmdline);
     {
-        buf fin = T.nd[root].mz_list ? project_list_text(T.nd[root].mzl, "MZ") : project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
+        buf fin = T.nd[root].mz_list ? project_list_text(T.nd[root].mzl, "MZ", 1) : project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
         append_lines_without(&body, &fin, "eof");
         if (body.n) fwrite(body.p, 1, body.n, dst);
         buf_free(&fin); buf_free(&body);

@@ -19,11 +19,11 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not (os.path.exists(REF_BIN) and os.path.exists(OUR_BIN)), reason="binaries not built")]
 
 
-def run(binary, args, workdir, tag, outs):
+def run(binary, args, workdir, tag, outs, env=None):
     # the driver echoes its argv into the output header, so both runs get identical argument strings
     d = os.path.join(workdir, tag)
     os.makedirs(d)
-    p = subprocess.run([binary] + args, capture_output=True, timeout=600, cwd=d)
+    p = subprocess.run([binary] + args, capture_output=True, timeout=600, cwd=d, env=env)
     assert p.returncode in (0, 1), p.stderr.decode()[-2000:]
     # (a run that yama() ends with a fatal message must fail the same way, after the same partial output)
     return (p.stdout, p.returncode, p.stderr) + tuple(open(os.path.join(d, o), "rb").read() for o in outs)
@@ -32,6 +32,10 @@ def run(binary, args, workdir, tag, outs):
 def both(tmp_path, args, outs=()):
     want = run(REF_BIN, args, str(tmp_path), "ref", outs)
     got = run(OUR_BIN, args, str(tmp_path), "gpu", outs)
+    for w, g in zip(want, got):
+        assert g == w
+    # the list walk in pieces of a few blocks side by side (mz_multiz.c, walk_contig; by default only lists of thousands of blocks are cut)
+    got = run(OUR_BIN, args, str(tmp_path), "gpu_pieces", outs, env=dict(os.environ, MZ_WALK_PIECE_MIN="6"))
     for w, g in zip(want, got):
         assert g == w
     return want
