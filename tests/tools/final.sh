@@ -21,6 +21,8 @@ bash tests/tools/profile_pre.sh c2 ${TAG}_pre > $O/${TAG}_pre_profile_c2.txt 2>&
 MZ_CHUNKS=1 MZ_CHUNK_PAIRS=1000000 bash tests/tools/profile_pre.sh c2 ${TAG}_pre_alone > $O/${TAG}_pre_alone_profile_c2.txt 2>&1
 cp gpurun_out/${TAG}_pre_kernel_stats_c2_v*.csv gpurun_out/${TAG}_pre_alone_kernel_stats_c2_v*.csv $O/ 2>/dev/null
 python tests/tools/roast_bench.py > $O/${TAG}_roast_bench.txt 2>&1
+# the guide-tree-scale run of the tree driver (30 leaves, ~1.9 M merges): per-batch JSON lines and phase times
+timeout 900 python tests/tools/roast_big.py 30 9000 600 > $O/${TAG}_roast30.txt 2>&1
 python - "$O" "$TAG" <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json"))):
