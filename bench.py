@@ -620,7 +620,7 @@ def main():
     # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat: C5 as one batch)
     row_kernel = "k_dp_row_big" if big else "k_dp_row_lat" if 0 < nrow <= 2048 else "k_dp_row"
     dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
-                          (int(modes[:5].sum()), "k_dp"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
+                          (int(modes[:4].sum()), "k_dp"), (int(modes[4]), "k_dp_tstrip"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
 
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",

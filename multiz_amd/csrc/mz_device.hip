@@ -476,7 +476,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     int nk = 0, last = 0;
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
-        CK(hipMemsetAsync(&b->totals[16], 0, 4 * sizeof(int64_t), main_s), "dp counters");
+        CK(hipMemsetAsync(&b->totals[16], 0, 5 * sizeof(int64_t), main_s), "dp counters");
     DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
     // (one set of side streams and events per DEVICE: two host threads on one device -- the tests' MZ_ALLOW_DUP_DEVICES --
     // must not interleave their record / wait sequences; what a wait refers to is fixed when it is enqueued)
@@ -507,6 +507,7 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         else if (kinds[i] == MZ_DP_WIDE) {                // the second list: blocks of 128+ rows, and the rolling form with late starts
             hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
             hipLaunchKernelGGL(k_dp_roll, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
+            hipLaunchKernelGGL(k_dp_tstrip, dim3(grid_of(count, 5120, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
         }
         else
             hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), dyn_lds_lag, s, *b, first, count);
