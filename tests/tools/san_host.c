@@ -86,6 +86,90 @@ int main(void)
             free(a); free(b); free(scr); free(out); free(lb); free(rb);
         }
     }
+    /* the text path's host assembly (mz_assemble_rows): rows spread by one bit per merged column, squeezed by bits or by their own
+     * dashes, on exactly-sized heap blocks at every phase of a 64-column word */
+    {
+        typedef struct { const uint8_t *src; int n, squeeze; const uint64_t *keep, *ops; uint8_t *tmp; } rowspec;
+        void mz_assemble_rows(int nrows, const rowspec *rows, int om, uint8_t *out);
+        int om, r;
+        for (om = 1; om <= 300; om += (om < 70 ? 1 : 37)) {
+            enum { NR = 3 };
+            const int words = (om + 63) / 64, nsrc = om + 9;
+            uint64_t *ops = calloc((size_t)words, 8), *keep = calloc((size_t)(nsrc + 63) / 64, 8);
+            uint8_t *src[NR], *tmp[NR], *out = malloc((size_t)NR * om);
+            rowspec rows[NR];
+            int taken = 0, kept = 0, live = 0, c;
+            for (c = 0; c < om; ++c) if (c % 3 != 1) { ops[c >> 6] |= 1ULL << (c & 63); ++taken; }
+            for (r = 0; r < NR; ++r) { src[r] = malloc((size_t)nsrc); tmp[r] = malloc((size_t)nsrc + 16); }
+            /* row 0: its first `taken` bytes as they are; row 1: the bytes whose keep bit is set (exactly `taken` of them); row 2: its non-dash bytes */
+            for (c = 0; c < nsrc; ++c) {
+                src[0][c] = (uint8_t)('A' + c % 4);
+                src[1][c] = (uint8_t)('a' + c % 4);
+                if (kept < taken && c % 7 != 3) { keep[c >> 6] |= 1ULL << (c & 63); ++kept; }
+                src[2][c] = (live < taken && c % 5 != 2) ? (++live, (uint8_t)'G') : (uint8_t)'-';
+            }
+            if (kept != taken || live != taken) { fprintf(stderr, "bad row test\n"); return 1; }
+            rows[0].src = src[0]; rows[0].n = taken; rows[0].squeeze = 0; rows[0].keep = NULL; rows[0].ops = ops; rows[0].tmp = NULL;
+            rows[1].src = src[1]; rows[1].n = nsrc; rows[1].squeeze = 1; rows[1].keep = keep; rows[1].ops = ops; rows[1].tmp = tmp[1];
+            rows[2].src = src[2]; rows[2].n = nsrc; rows[2].squeeze = 2; rows[2].keep = NULL; rows[2].ops = ops; rows[2].tmp = tmp[2];
+            mz_assemble_rows(NR, rows, om, out);
+            for (c = 0; c < om; ++c) {
+                const int dash = c % 3 == 1;
+                if ((out[c] == '-') != dash || (out[om + c] == '-') != dash || (out[2 * om + c] == '-') != dash) { fprintf(stderr, "row assembly wrong at om %d column %d\n", om, c); return 1; }
+            }
+            sum += out[0] + out[(size_t)NR * om - 1];
+            for (r = 0; r < NR; ++r) { free(src[r]); free(tmp[r]); }
+            free(ops); free(keep); free(out);
+        }
+    }
+    /* link images (mz_link_pack / mz_link_assemble: host only): jobs -> image, a hand-made result image -> merged columns; an image that
+     * is too short or points outside itself is refused */
+    {
+        enum { NJ = 7 };
+        typedef struct { int32_t status, badrow, om, f[3]; int64_t off, cells; } res_rec;
+        mz_job jobs[NJ];
+        mz_out outs[NJ];
+        mz_link_desc d;
+        void *img = NULL, *exc = NULL;
+        uint8_t *res;
+        res_rec *rec;
+        size_t at = 0, scripts_at = 64 + ((sizeof(res_rec) * NJ + 255) & ~(size_t)255), bytes;
+        int j, m;
+        for (j = 0; j < NJ; ++j) {
+            const int K_ = 1 + j % 4, L_ = 1 + (j * 3) % 5, M_ = 30 + 9 * j, N_ = 41 + 5 * j;
+            uint8_t *a = malloc((size_t)K_ * M_), *b = malloc((size_t)L_ * N_);
+            int *lb = malloc(sizeof(int) * (M_ + 1)), *rb = malloc(sizeof(int) * (M_ + 1));
+            memset(a, "ACGT-n"[j % 6], (size_t)K_ * M_); memset(b, 't', (size_t)L_ * N_);
+            for (m = 0; m <= M_; ++m) { lb[m] = m > 12 ? m - 12 : 0; rb[m] = m + 12 + (j == 3 && m > 9 ? 40 : 0) + (j == 5 && m > 4 ? 700 : 0); if (rb[m] > N_ || m == M_) rb[m] = N_; }
+            jobs[j].K = K_; jobs[j].L = L_; jobs[j].M = M_; jobs[j].N = N_; jobs[j].A = a; jobs[j].B = b; jobs[j].LB = lb; jobs[j].RB = rb;
+        }
+        if (mz_link_pack(NJ, jobs, &d, &img, &exc) != 0 || d.n != NJ || !img) { fprintf(stderr, "mz_link_pack: %s\n", mz_last_error()); return 1; }
+        sum += ((uint8_t *)img)[0] + ((uint8_t *)img)[d.image_bytes - 1] + d.exc_bytes;
+        bytes = scripts_at + 64;
+        for (j = 0; j < NJ; ++j) bytes += (((size_t)(jobs[j].M + jobs[j].N) - 20 + 3) / 4 + 3) & ~(size_t)3;
+        res = calloc(bytes, 1);
+        rec = (res_rec *)(res + 64);
+        for (j = 0; j < NJ; ++j) {
+            const int om = jobs[j].M + jobs[j].N - 20;
+            int ia = 0, ib = 0;
+            rec[j].status = j == 2 ? MZ_E_NARROW : MZ_OK; rec[j].badrow = j == 2 ? 5 : -1; rec[j].om = j == 2 ? 0 : om; rec[j].off = (int64_t)at; rec[j].cells = 100;
+            for (m = 0; m < om; ++m) {
+                const unsigned op = (m < 20) ? 0u : (ia < jobs[j].M ? 2u : 1u);
+                res[scripts_at + at + (m >> 2)] |= (uint8_t)(op << (2 * (m & 3)));
+                ia += op != 1u; ib += op != 2u;
+            }
+            at += (((size_t)om + 3) / 4 + 3) & ~(size_t)3;
+        }
+        if (mz_link_assemble(NJ, jobs, res, (int64_t)bytes, outs) != 1) { fprintf(stderr, "mz_link_assemble: %s\n", mz_last_error()); return 1; }
+        for (j = 0; j < NJ; ++j) if (j != 2) sum += outs[j].cols[0] + outs[j].cols[(size_t)outs[j].OM * (jobs[j].K + jobs[j].L) - 1];
+        if (outs[2].status != MZ_E_NARROW || outs[2].cols) { fprintf(stderr, "a refused pair got columns\n"); return 1; }
+        mz_free_outs(NJ, outs);
+        if (mz_link_assemble(NJ, jobs, res, (int64_t)scripts_at - 8, outs) != -1) { fprintf(stderr, "a short image was accepted\n"); return 1; }
+        rec[4].off = (int64_t)bytes;
+        if (mz_link_assemble(NJ, jobs, res, (int64_t)bytes, outs) != -1) { fprintf(stderr, "an image that points outside itself was accepted\n"); return 1; }
+        free(res); mz_link_free(img); mz_link_free(exc);
+        for (j = 0; j < NJ; ++j) { free((void *)jobs[j].A); free((void *)jobs[j].B); free((void *)jobs[j].LB); free((void *)jobs[j].RB); }
+    }
     init_scores70(); init_scores85(); init_scores70();
     printf("san host ok %lld\n", sum);
     return 0;
