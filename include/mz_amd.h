@@ -171,7 +171,8 @@ int  mz_init(int device);
 /* The same on several GPUs of the node (devices == NULL: GPUs first..first+ngpu-1, first = MZ_DEVICE in the
  * environment, default 0 -- the GPUs an environment-driven start opens); the first is the primary device, where
  * the device-resident API (mz_dev_*) runs.  mz_yama_batch() then deals a large batch out over all of them -- one host
- * thread, one set of streams and staging buffers per GPU, contiguous ranges of the job list balanced by band size;
+ * thread, one set of streams and staging buffers per GPU, the jobs dealt by weight in a snake so that every GPU gets the same mix
+ * of long and short pairs (mz_preyama_batch() deals its merges the same way, by text volume);
  * block pairs are independent, so there is no exchange between GPUs.  Without an explicit call the first use of the
  * library reads MZ_DEVICE (first GPU, default 0) and MZ_NGPU (count, default 1) from the environment, which is how
  * the drivers mz_multiz / mz_multic use a whole node. */

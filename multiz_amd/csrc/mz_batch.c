@@ -655,6 +655,37 @@ static double job_weight(const mz_job *j)
 /* bytes the last mz_yama_batch() call moved over the link, each way */
 static int64_t g_last_up, g_last_down;
 
+/* Work dealt over `use` GPUs by cost: the items are classed by weight in half octaves (a counting sort: no comparison sort of a
+ * million-item list) and dealt out from the heaviest class down in a snake (0..G-1, G-1..0, ...), as multiz_amd/shard.py deals a list
+ * over ranks: every GPU gets the same MIX -- a list that arrives long-pairs-first no longer gives the first GPU the few long pairs
+ * and the last all the short ones (contiguous ranges balance the total weight only).  owner[i]: the item's GPU; where[i]: its place in
+ * the GPU-major order (GPU d's items are [start[d], start[d] + cnt[d]), in their original order). */
+int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where, int *cnt, int *start)
+{
+    unsigned char *cls = (unsigned char *)malloc((size_t)(n ? n : 1));
+    int ccount[64], cstart[64], fill[MZ_MAX_DEV], pos, c, d, p;
+    if (!cls) return mzi_set_err("out of memory");
+    memset(ccount, 0, sizeof ccount);
+    for (p = 0; p < n; ++p) {                                /* half-octave class of the weight: 2 * log2 */
+        int e = 0;
+        const double m = frexp(weight[p] > 1.0 ? weight[p] : 1.0, &e);       /* w = m * 2^e, m in [0.5, 1) */
+        c = 2 * e + (m >= 0.70710678 ? 1 : 0);
+        cls[p] = (unsigned char)(c < 0 ? 0 : c > 63 ? 63 : c);
+        ccount[cls[p]]++;
+    }
+    for (c = 63, pos = 0; c >= 0; --c) { cstart[c] = pos; pos += ccount[c]; }     /* heaviest class first */
+    for (d = 0; d < use; ++d) cnt[d] = 0;
+    for (p = 0; p < n; ++p) {                                /* rank of the item in the sorted order -> its GPU, in a snake */
+        const int rank = cstart[cls[p]]++, rnd = rank / use, k = rank % use;
+        owner[p] = (rnd & 1) ? use - 1 - k : k;
+        cnt[owner[p]]++;
+    }
+    for (d = 0, pos = 0; d < use; ++d) { start[d] = fill[d] = pos; pos += cnt[d]; }
+    for (p = 0; p < n; ++p) where[p] = fill[owner[p]]++;
+    free(cls);
+    return 0;
+}
+
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
     static int env_pairs = -1;
@@ -704,41 +735,25 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
          * over its own PCIe link. */
         dev_task task[MZ_MAX_DEV];
         pthread_t th[MZ_MAX_DEV];
-        int d, started[MZ_MAX_DEV], cnt[MZ_MAX_DEV], fill[MZ_MAX_DEV];
+        int d, started[MZ_MAX_DEV], cnt[MZ_MAX_DEV], first[MZ_MAX_DEV];
         int *owner = (int *)malloc((size_t)n * sizeof *owner), *where = (int *)malloc((size_t)n * sizeof *where);
-        unsigned char *cls = (unsigned char *)malloc((size_t)n);
+        double *wt = (double *)malloc((size_t)n * sizeof *wt);
         mz_job *jbuf = (mz_job *)malloc((size_t)n * sizeof *jbuf);
         mz_out *obuf = (mz_out *)malloc((size_t)n * sizeof *obuf);
-        int ccount[64], cstart[64], pos, c;
-        if (!owner || !where || !cls || !jbuf || !obuf) {
-            free(owner); free(where); free(cls); free(jbuf); free(obuf);
+        if (!owner || !where || !wt || !jbuf || !obuf) {
+            free(owner); free(where); free(wt); free(jbuf); free(obuf);
             pthread_mutex_unlock(&g_big);
             return mzi_set_err("out of memory");
         }
-        memset(ccount, 0, sizeof ccount);
-        for (p = 0; p < n; ++p) {                            /* half-octave class of the weight: 2 * log2 */
-            const double w = job_weight(&jobs[p]);
-            int e = 0;
-            const double m = frexp(w > 1.0 ? w : 1.0, &e);   /* w = m * 2^e, m in [0.5, 1) */
-            c = 2 * e + (m >= 0.70710678 ? 1 : 0);
-            cls[p] = (unsigned char)(c < 0 ? 0 : c > 63 ? 63 : c);
-            ccount[cls[p]]++;
-        }
-        for (c = 63, pos = 0; c >= 0; --c) { cstart[c] = pos; pos += ccount[c]; }     /* heaviest class first */
-        memset(cnt, 0, sizeof cnt);
-        for (p = 0; p < n; ++p) {                            /* rank of the pair in the sorted order -> its GPU, in a snake */
-            const int rank = cstart[cls[p]]++, rnd = rank / use, k = rank % use;
-            owner[p] = (rnd & 1) ? use - 1 - k : k;
-            cnt[owner[p]]++;
-        }
-        for (d = 0, pos = 0; d < use; ++d) { fill[d] = pos; pos += cnt[d]; }
-        for (d = 0, pos = 0; d < use; ++d) {
-            task[d].X = &g_dev[d]; task[d].jobs = jbuf + pos; task[d].outs = obuf + pos;
+        for (p = 0; p < n; ++p) wt[p] = job_weight(&jobs[p]);
+        if (mzi_deal_snake(n, wt, use, owner, where, cnt, first)) { free(owner); free(where); free(wt); free(jbuf); free(obuf); pthread_mutex_unlock(&g_big); return -1; }
+        free(wt);
+        for (d = 0; d < use; ++d) {
+            task[d].X = &g_dev[d]; task[d].jobs = jbuf + first[d]; task[d].outs = obuf + first[d];
             task[d].n = cnt[d]; task[d].max_pairs = max_pairs; task[d].rc = 0; task[d].err[0] = 0; memset(&task[d].st, 0, sizeof task[d].st);
             g_dev[d].copy_threads = MZ_COPY_THREADS * 2 / use < 4 ? 4 : MZ_COPY_THREADS * 2 / use > MZ_COPY_THREADS ? MZ_COPY_THREADS : MZ_COPY_THREADS * 2 / use;
-            pos += cnt[d];
         }
-        for (p = 0; p < n; ++p) { where[p] = fill[owner[p]]++; jbuf[where[p]] = jobs[p]; obuf[where[p]] = outs[p]; }
+        for (p = 0; p < n; ++p) { jbuf[where[p]] = jobs[p]; obuf[where[p]] = outs[p]; }
         for (d = 1; d < use; ++d) {
             started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, dev_worker, &task[d]) == 0;
             if (!started[d] && task[d].n > 0) dev_worker(&task[d]);         /* no thread: do it here, after the others started */
@@ -754,7 +769,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
             g_dev[d].copy_threads = MZ_COPY_THREADS;
         }
         for (p = 0; p < n; ++p) outs[p] = obuf[where[p]];    /* (a chunk's result block hangs on its first pair: mz_free_outs() walks all n) */
-        free(owner); free(where); free(cls); free(jbuf); free(obuf);
+        free(owner); free(where); free(jbuf); free(obuf);
         hipSetDevice(G.device);
         if (rc >= 0) rc = failed;
     }

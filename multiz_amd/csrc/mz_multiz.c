@@ -274,8 +274,8 @@ static void walk_contig(record *R, struct mafAli **wk1, struct mafAli **wk2, int
     int *cut1, *cut2;
     long long reach;
     record *piece;
-    static int piece_min = 0;
-    if (!piece_min) { const char *e = getenv("MZ_WALK_PIECE_MIN"); piece_min = e && atoi(e) > 1 ? atoi(e) : WALK_PIECE_MIN; }   /* (tests: pieces of a few blocks) */
+    const char *pm = getenv("MZ_WALK_PIECE_MIN");           /* (tests: pieces of a few blocks; read per contig -- the tree driver walks several nodes' lists at once) */
+    const int piece_min = pm && atoi(pm) > 1 ? atoi(pm) : WALK_PIECE_MIN;
     for (a = *wk1; a; a = a->next) ++n1;
     for (a = *wk2; a; a = a->next) ++n2;
     if (n1 + n2 < piece_min) { walk(R, wk1, wk2, v, radius, minw); return; }

@@ -635,22 +635,28 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
     if (use == 1) {
         rc = mzi_pre_on_ctx(&G, n, jobs, outs, st);
     } else {
-        /* several GPUs: contiguous ranges of about equal text volume, one host thread per GPU (as mz_yama_batch) */
+        /* several GPUs: dealt by text volume in a snake over the GPUs (mzi_deal_snake, as mz_yama_batch: every GPU gets the same mix of
+         * large and small merges), each GPU's jobs in a list of its own, one host thread per GPU, results back at the jobs' places */
         pre_task task[MZ_MAX_DEV];
         pthread_t th[MZ_MAX_DEV];
-        double total = 0.0, acc = 0.0;
-        int d = 0, start = 0, started[MZ_MAX_DEV];
-        for (p = 0; p < n; ++p) total += (double)text_bytes(&jobs[p]);
-        for (p = 0; p < n && d < use; ++p) {
-            acc += (double)text_bytes(&jobs[p]);
-            if (d == use - 1) { p = n - 1; acc = total; }
-            if (acc >= total * (d + 1) / use || p == n - 1) {
-                task[d].X = &g_dev[d]; task[d].jobs = jobs + start; task[d].outs = outs + start;
-                task[d].n = p + 1 - start; task[d].rc = 0; task[d].err[0] = 0; memset(task[d].st, 0, sizeof task[d].st);
-                start = p + 1; ++d;
-            }
+        int d, started[MZ_MAX_DEV], cnt[MZ_MAX_DEV], first[MZ_MAX_DEV];
+        int *owner = (int *)malloc((size_t)n * sizeof *owner), *where = (int *)malloc((size_t)n * sizeof *where);
+        double *wt = (double *)malloc((size_t)n * sizeof *wt);
+        mz_prejob *jbuf = (mz_prejob *)malloc((size_t)n * sizeof *jbuf);
+        mz_preout *obuf = (mz_preout *)malloc((size_t)n * sizeof *obuf);
+        if (!owner || !where || !wt || !jbuf || !obuf) {
+            free(owner); free(where); free(wt); free(jbuf); free(obuf);
+            pthread_mutex_unlock(&g_big);
+            return mzi_set_err("out of memory");
         }
-        use = d;
+        for (p = 0; p < n; ++p) wt[p] = (double)text_bytes(&jobs[p]) * (jobs[p].v == 0 ? 2.0 : 1.0);
+        if (mzi_deal_snake(n, wt, use, owner, where, cnt, first)) { free(owner); free(where); free(wt); free(jbuf); free(obuf); pthread_mutex_unlock(&g_big); return -1; }
+        free(wt);
+        for (d = 0; d < use; ++d) {
+            task[d].X = &g_dev[d]; task[d].jobs = jbuf + first[d]; task[d].outs = obuf + first[d];
+            task[d].n = cnt[d]; task[d].rc = 0; task[d].err[0] = 0; memset(task[d].st, 0, sizeof task[d].st);
+        }
+        for (p = 0; p < n; ++p) { jbuf[where[p]] = jobs[p]; obuf[where[p]] = outs[p]; }
         for (d = 1; d < use; ++d) {
             started[d] = task[d].n > 0 && pthread_create(&th[d], NULL, pre_worker, &task[d]) == 0;
             if (!started[d] && task[d].n > 0) pre_worker(&task[d]);
@@ -664,6 +670,8 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
             else failed += task[d].rc;
             st[0] += task[d].st[0]; st[1] += task[d].st[1]; st[2] += task[d].st[2];
         }
+        for (p = 0; p < n; ++p) outs[p] = obuf[where[p]];    /* (a chunk's result block hangs on its first merge: mz_free_preouts() walks all n) */
+        free(owner); free(where); free(jbuf); free(obuf);
         hipSetDevice(G.device);
         if (rc >= 0) rc = failed;
     }
