@@ -126,7 +126,7 @@ typedef struct mz_dev_batch {
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
-                              [11] rows (K+L) of all valid pairs, [12] bytes of the packed outputs (host path), [16..20] work counters of k_dp / k_dp_wide / k_dp_lag / k_dp_roll / k_dp_tstrip, [32..95] the pair lists' totals per (kind, size class): 128 ints; MZ_TOTALS entries in all */
+                              [11] rows (K+L) of all valid pairs in bits 0..43 and the number of MZ_MODE_TSTRIP pairs from bit 44 up, [12] bytes of the packed outputs (host path), [16..20] work counters of k_dp / k_dp_wide / k_dp_lag / k_dp_roll / k_dp_tstrip, [32..95] the pair lists' totals per (kind, size class): 128 ints; MZ_TOTALS entries in all */
     int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other, each with the pairs of most cells first */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels and the plan: MZ_SCAN_AUX_BYTES(n) bytes (8 sums, then 128 ints of list counts, per 64 pairs; 16 x 12 ints per pair for batches of at most MZ_PLAN_FOLD_MAX pairs) */
     /* workspaces + results (device) */

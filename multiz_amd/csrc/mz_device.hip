@@ -32,6 +32,8 @@
 
 #define WAVE   64
 #define ROLL_VMAX 90            // kernels/roll.inc: the longest wait (in steps) of a row the rolling form with late starts admits
+#define MZ_ROWS_SUM(t11)     ((t11) & ((1LL << 44) - 1))      // totals[11]: rows (K+L) of all valid pairs ...
+#define MZ_TSTRIP_PAIRS(t11) ((t11) >> 44)                    // ... and the number of MZ_MODE_TSTRIP pairs (kernels/plan.inc, scan_load)
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each
 #define REC_DW 16           // dwords per staged row record
 // row-parallel kernel: prep layout of a pair (dwords): row records of rows 1..M+2 (dead beyond M), then (COL
@@ -505,9 +507,11 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         else if (kinds[i] == MZ_DP_WAVEFRONT)
             hipLaunchKernelGGL(k_dp, dim3(grid_of(count, 6144, b->dp_grid & 1023)), dim3(WAVE), dyn_lds, s, *b, first, count);
         else if (kinds[i] == MZ_DP_WIDE) {                // the second list: blocks of 128+ rows, and the rolling form with late starts
+            // (three kernels share the list and follow one another on this stream; one without pairs of its own leaves at once -- the
+            //  tagged strips first: theirs are the usual ones)
+            hipLaunchKernelGGL(k_dp_tstrip, dim3(grid_of(count, 5120, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
             hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
             hipLaunchKernelGGL(k_dp_roll, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
-            hipLaunchKernelGGL(k_dp_tstrip, dim3(grid_of(count, 5120, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
         }
         else
             hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), dyn_lds_lag, s, *b, first, count);
@@ -546,7 +550,7 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
 extern "C" int mz_walk_choice(int n, const int64_t *totals)
 {
     const long long ok = (long long)n - totals[3];
-    return (n > 16384 && totals[11] < 8 * (ok > 0 ? ok : 1)) ? MZ_WALK_CHASE : MZ_WALK_RUNS;
+    return (n > 16384 && MZ_ROWS_SUM(totals[11]) < 8 * (ok > 0 ? ok : 1)) ? MZ_WALK_CHASE : MZ_WALK_RUNS;
 }
 
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)
