@@ -68,7 +68,6 @@ typedef struct pack_ctx {
     uint32_t *esz;
 } pack_ctx;
 
-int mzi_pack_prefetch = 1;                  /* MZ_PACK_PREFETCH (read by the batch entry points before the pool's threads run) */
 static void pack_range(void *ctx, int lo, int hi)
 {
     const pack_ctx *q = (const pack_ctx *)ctx;
@@ -84,15 +83,10 @@ static void pack_range(void *ctx, int lo, int hi)
             const mz_job *nx = &q->jobs[p + 1];
             if (job_ok(nx)) {
                 int k;
-                /* (round 4: ALL of them, up to 8 KB of bounds and 4 KB of columns each -- four short streams per pair, every one on fresh
-                 *  pages, never get the hardware prefetchers up to speed: +30 % packing rate on an 8-core box, MZ_PACK_PREFETCH=0: the
-                 *  first 256 bytes of each as before) */
-                const int all = mzi_pack_prefetch;
-                const int nb = !all ? 256 : 4 * (nx->M + 1) < 8192 ? 4 * (nx->M + 1) : 8192;
-                const int na = !all ? 256 : nx->K * nx->M < 4096 ? nx->K * nx->M : 4096, nbb = !all ? 256 : nx->L * nx->N < 4096 ? nx->L * nx->N : 4096;
-                for (k = 0; k < nb; k += 64) { _mm_prefetch((const char *)nx->LB + k, _MM_HINT_T0); _mm_prefetch((const char *)nx->RB + k, _MM_HINT_T0); }
-                for (k = 0; k < na; k += 64) _mm_prefetch((const char *)nx->A + k, _MM_HINT_T0);
-                for (k = 0; k < nbb; k += 64) _mm_prefetch((const char *)nx->B + k, _MM_HINT_T0);
+                for (k = 0; k < 256; k += 64) {
+                    _mm_prefetch((const char *)nx->LB + k, _MM_HINT_T0); _mm_prefetch((const char *)nx->RB + k, _MM_HINT_T0);
+                    _mm_prefetch((const char *)nx->A + k, _MM_HINT_T0); _mm_prefetch((const char *)nx->B + k, _MM_HINT_T0);
+                }
             }
         }
         if (job_ok(j)) {
@@ -338,12 +332,9 @@ static void assemble_range(void *ctx, int lo, int hi)
         o->OM = r->om;
         o->score[0] = r->f[0]; o->score[1] = r->f[1]; o->score[2] = r->f[2];
         o->cols = q->block + q->where[p];
-        if (p + 1 < hi) {                                    /* (as in pack_range: the next pair's sources, all of them up to 4 KB each) */
-            const mz_job *nx = &q->jobs[p + 1];
-            const int na = !mzi_pack_prefetch ? 256 : nx->K * nx->M < 4096 ? nx->K * nx->M : 4096, nb = !mzi_pack_prefetch ? 256 : nx->L * nx->N < 4096 ? nx->L * nx->N : 4096;
+        if (p + 1 < hi) {                                    /* (as in pack_range: the next pair's sources) */
             int k;
-            for (k = 0; k < na; k += 64) _mm_prefetch((const char *)nx->A + k, _MM_HINT_T0);
-            for (k = 0; k < nb; k += 64) _mm_prefetch((const char *)nx->B + k, _MM_HINT_T0);
+            for (k = 0; k < 256; k += 64) { _mm_prefetch((const char *)q->jobs[p + 1].A + k, _MM_HINT_T0); _mm_prefetch((const char *)q->jobs[p + 1].B + k, _MM_HINT_T0); }
         }
         mz_assemble_cols(j->K, j->L, j->M, j->N, j->A, j->B, q->packed + r->off, r->om, o->cols);
     }
@@ -703,7 +694,6 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     double t_call = mzi_now_s();
     if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (g_timing < 0) g_timing = mzi_timing();
-    { const char *e = getenv("MZ_PACK_PREFETCH"); mzi_pack_prefetch = !(e && e[0] == '0'); }
     if (n <= 0) return 0;
     for (p = 0; outs && p < n; ++p) {                    /* "not computed" until a chunk says otherwise */
         outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL;

@@ -113,7 +113,6 @@ extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_
 MZ_INTERNAL int mzi_sync_scores(void);
 MZ_INTERNAL int mzi_timing(void);                       /* MZ_TIMING, parsed once: 0 quiet, 1 per call, 2 per chunk */
 MZ_INTERNAL void mzi_workers_stop(mz_ctx *X);           /* mz_batch.c: ctx_close() ends the context's helper threads */
-extern MZ_INTERNAL int mzi_pack_prefetch;               /* mz_batch.c: prefetch ALL of the next pair's arrays in the pack / assemble loops */
 MZ_INTERNAL int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where, int *cnt, int *start);    /* mz_batch.c */
 MZ_INTERNAL int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int64_t stats[3]);   /* mz_prebatch.c */
 

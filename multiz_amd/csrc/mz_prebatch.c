@@ -73,13 +73,7 @@ static void pack_text(void *ctx, int lo, int hi)
         const mz_prejob *j = &q->jobs[p];
         const size_t sA = row_stride(j->M_all), sB = row_stride(j->N_all);
         uint8_t *d = q->hTxt + q->hoT1[p] / 2;
-        if (p + 1 < hi) {                                    /* the next merge's rows: every line of every row (up to 2 KB a row), as mz_batch.c's packing */
-            const mz_prejob *nx = &q->jobs[p + 1];
-            const int la = !mzi_pack_prefetch ? 64 : nx->M_all < 2048 ? nx->M_all : 2048, lb = !mzi_pack_prefetch ? 64 : nx->N_all < 2048 ? nx->N_all : 2048;
-            int r, t;
-            for (r = 0; r < (mzi_pack_prefetch ? nx->K : 1); ++r) for (t = 0; t < la; t += 64) _mm_prefetch((const char *)nx->rows1[r] + t, _MM_HINT_T0);
-            for (r = 0; r < (mzi_pack_prefetch ? nx->L1 : 1); ++r) for (t = 0; t < lb; t += 64) _mm_prefetch((const char *)nx->rows2[r] + t, _MM_HINT_T0);
-        }
+        if (p + 1 < hi) { _mm_prefetch((const char *)q->jobs[p + 1].rows1[0], _MM_HINT_T0); _mm_prefetch((const char *)q->jobs[p + 1].rows2[0], _MM_HINT_T0); }
         for (k = 0; k < j->K; ++k, d += sA / 2) mz_pack_classes_stream((const uint8_t *)j->rows1[k], (size_t)j->M_all, d, sA / 2);
         for (k = 0; k < j->L1; ++k, d += sB / 2) mz_pack_classes_stream((const uint8_t *)j->rows2[k], (size_t)j->N_all, d, sB / 2);
     }
@@ -622,7 +616,6 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
     if (n <= 0) return 0;
     if (!jobs || !outs) return mzi_set_err("mz_preyama_batch: NULL jobs or outs");
     if (g_ptiming < 0) g_ptiming = mzi_timing();
-    { const char *e = getenv("MZ_PACK_PREFETCH"); mzi_pack_prefetch = !(e && e[0] == '0'); }
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
         if (j->K < 1 || j->L1 < 1 || j->M_all < 1 || j->N_all < 1 || !j->rows1 || !j->rows2)
