@@ -494,11 +494,15 @@ static void stage_l1(void *P) { stage_loop((ppipe *)P, ST_L1); }
 static void stage_l2(void *P) { stage_loop((ppipe *)P, ST_L2); }
 static void stage_col(void *P) { stage_loop((ppipe *)P, ST_COL); }
 
-static int pre_parts(void)
+/* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides): twelve, as mz_yama_batch() -- four when most of the merges are
+ * two-stage ones: a chunk of those goes through two plans and two sets of DP / walk / emit, every stage with its wait for the stage
+ * before, and fewer, larger chunks measured better (C2-shaped text, 50 000 two-stage merges, 4 / 6 / 8 / 12 / 16 pieces: 19.9 / 21.6 /
+ * 23.6 / 22.2 / 25.7 ms; one-stage merges: 10.0 / 9.9 / 10.4 / 9.6 / 11.1) */
+static int pre_parts(int n, int two_stage)
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 12; }
-    return v;
+    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
+    return v ? v : 2 * two_stage >= n ? 4 : 12;
 }
 
 #define PRE_MIN_CHUNK 1024
@@ -518,7 +522,7 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
 {
     ppipe *P;
     size_t max_bytes = 0;
-    int k = 0, up = 0, rc = 0, s, threaded, max_pairs;
+    int k = 0, up = 0, rc = 0, s, threaded, max_pairs, two_stage = 0, parts;
     static int env_pairs = -1;
 
     if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
@@ -537,12 +541,13 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
         if (X->ptime_ready && hipEventCreate(&P->ev0) == hipSuccess) hipEventRecord(P->ev0, X->stream);
         else X->ptime_ready = 0;
     }
-    for (s = 0; s < n; ++s) max_bytes += text_bytes(&jobs[s]);
-    max_bytes = max_bytes / (size_t)pre_parts() + 1;
+    for (s = 0; s < n; ++s) { max_bytes += text_bytes(&jobs[s]); two_stage += jobs[s].v == 0; }
+    parts = pre_parts(n, two_stage);
+    max_bytes = max_bytes / (size_t)parts + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
     {
-        const int per = (n + pre_parts() - 1) / pre_parts();
+        const int per = (n + parts - 1) / parts;
         max_pairs = env_pairs ? env_pairs : per < PRE_MIN_CHUNK ? PRE_MIN_CHUNK : per > 16384 ? 16384 : per;
     }
     threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes) < n && mzi_workers_start(X->pworker, 3) == 0;
