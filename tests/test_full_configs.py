@@ -128,3 +128,45 @@ def test_c1_two_100_block_mafs_literal(tmp_path, v):
     assert want[0].count(b"a score=") >= 60                  # most of the 100 + 100 blocks overlap and merge
     assert run(os.path.join(REF, "multiz_mzamd"), "dropin") == want
     assert run(os.path.join(ROOT, "multiz_amd", "mz_multiz"), "batched") == want
+
+
+@pytest.mark.parametrize("cfg,v", [("c2", 1), ("c2", 0), ("c4", 1)])
+def test_text_path_full_size(mz, cfg, v):
+    """mz_preyama_batch() -- block TEXT in, block rows out: what mz_multiz / mz_roast run every merge through -- at a BASELINE
+    configuration's full size (C2: 50 000 merges, one-stage and two-stage; C4: one GPU's 125 000).  Every merge: the status, and what
+    no aligner may change -- a merged row without its dashes IS its source row without its dashes, in the order mafBuild() keeps
+    (all of block 1, then block 2 below its reference row), the base counts are the rows' own, every row is OM columns long, no
+    merged column is all dashes.  A seeded sample of 1 000 merges against the compiled reference's pre_yama(): rows, counts, score."""
+    import bench
+    from multiz_amd import api, synth
+    c = synth.CONFIGS[cfg]
+    n = c["pairs"]
+    pb = synth.make_pre_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], events=c.get("indel", 0), v=v)
+    jobs, outs = pb["jobs"], pb["outs"]
+    api.preyama_batch_records(jobs, outs)
+    try:
+        assert (outs["status"] == 0).all()
+        if v == 0:
+            assert int((outs["stage"] == 2).sum()) >= n // 2            # the two-stage path really ran
+        step = 1 if n <= 50000 else 3                                  # (Python loop: every merge of C2, every third of C4's 125 000)
+        for i in range(0, n, step):
+            r1, r2 = synth.pre_rows_of(pb, i)
+            src = r1 + r2[1:]
+            rows, size = api.preout_rows(outs, i, len(src))
+            if rows is None:
+                assert int(outs["null_result"][i]) != 0, i
+                continue
+            om = int(outs["OM"][i])
+            cols_alive = np.zeros(om, dtype=bool)
+            for k, (t, s) in enumerate(zip(rows, src)):
+                assert len(t) == om
+                bases = t.replace(b"-", b"")
+                assert bases == s.replace(b"-", b""), (i, k)
+                assert int(size[k]) == len(bases), (i, k)
+                cols_alive |= np.frombuffer(t, dtype=np.uint8) != 0x2D
+            assert cols_alive.all(), i
+        idx = np.sort(np.random.default_rng(9).choice(n, size=1000, replace=False))
+        bad, what = bench.pre_check(pb, outs, idx, c["radius"])
+        assert bad == 0, f"{bad} of 1000 sampled merges differ from the {what}"
+    finally:
+        api.free_preouts(outs)
