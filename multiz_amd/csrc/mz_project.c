@@ -57,15 +57,18 @@ static struct mafComp *row_of(struct mafAli *a, const char *src)
 /* The same look-up behind a 15-bit hash of the source name, kept in the row's nameID (nothing in this library reads that field; 0 = not
  * computed yet; whoever rewrites a row's src -- mz_ali_as_reread() -- resets it): the fusion pass asks for every row of a block in its
  * neighbour, twice, and a guide-tree level is half a million blocks of up to thirty rows -- 2 s of string comparisons in a 9 s run. */
-static short src_hash(struct mafComp *c)
+static short src_hash(struct mafComp *c)                     /* (relaxed atomics: the long fusion pass asks from several threads, and two of them
+                                                               * may meet in a block at the border of their ranges -- with the same value) */
 {
-    if (c->nameID == 0) {
+    short v = __atomic_load_n(&c->nameID, __ATOMIC_RELAXED);
+    if (v == 0) {
         unsigned h = 2166136261u;
         const unsigned char *p;
         for (p = (const unsigned char *)c->src; *p; ++p) h = (h ^ *p) * 16777619u;
-        c->nameID = (short)(1 + ((h ^ (h >> 15)) % 32767u));
+        v = (short)(1 + ((h ^ (h >> 15)) % 32767u));
+        __atomic_store_n(&c->nameID, v, __ATOMIC_RELAXED);
     }
-    return c->nameID;
+    return v;
 }
 static struct mafComp *row_of_hashed(struct mafAli *a, struct mafComp *like)
 {
@@ -172,6 +175,38 @@ static void fuse_neighbours(struct mafAli *list)
         } else a = b;
 }
 
+/* The same pass over a long list, with the question "does b continue a" asked for every neighbouring pair of the list AS IT STANDS on
+ * all threads first (the answers only read the blocks: a guide-tree level is half a million blocks of up to thirty rows, all but a
+ * few thousand of the answers are no, and each costs a chase through both blocks' rows), and the fusions made in one pass after it.
+ * A fusion changes its left block, so the pair behind a fused one is asked again, there and then, as the plain pass would. */
+#define FUSE_PARALLEL_MIN 20000
+static void fuse_neighbours_long(struct mafAli *list)
+{
+    struct mafAli *a, *b, **arr;
+    unsigned char *yes;
+    int n = 0, i;
+    const char *e = getenv("MZ_FUSE_PARALLEL_MIN");         /* (tests: the long form on short lists) */
+    for (a = list; a; a = a->next) ++n;
+    if (n < (e && atoi(e) > 1 ? atoi(e) : FUSE_PARALLEL_MIN)) { fuse_neighbours(list); return; }
+    arr = (struct mafAli **)mz_xmalloc((size_t)n * sizeof *arr);
+    yes = (unsigned char *)mz_xmalloc((size_t)n);
+    for (a = list, i = 0; a; a = a->next) arr[i++] = a;
+#pragma omp parallel for schedule(static, 512) num_threads(MZ_STAGE_THREADS)
+    for (i = 0; i < n - 1; ++i) yes[i] = (unsigned char)continues(arr[i], arr[i + 1]);
+    yes[n - 1] = 0;
+    for (a = list, i = 0; (b = a->next) != NULL; ) {        /* a == arr[i] or a block that has grown by fusions; b == arr[i + 1] */
+        const int fuse = (a == arr[i]) ? yes[i] : continues(a, b);
+        ++i;
+        if (fuse) {
+            append_block(a, b);
+            a->next = b->next;
+            b->next = NULL;
+            mafAliFree(&b);
+        } else a = b;
+    }
+    free(arr); free(yes);
+}
+
 /* Project `all` (blocks in file order; consumed) onto `target` (a species name or a full source name).  Returns
  * the projected blocks in output order; blocks without a row of the target go to *others in file order (freed
  * when others == NULL). */
@@ -221,8 +256,8 @@ struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct m
         arr[n - 1].a->next = NULL;
         a = arr[0].a;
         free(arr);
-        fuse_neighbours(a);
-        fuse_neighbours(a);                              /* (the stock tool's second pass, maf_project.c:690-695) */
+        fuse_neighbours_long(a);
+        fuse_neighbours_long(a);                         /* (the stock tool's second pass, maf_project.c:690-695) */
         if (out_tail) out_tail->next = a; else out = a;
         for (out_tail = a; out_tail->next; out_tail = out_tail->next)
             ;

@@ -90,6 +90,11 @@ def test_projection_matches_the_stock_tool(tmp_path, seed):
     w, g = strip(want.stdout), strip(got.stdout)
     assert sum(l.startswith("a score=") for l in w) >= 30
     assert g == w
+    # the fusion pass in its long-list form (the answers for all neighbouring pairs first, on all threads; by default only lists of
+    # 20 000 blocks and more take it)
+    got = subprocess.run([ROAST, "--project", path, "ref"], capture_output=True, timeout=120, env=dict(os.environ, MZ_FUSE_PARALLEL_MIN="2"))
+    assert got.returncode == 0, got.stderr.decode()[-1000:]
+    assert strip(got.stdout) == w
 
 
 def test_tree_parse_errors_and_plan():

@@ -37,6 +37,10 @@ def test_projection_and_tree_parser(san, tmp_path):
         p = subprocess.run([os.path.join(san, "mz_roast"), "--project", path, "ref"], capture_output=True, timeout=300, env=ENV)
         assert p.returncode == 0 and p.stdout.count(b"a score=") > 30
         _clean(p)
+        q = subprocess.run([os.path.join(san, "mz_roast"), "--project", path, "ref"], capture_output=True, timeout=300,
+                           env=dict(ENV, MZ_FUSE_PARALLEL_MIN="2"))              # (the fusion pass's long-list form)
+        assert q.returncode == 0 and q.stdout == p.stdout
+        _clean(q)
     p = subprocess.run([os.path.join(san, "mz_roast"), "-", "E=ref", "(((ref a) (b c)) (d (e f)))", "x", "o.maf"], capture_output=True, timeout=60, env=ENV)
     assert p.returncode == 0
     _clean(p)
