@@ -29,16 +29,36 @@
 #include "mz_ctx.h"
 #include "mz_pack.h"
 
+struct asm_ctx;
+
 /* ------------------------------------------------------------------------------------------------ one chunk */
+
+typedef struct pack_ctx {
+    const mz_job *jobs;
+    const int64_t *hoA, *hoB;
+    int64_t *hoC;
+    uint8_t *hA, *hB, *hC, *hFmt, *hE;
+    int32_t *hLB0, *hRB0;                  /* (NULL: the caller has filled them in) */
+    uint32_t *esz;
+} pack_ctx;
 
 typedef struct chunk {
     mz_ctx *X;
-    int set, n, index;
+    int set, n, index, lane;               /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk) */
     const mz_job *jobs;
     mz_out *outs;
     mz_dev_batch b;
+    pack_ctx pc;
+    /* the staging block's device-side pointers that are not part of b */
+    const int32_t *dLen, *dLB0, *dRB0;
+    const int64_t *doC;
+    const uint8_t *dFmt, *dC, *dA;
+    size_t eA, eB;
+    /* the assembling (results_prepare / assemble_range) */
+    size_t *where;
+    struct asm_ctx *ac;
     int64_t in_bytes, exc_bytes, res_bytes, cells;
-    double t_pack0, t_pack1, t_launch0, t_launch1, t_launch2, t_col0, t_col1, t_col2;
+    double t_cut0, t_cut1, t_packed, t_send1, t_launch0, t_launch1, t_launch2, t_col0, t_col1, t_col2;
 } chunk;
 
 /* a job whose arrays the host may read: the packing loops run before the device's validity prologue (a NULL array is a
@@ -59,14 +79,6 @@ static int pack_grain(int n)
     const int g = n / (4 * mzi_pool_threads());
     return g < 1 ? 1 : g > 64 ? 64 : g;
 }
-
-typedef struct pack_ctx {
-    const mz_job *jobs;
-    const int64_t *hoA, *hoB;
-    int64_t *hoC;
-    uint8_t *hA, *hB, *hC, *hFmt, *hE;
-    uint32_t *esz;
-} pack_ctx;
 
 static void pack_range(void *ctx, int lo, int hi)
 {
@@ -89,6 +101,7 @@ static void pack_range(void *ctx, int lo, int hi)
                 }
             }
         }
+        if (q->hLB0) { const int ok = job_ok(j); q->hLB0[p] = ok ? j->LB[0] : 0; q->hRB0[p] = ok ? j->RB[0] : 0; }     /* (an invalid job: one dummy entry, LB[0] = RB[0] = 0) */
         if (job_ok(j)) {
             uint32_t steps;
             mz_pack_classes_stream(j->A, (size_t)j->K * j->M, q->hA + q->hoA[p] / 2, cols_padded(j->K, j->M) / 2);
@@ -121,14 +134,6 @@ static void pack_exceptions(void *ctx, int lo, int hi)
 static int g_timing = -1;                  /* mzi_timing(): 1 = one JSON line per call, 2 = and one per chunk (stderr) */
 #define TSTAMP(X, set, k, st) do { if (g_timing >= 2 && (X)->btime_ready) HIPCK(hipEventRecord((X)->btime[set][k], st)); } while (0)
 
-static int up_prio(void)                   /* MZ_UP_PRIO=1: upload + expansion + plan on a high-priority stream per set.  Off by default: measured
-                                            * on C2 it gains nothing -- a kernel of any priority waits for a DP wave to retire before it gets a slot */
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MZ_UP_PRIO"); v = e && e[0] == '1'; }
-    return v;
-}
-
 static int chunk_parts(void)               /* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides) */
 {
     static int v = -1;
@@ -136,48 +141,42 @@ static int chunk_parts(void)               /* pieces a GPU's share of a call is 
     return v;
 }
 
-static int chunk_upload(mz_ctx *X, chunk *c, int index, int set, int n, const mz_job *jobs, mz_out *outs)
+/* the chunk's streams (mz_ctx.h): front (staging block -> device, expansion, plan), DP, tail (walk, script packing, results -> host) */
+static hipStream_t chunk_front(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qf[c->index % c->X->nf]; }
+static hipStream_t chunk_dp(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qd[c->lane]; }
+static hipStream_t chunk_tail(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qt[c->index % c->X->nt]; }
+
+/* The calling thread: chunk `index` = the n jobs at `jobs`, laid out in buffer set `set`; its packing as a loop (*pack).
+ * One pinned staging block: [K L M N](int32 x n) [offA offB offBand](int64 x n) [bandLen LB0 RB0](int32 x n) offC(int64 x n)
+ * fmt(n), band steps, class nibbles of A, class nibbles of B -- every part at a multiple of 256 bytes. */
+static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, const mz_job *jobs, mz_out *outs, mz_ajob *pack)
 {
-    hipStream_t st;
     mz_dev_batch b;
-    size_t eA = 0, eB = 0, nband = 0, bytesC = 0, hdr, in_bytes, nexc = 0, bytesE = 0;
+    size_t eA = 0, eB = 0, nband = 0, bytesC = 0, nprep = 0, hdr, in_bytes;
     char *h, *d;
     int32_t *hK, *hL, *hM, *hN, *hLen, *hLB0, *hRB0;
-    const int32_t *dLen, *dLB0, *dRB0;
     int64_t *hoA, *hoB, *hoBand, *hoC;
-    const int64_t *doC;
     uint8_t *hFmt, *hC, *hA, *hB;
-    const uint8_t *dFmt, *dC, *dA;
-    uint32_t *esz;
     int p;
 
-    c->t_pack0 = mzi_now_s();
-    if (mzi_lazy_stream(&X->bstream[set])) return -1;
-    st = X->bstream[set];
-    if (up_prio()) {
-        if (!X->ustream[set]) {
-            int least = 0, greatest = 0;
-            HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPCK(hipStreamCreateWithPriority(&X->ustream[set], hipStreamNonBlocking, greatest));
-        }
-        st = X->ustream[set];
-    }
-    c->X = X; c->set = set; c->index = index; c->n = n; c->jobs = jobs; c->outs = outs;
-
+    c->t_cut0 = mzi_now_s();
+    c->X = X; c->set = set; c->index = index; c->lane = lane; c->n = n; c->jobs = jobs; c->outs = outs;
+    c->where = NULL; c->ac = NULL; c->cells = 0; c->exc_bytes = 0; c->res_bytes = 0;
     for (p = 0; p < n; ++p) {
         const mz_job *j = &jobs[p];
-        if (job_ok(j)) { eA += cols_padded(j->K, j->M); eB += cols_padded(j->L, j->N); nband += (size_t)j->M + 1; bytesC += band_slot(j->M); }
+        if (job_ok(j)) { eA += cols_padded(j->K, j->M); eB += cols_padded(j->L, j->N); nband += (size_t)j->M + 1; bytesC += band_slot(j->M); nprep += MZ_PREP_BOUND(j->N); }
         else { nband += 1; }
     }
-    /* one pinned staging block: [K L M N bandLen LB0 RB0](int32 x n) [offA offB offBand offC](int64 x n) fmt(n) band steps,
-     * class nibbles of A, class nibbles of B */
     hdr = mzi_al256(4 * (size_t)n) * 7 + mzi_al256(8 * (size_t)n) * 4 + mzi_al256((size_t)n);
     in_bytes = hdr + mzi_al256(bytesC) + mzi_al256(eA / 2) + mzi_al256(eB / 2);
-    esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *esz);
-    if (!esz) return mzi_set_err("out of memory");
+    free(c->pc.esz);
+    c->pc.esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *c->pc.esz);
+    if (!c->pc.esz) return mzi_set_err("out of memory");
     if (mzi_host_reserve(&X->h_in[set], in_bytes) || mzi_dev_reserve(&X->d_in[set], in_bytes) ||
         mzi_dev_reserve(&X->d_cols[set], 2 * (mzi_al256(eA / 2) + mzi_al256(eB / 2)) + 256) ||
-        mzi_dev_reserve(&X->d_band[set], 2 * mzi_al256(4 * nband))) { free(esz); return -1; }
+        mzi_dev_reserve(&X->d_band[set], 2 * mzi_al256(4 * nband)) ||
+        mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t)) ||
+        mzi_dev_reserve(&X->d_prep[set], 4 * nprep + 256)) return -1;
     h = (char *)X->h_in[set].p; d = (char *)X->d_in[set].p;
 
     memset(&b, 0, sizeof b);
@@ -190,12 +189,12 @@ static int chunk_upload(mz_ctx *X, chunk *c, int index, int set, int n, const mz
     SLICE(hM, int32_t, M, 4 * (size_t)n); SLICE(hN, int32_t, N, 4 * (size_t)n);
     SLICE(hoA, int64_t, offA, 8 * (size_t)n); SLICE(hoB, int64_t, offB, 8 * (size_t)n);
     SLICE(hoBand, int64_t, offBand, 8 * (size_t)n);
-    SLICE2(hLen, dLen, int32_t, 4 * (size_t)n);
-    SLICE2(hLB0, dLB0, int32_t, 4 * (size_t)n); SLICE2(hRB0, dRB0, int32_t, 4 * (size_t)n);
-    SLICE2(hoC, doC, int64_t, 8 * (size_t)n);
-    SLICE2(hFmt, dFmt, uint8_t, (size_t)n);
-    SLICE2(hC, dC, uint8_t, bytesC);
-    SLICE2(hA, dA, uint8_t, eA / 2);
+    SLICE2(hLen, c->dLen, int32_t, 4 * (size_t)n);
+    SLICE2(hLB0, c->dLB0, int32_t, 4 * (size_t)n); SLICE2(hRB0, c->dRB0, int32_t, 4 * (size_t)n);
+    SLICE2(hoC, c->doC, int64_t, 8 * (size_t)n);
+    SLICE2(hFmt, c->dFmt, uint8_t, (size_t)n);
+    SLICE2(hC, c->dC, uint8_t, bytesC);
+    SLICE2(hA, c->dA, uint8_t, eA / 2);
     hB = (uint8_t *)h;
 #undef SLICE
 #undef SLICE2
@@ -206,66 +205,77 @@ static int chunk_upload(mz_ctx *X, chunk *c, int index, int set, int n, const mz
     b.poolRB = (const int32_t *)((char *)X->d_band[set].p + mzi_al256(4 * nband));
     {
         size_t oa = 0, ob = 0, oband = 0, oc = 0;
-        for (p = 0; p < n; ++p) {                            /* offsets first ... */
+        for (p = 0; p < n; ++p) {
             const mz_job *j = &jobs[p];
             const int ok = job_ok(j);
             const int nul = !j->A || !j->B || !j->LB || !j->RB;                 /* (reported as MZ_E_SHAPE: the plan sees M = N = 0) */
             hK[p] = j->K; hL[p] = j->L; hM[p] = nul ? 0 : j->M; hN[p] = nul ? 0 : j->N;
             hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
-            hLen[p] = ok ? j->M + 1 : 1;
-            hLB0[p] = ok ? j->LB[0] : 0; hRB0[p] = ok ? j->RB[0] : 0;         /* (an invalid job: one dummy entry, LB[0] = RB[0] = 0) */
+            hLen[p] = ok ? j->M + 1 : 1;                                        /* (LB[0], RB[0]: pack_range -- the first touch of the pair's arrays is the pool's) */
             if (ok) { oa += cols_padded(j->K, j->M); ob += cols_padded(j->L, j->N); oband += (size_t)j->M + 1; oc += band_slot(j->M); }
             else { oband += 1; }
         }
     }
-    /* ... then the packing, on the host threads: byte classes two per byte (mz_pack_classes), band bounds a byte per row
-     * where every step is below 16 (the others are noted and sent apart, below) */
-    {
-        pack_ctx pc;
-        pc.jobs = jobs; pc.hoA = hoA; pc.hoB = hoB; pc.hoC = hoC; pc.hA = hA; pc.hB = hB; pc.hC = hC; pc.hFmt = hFmt; pc.esz = esz; pc.hE = NULL;
-        mzi_parallel_for(n, pack_grain(n), pack_range, &pc);
-    }
-    for (p = 0; p < n; ++p) if (esz[p]) { ++nexc; bytesE += esz[p]; }
-    if (nexc) {
-        size_t oe = 0;
-        uint8_t *hE;
-        if (mzi_host_reserve(&X->h_exc[set], bytesE) || mzi_dev_reserve(&X->d_exc[set], bytesE)) { free(esz); return -1; }
-        hE = (uint8_t *)X->h_exc[set].p;
-        for (p = 0; p < n; ++p) if (esz[p]) { hoC[p] = (int64_t)oe; oe += esz[p]; }
-        {
-            pack_ctx pc;
-            pc.jobs = jobs; pc.hoC = hoC; pc.hFmt = hFmt; pc.esz = esz; pc.hE = hE;
-            pc.hoA = pc.hoB = NULL; pc.hA = pc.hB = pc.hC = NULL;
-            mzi_parallel_for(n, pack_grain(n), pack_exceptions, &pc);
-        }
-    }
-    free(esz);
-    c->t_pack1 = mzi_now_s();
-    c->in_bytes = (int64_t)in_bytes; c->exc_bytes = (int64_t)bytesE;
-    TSTAMP(X, set, 0, st);
-    HIPCK(hipMemcpyAsync(X->d_in[set].p, X->h_in[set].p, in_bytes, hipMemcpyHostToDevice, st));
-    if (nexc) HIPCK(hipMemcpyAsync(X->d_exc[set].p, X->h_exc[set].p, bytesE, hipMemcpyHostToDevice, st));
-    if (mzk_unband(n, dLen, dLB0, dRB0, b.offBand, doC, dFmt, dC, (const uint8_t *)X->d_exc[set].p, (int32_t *)b.poolLB, (int32_t *)b.poolRB, st) ||
-        mzk_unnib(dA, (void *)b.poolA, (long long)(2 * (mzi_al256(eA / 2) + mzi_al256(eB / 2))), st))
-        return mzi_set_err("%s", mzk_last_error());
-    TSTAMP(X, set, 1, st);
-
-    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
     mz_dev_carve(&b, X->d_plan[set].p);
-    b.capTb = b.capScript = b.capOut = b.capPrep = INT64_MAX;   /* sizes are not known yet */
-    if (mzk_plan(&b, st)) return mzi_set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(X->h_tot[set].p, b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    TSTAMP(X, set, 2, st);
-    HIPCK(hipEventRecord(X->bplan[set], st));
-    c->b = b;
+    b.capTb = b.capScript = b.capOut = INT64_MAX;               /* sizes are not known yet -- except the prep records': at most MZ_PREP_BOUND(N) */
+    b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);      /* dwords per pair, so they are made with the plan (chunk_send) */
+    c->b = b; c->eA = eA; c->eB = eB; c->in_bytes = (int64_t)in_bytes;
+    /* the packing, for the pool's threads: byte classes two per byte (mz_pack_classes), band bounds a byte per row where every
+     * step is below 16 (the others are noted and sent apart: chunk_send) */
+    c->pc.jobs = jobs; c->pc.hoA = hoA; c->pc.hoB = hoB; c->pc.hoC = hoC; c->pc.hA = hA; c->pc.hB = hB; c->pc.hC = hC; c->pc.hFmt = hFmt; c->pc.hE = NULL;
+    c->pc.hLB0 = hLB0; c->pc.hRB0 = hRB0;
+    pack->fn = pack_range; pack->ctx = &c->pc; pack->n = n; pack->grain = pack_grain(n);
+    c->t_cut1 = mzi_now_s();
     return 0;
 }
 
+/* stage 1: the chunk is packed -- the bands that do not fit a nibble per step, then staging block -> device (a kernel on the chunk's
+ * stream: mzk_link_copy), expansion, plan, the plan's totals -> host */
+static int chunk_send(chunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set, n = c->n;
+    hipStream_t st = chunk_front(c);
+    const mz_dev_batch *b = &c->b;
+    size_t nexc = 0, bytesE = 0;
+    int p;
+
+    c->t_packed = mzi_now_s();
+    for (p = 0; p < n; ++p) if (c->pc.esz[p]) { ++nexc; bytesE += c->pc.esz[p]; }
+    if (nexc) {
+        size_t oe = 0;
+        bytesE = (bytesE + 15) & ~(size_t)15;
+        if (mzi_host_reserve(&X->h_exc[set], bytesE) || mzi_dev_reserve(&X->d_exc[set], bytesE)) return -1;
+        for (p = 0; p < n; ++p) if (c->pc.esz[p]) { c->pc.hoC[p] = (int64_t)oe; oe += c->pc.esz[p]; }
+        c->pc.hE = (uint8_t *)X->h_exc[set].p;
+        mzi_parallel_for(n, pack_grain(n), pack_exceptions, &c->pc);
+    }
+    c->exc_bytes = (int64_t)bytesE;
+    TSTAMP(X, set, 0, st);
+    if (mzk_link_copy(X->d_in[set].p, X->h_in[set].p, mzi_al256((size_t)c->in_bytes), st) ||
+        (nexc && mzk_link_copy(X->d_exc[set].p, X->h_exc[set].p, bytesE, st)) ||
+        mzk_unband(n, c->dLen, c->dLB0, c->dRB0, b->offBand, c->doC, c->dFmt, c->dC, (const uint8_t *)X->d_exc[set].p, (int32_t *)b->poolLB, (int32_t *)b->poolRB, st) ||
+        mzk_unnib(c->dA, (void *)b->poolA, (long long)(2 * (mzi_al256(c->eA / 2) + mzi_al256(c->eB / 2))), st))
+        return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 1, st);
+    /* the totals go home before the prep records are made: the launcher can size the workspaces meanwhile */
+    if (mzk_plan(b, st) || mzk_link_copy(X->h_tot[set].p, b->totals, 16 * sizeof(int64_t), st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(X->bplan[set], st));
+    if (mzk_prep(b, st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(X->bprep[set], st));
+    TSTAMP(X, set, 2, st);
+    c->t_send1 = mzi_now_s();
+    return 0;
+}
+
+/* stage 2: wait for the plan's totals, size the workspaces; the DP on the slot's DP stream (the plan is through -- the host has
+ * seen its totals -- so nothing there has to wait for the front stream), walk / script packing / results -> host on the tail stream
+ * behind the DP's event */
 static int chunk_launch(chunk *c)
 {
     mz_ctx *X = c->X;
     const int set = c->set, n = c->n;
-    hipStream_t st = X->bstream[set];
+    hipStream_t sd = chunk_dp(c), st = chunk_tail(c);
     mz_dev_batch b = c->b;
     const int64_t *totals = (const int64_t *)X->h_tot[set].p;
     size_t res_bytes;
@@ -273,31 +283,31 @@ static int chunk_launch(chunk *c)
 
     c->t_launch0 = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bplan[set]));
-    if (up_prio()) HIPCK(hipStreamWaitEvent(st, X->bplan[set], 0));     /* (this stream's kernels read what the upload stream produced) */
     c->t_launch1 = mzi_now_s();
 
     /* results: 64-byte header, a record per pair, the scripts at a quarter of the plan's script slices */
-    res_bytes = 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n) + (size_t)totals[1] / 4 + 64;
+    res_bytes = mzi_al256(64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n) + (size_t)totals[1] / 4 + 64);
     if (mzi_dev_reserve(&X->d_tb[set], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[set], (size_t)totals[1] + 256) ||
-        mzi_dev_reserve(&X->d_prep[set], 4 * (size_t)totals[4] + 256) || mzi_dev_reserve(&X->d_res[set], res_bytes) ||
-        mzi_host_reserve(&X->h_res[set], res_bytes))
+        mzi_dev_reserve(&X->d_res[set], res_bytes) || mzi_host_reserve(&X->h_res[set], res_bytes))
         return -1;
     b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = NULL;     /* (no merged columns on the device) */
-    b.prep = (uint32_t *)X->d_prep[set].p; b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
     b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
     b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
     b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
 
     dres = (char *)X->d_res[set].p;
-    if (mzk_prep(&b, st) || mzk_dp(&b, st)) return mzi_set_err("%s", mzk_last_error());
-    TSTAMP(X, set, 3, st);
+    if (sd != chunk_front(c)) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));      /* (the prep records: behind the plan on the front stream) */
+    if (mzk_dp_range_on(&b, 0, n, sd, c->lane < 0 ? NULL : &X->qlane[c->lane])) return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 3, sd);
+    if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
     if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
         return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 4, st);
-    /* The copy of the results is NOT issued here: the copy engine takes its commands in order, and a copy that has to wait
-     * for this chunk's kernels holds up the uploads of the chunks behind it (round 4: the H2D of chunk k+3 started when the
-     * results of chunk k were through).  The collector issues it once the chunk's last kernel is done. */
+    /* the results go home as the chunk's last kernel: no copy engine, nothing that could wait for anything but this chunk's
+     * own kernels */
+    if (mzk_link_copy(X->h_res[set].p, dres, res_bytes, st)) return mzi_set_err("%s", mzk_last_error());
+    TSTAMP(X, set, 5, st);
     HIPCK(hipEventRecord(X->bdone[set], st));
     c->b = b; c->res_bytes = (int64_t)res_bytes;
     c->t_launch2 = mzi_now_s();
@@ -343,26 +353,46 @@ static void assemble_range(void *ctx, int lo, int hi)
     _mm_sfence();
 }
 
+/* Does the 2-bit script of `om` columns take exactly M columns of A and N of B?  (C = 0 takes both, I = 1 one of B, D = 2 one of A;
+ * 3 is no operation of the reference, mz_yama.c:24-26.)  The device checks its own scripts (MZ_E_EMIT); an image that arrives from
+ * somewhere else -- another rank's, over the wire -- is only as good as this. */
+static int script_fits(const uint8_t *s, int om, int M, int N)
+{
+    long a = 0, b = 0;
+    int m;
+    for (m = 0; m < om; ++m) {
+        const unsigned op = (s[m >> 2] >> (2 * (m & 3))) & 3u;
+        if (op == 3u) return 0;
+        a += op != 1u; b += op != 2u;
+    }
+    return a == M && b == N;
+}
+
 /* outs[] of n jobs from their result image in host memory (64-byte header, a record per pair, the packed scripts): ONE block for the
  * merged columns, assembled on the pool threads from the caller's own A and B.  `limit`: bytes of the image when it came from
- * somewhere else (a link image: every record is checked against it), 0 for the pipeline's own. */
-static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, int64_t *cells)
+ * somewhere else (a link image: every record AND every script is checked against the jobs), 0 for the pipeline's own.
+ * results_prepare(): the block and where every pair's columns go (*ac for assemble_range over [0, n)); results_close(): what hangs
+ * on outs[0] afterwards; returns the failed pairs. */
+static int results_prepare(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, asm_ctx *ac, size_t **where_out)
 {
     const mz_res_rec *rec = (const mz_res_rec *)(r + 64);
     const size_t scripts_at = 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n);
     const uint8_t *packed = (const uint8_t *)r + scripts_at;
     size_t *where, total = 0;
     uint8_t *block = NULL;
-    int p, failed = 0;
+    int p;
 
+    *where_out = NULL;
     if (limit) {
         if (limit < scripts_at) return mzi_set_err("result image of %zu bytes is too short for %d pairs", limit, n);
         for (p = 0; p < n; ++p) {
             const mz_res_rec *q = &rec[p];
             if (q->status != MZ_OK) continue;
-            if (q->om < 0 || (int64_t)q->om > (int64_t)jobs[p].M + jobs[p].N || q->off < 0 ||
+            if (!job_ok(&jobs[p]) || q->om < 0 || (int64_t)q->om > (int64_t)jobs[p].M + jobs[p].N || q->off < 0 ||
                 scripts_at + (size_t)q->off + ((size_t)q->om + 3) / 4 > limit)
                 return mzi_set_err("result image does not belong to these jobs (pair %d: %d columns at %lld)", p, q->om, (long long)q->off);
+            if (!script_fits(packed + q->off, q->om, jobs[p].M, jobs[p].N))
+                return mzi_set_err("result image does not belong to these jobs (pair %d: its script does not take %d columns of A and %d of B)", p, jobs[p].M, jobs[p].N);
         }
     }
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
@@ -384,147 +414,84 @@ static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char 
             at = ((at + mis + 63) & ~(size_t)63) - mis;      /* the next pair's first byte at a multiple of 64 */
         }
     }
-    {
-        asm_ctx ac;
-        ac.jobs = jobs; ac.outs = outs; ac.rec = rec; ac.packed = packed; ac.where = where; ac.block = block; ac.failed = 0; ac.cells = 0;
-        mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
-        failed = ac.failed;
-        *cells = ac.cells;
-    }
-    outs[0].block = block;
-    free(where);
-    return failed;
+    ac->jobs = jobs; ac->outs = outs; ac->rec = rec; ac->packed = packed; ac->where = where; ac->block = block; ac->failed = 0; ac->cells = 0;
+    *where_out = where;
+    return 0;
 }
 
-static int chunk_collect(chunk *c)
+static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, int64_t *cells)
+{
+    asm_ctx ac;
+    size_t *where;
+    if (results_prepare(n, jobs, outs, r, limit, &ac, &where) < 0) return -1;
+    mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
+    outs[0].block = ac.block;
+    *cells = ac.cells;
+    free(where);
+    return ac.failed;
+}
+
+/* stage 3: wait for the chunk's last kernel (the results are in host memory then), lay the merged columns' block out; the
+ * assembling itself is the loop *post */
+static int chunk_collect(chunk *c, mz_ajob *post)
 {
     mz_ctx *X = c->X;
     const int set = c->set;
-    int failed;
 
     c->t_col0 = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bdone[set]));
-    HIPCK(hipMemcpyAsync(X->h_res[set].p, X->d_res[set].p, (size_t)c->res_bytes, hipMemcpyDeviceToHost, X->bstream[set]));
-    TSTAMP(X, set, 5, X->bstream[set]);
-    HIPCK(hipStreamSynchronize(X->bstream[set]));
     c->t_col1 = mzi_now_s();
-    failed = results_assemble(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, &c->cells);
-    c->t_col2 = mzi_now_s();
-    return failed;
+    if (!c->ac && !(c->ac = (asm_ctx *)malloc(sizeof *c->ac))) return mzi_set_err("out of memory");
+    if (results_prepare(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, c->ac, &c->where) < 0) return -1;
+    post->fn = assemble_range; post->ctx = c->ac; post->n = c->n; post->grain = pack_grain(c->n);
+    return 0;
 }
 
-/* ------------------------------------------------------------------------------------------------ the pipeline */
+static int chunk_finish(chunk *c)
+{
+    c->outs[0].block = c->ac->block;
+    c->cells = c->ac->cells;
+    free(c->where); c->where = NULL;
+    c->t_col2 = mzi_now_s();
+    return c->ac->failed;
+}
 
-typedef struct mz_pipe {
-    mz_ctx *X;
-    int n, max_pairs;
-    const mz_job *jobs;
-    mz_out *outs;
-    chunk ck[MZ_SETS];
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    int uploaded, launched, collected;     /* chunks through each stage */
-    int total;                             /* chunks in all; -1 until the packer has cut the last one */
-    int failed, rc, done;
-    int64_t cells, bytes_up, bytes_down;   /* of the chunks collected so far */
-    double t0;
-    hipEvent_t ev0;                        /* MZ_TIMING=2: recorded on the first set's stream when the call starts */
-    char err[600];
-} mz_pipe;
+/* ------------------------------------------------------------------------------------------------ the pipeline (mz_flow.c) */
 
 typedef struct batch_stats { int64_t cells, bytes_up, bytes_down; } batch_stats;
 
-static void pipe_abort(mz_pipe *P)
-{
-    pthread_mutex_lock(&P->mu);
-    if (P->rc >= 0) { P->rc = -1; snprintf(P->err, sizeof P->err, "%s", mz_last_error()); }
-    pthread_cond_broadcast(&P->cv);
-    pthread_mutex_unlock(&P->mu);
-}
+typedef struct ypipe {
+    mz_ctx *X;
+    int n, up, max_pairs, threaded;
+    size_t max_bytes;
+    const mz_job *jobs;
+    mz_out *outs;
+    chunk ck[MZ_SETS];
+    batch_stats st;
+    pthread_mutex_t mu;                    /* st, the report lines */
+    double t0;
+    hipEvent_t ev0;                        /* MZ_TIMING=2: recorded on the context's stream when the call starts */
+} ypipe;
 
-static void pipe_count(mz_pipe *P, const chunk *c)
-{
-    P->cells += c->cells; P->bytes_up += c->in_bytes + c->exc_bytes; P->bytes_down += c->res_bytes;
-}
-
-static void chunk_report(const mz_pipe *P, const chunk *c)
+static void chunk_report(const ypipe *P, const chunk *c)
 {
     float g[5] = { 0, 0, 0, 0, 0 }, since0 = 0;
     int k;
     if (g_timing < 2) return;
     if (c->X->btime_ready) {
-        /* GPU time stamps of this chunk's stream: H2D + expansion, plan, (wait for the host) prep + DP, walk + script packing, D2H;
-         * `gpu_start_ms` is the chunk's first stamp against chunk 0's of set 0 (the same clock only roughly: sets differ) */
+        /* GPU time stamps of this chunk's stream: staging block -> device + expansion, plan, (wait for the host) prep + DP, walk + script
+         * packing, results -> host; `gpu_start_ms`: the chunk's first stamp against the call's */
+        hipSetDevice(c->X->device);
         for (k = 0; k < 5; ++k) hipEventElapsedTime(&g[k], c->X->btime[c->set][k], c->X->btime[c->set][k + 1]);
         hipEventElapsedTime(&since0, P->ev0, c->X->btime[c->set][0]);
     }
-    fprintf(stderr, "{\"mz_yama_batch_chunk\": %d, \"pairs\": %d, \"cells\": %lld, \"bytes_up\": %lld, \"bytes_down\": %lld, "
-                    "\"pack_ms\": [%.3f, %.3f], \"plan_wait_ms\": [%.3f, %.3f], \"launched_ms\": %.3f, \"result_wait_ms\": [%.3f, %.3f], \"assembled_ms\": %.3f, "
+    fprintf(stderr, "{\"mz_yama_batch_chunk\": %d, \"pairs\": %d, \"stream\": %d, \"cells\": %lld, \"bytes_up\": %lld, \"bytes_down\": %lld, "
+                    "\"cut_ms\": [%.3f, %.3f], \"packed_ms\": %.3f, \"sent_ms\": %.3f, \"plan_wait_ms\": [%.3f, %.3f], \"launched_ms\": %.3f, \"result_wait_ms\": [%.3f, %.3f], \"assembled_ms\": %.3f, "
                     "\"gpu_start_ms\": %.3f, \"gpu_ms\": {\"h2d_expand\": %.3f, \"plan\": %.3f, \"host_gap_dp\": %.3f, \"walk_pack\": %.3f, \"d2h\": %.3f}}\n",
-            c->index, c->n, (long long)c->cells, (long long)(c->in_bytes + c->exc_bytes), (long long)c->res_bytes,
-            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_launch0 - P->t0), 1e3 * (c->t_launch1 - P->t0),
+            c->index, c->n, c->lane, (long long)c->cells, (long long)(c->in_bytes + c->exc_bytes), (long long)c->res_bytes,
+            1e3 * (c->t_cut0 - P->t0), 1e3 * (c->t_cut1 - P->t0), 1e3 * (c->t_packed - P->t0), 1e3 * (c->t_send1 - P->t0), 1e3 * (c->t_launch0 - P->t0), 1e3 * (c->t_launch1 - P->t0),
             1e3 * (c->t_launch2 - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0),
             since0, g[0], g[1], g[2], g[3], g[4]);
-}
-
-static void stage_done(mz_pipe *P)          /* the last thing a stage does with the pipe: the caller may free it at once */
-{
-    pthread_mutex_lock(&P->mu);
-    P->done++;
-    pthread_cond_broadcast(&P->cv);
-    pthread_mutex_unlock(&P->mu);
-}
-
-/* stage 2: for chunk k = 0, 1, ...: wait until it is uploaded, wait for its plan, issue its kernels */
-static void launcher_main(void *arg)
-{
-    mz_pipe *P = (mz_pipe *)arg;
-    int k;
-    hipSetDevice(P->X->device);
-    for (k = 0;; ++k) {
-        pthread_mutex_lock(&P->mu);
-        while (P->rc >= 0 && P->uploaded <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
-        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
-        pthread_mutex_unlock(&P->mu);
-        if (chunk_launch(&P->ck[k % MZ_SETS]) < 0) { pipe_abort(P); break; }
-        pthread_mutex_lock(&P->mu);
-        P->launched = k + 1;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-    stage_done(P);
-}
-
-/* stage 3: wait for the results of chunk k, assemble its merged columns, free its buffer set */
-static void collector_main(void *arg)
-{
-    mz_pipe *P = (mz_pipe *)arg;
-    int k;
-    hipSetDevice(P->X->device);
-    for (k = 0;; ++k) {
-        int rc;
-        pthread_mutex_lock(&P->mu);
-        while (P->rc >= 0 && P->launched <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
-        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
-        pthread_mutex_unlock(&P->mu);
-        rc = chunk_collect(&P->ck[k % MZ_SETS]);
-        if (rc < 0) { pipe_abort(P); break; }
-        chunk_report(P, &P->ck[k % MZ_SETS]);
-        pthread_mutex_lock(&P->mu);
-        P->failed += rc;
-        pipe_count(P, &P->ck[k % MZ_SETS]);
-        P->collected = k + 1;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-    stage_done(P);
-}
-
-/* the two helper threads of a context are persistent (mz_pool.c: mzi_workers_start / mzi_worker_give) */
-void mzi_workers_stop(mz_ctx *X)
-{
-    mzi_workers_end(X->worker, 2);
-    mzi_workers_end(X->pworker, 3);
 }
 
 /* what a pair weighs in the cutting of chunks: its input bytes as the caller holds them */
@@ -550,22 +517,58 @@ static int next_chunk(const mz_job *jobs, int n, int first, int limit, size_t ma
     return m;
 }
 
+static int y_cut(void *self, int k, int set, mz_ajob *pack)
+{
+    ypipe *P = (ypipe *)self;
+    /* the first chunks are a quarter and a half of the size: the GPU starts that much earlier */
+    const int ramp = P->threaded && k < 2 && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) ? 2 - k : 0;
+    const int limit = P->max_pairs >> ramp < MIN_CHUNK_PAIRS / 2 ? MIN_CHUNK_PAIRS / 2 : P->max_pairs >> ramp;
+    int m;
+    if (P->up >= P->n) return 0;
+    m = next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp);
+    if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? k % P->X->nq : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    P->up += m;
+    return 1;
+}
+static int y_send(void *self, int k, int set, mz_ajob *post) { (void)k; (void)post; return chunk_send(&((ypipe *)self)->ck[set]); }
+static int y_launch(void *self, int k, int set, mz_ajob *post) { (void)k; (void)post; return chunk_launch(&((ypipe *)self)->ck[set]); }
+static int y_collect(void *self, int k, int set, mz_ajob *post) { (void)k; return chunk_collect(&((ypipe *)self)->ck[set], post); }
+static int y_finish(void *self, int k, int set)
+{
+    ypipe *P = (ypipe *)self;
+    chunk *c = &P->ck[set];
+    const int failed = chunk_finish(c);
+    (void)k;
+    pthread_mutex_lock(&P->mu);
+    chunk_report(P, c);
+    P->st.cells += c->cells; P->st.bytes_up += c->in_bytes + c->exc_bytes; P->st.bytes_down += c->res_bytes;
+    pthread_mutex_unlock(&P->mu);
+    return failed;
+}
+
+/* the stage threads of a context are persistent (mz_pool.c: mzi_workers_start / mzi_worker_give) */
+void mzi_workers_stop(mz_ctx *X)
+{
+    mzi_workers_end(X->fworker, MZ_FLOW_STAGES);
+}
+
 /* A batch of any size on ONE context.  A guide-tree level with a million merges (BASELINE config 4) needs a bounded
  * amount of pinned host memory and HBM: MZ_SETS chunks at most are in flight.  On a device error everything in flight
  * is drained and every pair not yet collected is left marked MZ_E_DEVICE with cols == NULL (mz_yama_batch() pre-marks
  * all of them), so a caller may clean up outs. */
 static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int max_pairs, batch_stats *stats)
 {
-    mz_pipe *P;
+    ypipe *P;
+    mz_flow *F;
     size_t max_bytes = 0;
-    int k = 0, up = 0, rc = 0, s, threaded;
+    int rc, s;
 
     if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
-    P = (mz_pipe *)calloc(1, sizeof *P);
-    if (!P) return mzi_set_err("out of memory");
-    P->X = X; P->n = n; P->jobs = jobs; P->outs = outs; P->max_pairs = max_pairs; P->total = -1; P->t0 = mzi_now_s();
+    P = (ypipe *)calloc(1, sizeof *P);
+    F = (mz_flow *)calloc(1, sizeof *F);
+    if (!P || !F) { free(P); free(F); return mzi_set_err("out of memory"); }
+    P->X = X; P->n = n; P->jobs = jobs; P->outs = outs; P->max_pairs = max_pairs; P->t0 = mzi_now_s();
     pthread_mutex_init(&P->mu, NULL);
-    pthread_cond_init(&P->cv, NULL);
 
     if (g_timing >= 2) {
         if (!X->btime_ready) {
@@ -582,54 +585,19 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     max_bytes = max_bytes / (size_t)chunk_parts() + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
-    /* one chunk: the three steps inline (no thread is woken for a single yama() call); also when no thread can be had */
-    threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n && mzi_workers_start(X->worker, 2) == 0;
-    if (!threaded) {
-        while (up < n) {
-            chunk *c = &P->ck[0];
-            const int m = next_chunk(jobs, n, up, max_pairs, max_bytes);
-            int f;
-            if (chunk_upload(X, c, k, 0, m, jobs + up, outs + up) < 0 || chunk_launch(c) < 0 || (f = chunk_collect(c)) < 0) { rc = -1; break; }
-            chunk_report(P, c);
-            pipe_count(P, c);
-            P->failed += f; up += m; ++k;
-        }
-        if (rc >= 0) rc = P->failed;
-    } else {
-        mzi_worker_give(&X->worker[0], launcher_main, P);
-        mzi_worker_give(&X->worker[1], collector_main, P);
-        /* stage 1 here: cut, pack, upload, plan.  The first chunk is a half-size one: the GPU starts that much earlier. */
-        while (up < n) {
-            const int first_half = k == 0 && (max_pairs >= 2048 || max_bytes >= ((size_t)32 << 20));
-            const int limit = first_half ? (max_pairs + 1) / 2 : max_pairs;
-            int m, bad;
-            pthread_mutex_lock(&P->mu);
-            while (P->rc >= 0 && k - P->collected >= MZ_SETS) pthread_cond_wait(&P->cv, &P->mu);    /* its buffer set is still in use */
-            bad = P->rc < 0;
-            pthread_mutex_unlock(&P->mu);
-            if (bad) break;
-            m = next_chunk(jobs, n, up, limit, first_half ? max_bytes / 2 : max_bytes);
-            if (chunk_upload(X, &P->ck[k % MZ_SETS], k, k % MZ_SETS, m, jobs + up, outs + up) < 0) { pipe_abort(P); break; }
-            up += m; ++k;
-            pthread_mutex_lock(&P->mu);
-            P->uploaded = k;
-            pthread_cond_broadcast(&P->cv);
-            pthread_mutex_unlock(&P->mu);
-        }
-        pthread_mutex_lock(&P->mu);
-        P->total = k;
-        pthread_cond_broadcast(&P->cv);
-        while (P->done < 2) pthread_cond_wait(&P->cv, &P->mu);
-        rc = P->rc < 0 ? -1 : P->failed;
-        pthread_mutex_unlock(&P->mu);
-        if (rc < 0) mzi_set_err("%s", P->err);
-    }
-    if (rc < 0) for (s = 0; s < MZ_SETS; ++s) { if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]); if (X->ustream[s]) hipStreamSynchronize(X->ustream[s]); }
+    P->max_bytes = max_bytes;
+    /* one chunk: the steps inline (no thread is woken for a single yama() call); also when no thread can be had */
+    P->threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n;
+    F->X = X; F->self = P; F->nstage = 3; F->threaded = P->threaded;
+    F->cut = y_cut; F->stage[0] = y_send; F->stage[1] = y_launch; F->stage[2] = y_collect; F->finish = y_finish;
+    if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }
+    rc = mzi_flow_run(F);
+    if (rc < 0) mzi_flow_sync(X);
+    for (s = 0; s < MZ_SETS; ++s) { free(P->ck[s].pc.esz); free(P->ck[s].ac); free(P->ck[s].where); }
     if (g_timing >= 2 && X->btime_ready) hipEventDestroy(P->ev0);
-    if (stats) { stats->cells = P->cells; stats->bytes_up = P->bytes_up; stats->bytes_down = P->bytes_down; }
+    if (stats) *stats = P->st;
     pthread_mutex_destroy(&P->mu);
-    pthread_cond_destroy(&P->cv);
-    free(P);
+    free(P); free(F);
     return rc;
 }
 
@@ -854,7 +822,7 @@ int mz_link_pack(int n, const mz_job *jobs, mz_link_desc *d, void **image, void 
         else oband += 1;
     }
     pc.jobs = jobs; pc.hoA = hoA; pc.hoB = hoB; pc.hoC = hoC; pc.hA = (uint8_t *)h + y.nibA; pc.hB = (uint8_t *)h + y.nibB;
-    pc.hC = (uint8_t *)h + y.steps; pc.hFmt = (uint8_t *)h + y.fmt; pc.esz = esz; pc.hE = NULL;
+    pc.hC = (uint8_t *)h + y.steps; pc.hFmt = (uint8_t *)h + y.fmt; pc.esz = esz; pc.hE = NULL; pc.hLB0 = pc.hRB0 = NULL;
     mzi_parallel_for(n, pack_grain(n), pack_range, &pc);
     for (p = 0; p < n; ++p) if (esz[p]) { hoC[p] = (int64_t)bytesE; bytesE += esz[p]; }
     if (bytesE) {
@@ -1055,7 +1023,7 @@ double mz_host_pack_probe(int n, const mz_job *jobs, int what, int reps)
         if (job_ok(&jobs[p])) { oa += cols_padded(jobs[p].K, jobs[p].M); ob += cols_padded(jobs[p].L, jobs[p].N); oc += band_slot(jobs[p].M); }
     }
     P.what = what;
-    P.pc.jobs = jobs; P.pc.hoA = hoA; P.pc.hoB = hoB; P.pc.hoC = hoC; P.pc.hFmt = fmt; P.pc.esz = esz; P.pc.hE = NULL;
+    P.pc.jobs = jobs; P.pc.hoA = hoA; P.pc.hoB = hoB; P.pc.hoC = hoC; P.pc.hFmt = fmt; P.pc.esz = esz; P.pc.hE = NULL; P.pc.hLB0 = P.pc.hRB0 = NULL;
     P.pc.hC = buf; P.pc.hA = buf + mzi_al256(bytesC); P.pc.hB = P.pc.hA + mzi_al256(eA / 2);
     mzi_parallel_for(n, pack_grain(n), probe_range, &P);             /* warm: pages, pool */
     t0 = mzi_now_s();

@@ -27,6 +27,8 @@ typedef struct gbuf { void *p; size_t cap; } gbuf;
 enum { MZ_PD_IN, MZ_PD_TXT, MZ_PD_COLS, MZ_PD_BAND, MZ_PD_SCR, MZ_PD_META, MZ_PD_OUT1, MZ_PD_OUT2, MZ_PD_A2, MZ_PD_BAND2, MZ_PD_PLAN2, MZ_PD_TB2,
        MZ_PD_SCRIPT2, MZ_PD_PREP2, MZ_PD_RES, MZ_PD_N };
 enum { MZ_PH_IN, MZ_PH_RES, MZ_PH_TOT2, MZ_PH_N };
+#define MZ_QS 4                            /* stream slots of the chunk pipelines at most (MZ_STREAMS; default 2) */
+#define MZ_FLOW_STAGES 4                   /* stage threads of a chunk pipeline at most */
 #define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
 #define MZ_MAX_DEV 16
 #define MZ_MULTI_MIN 2048                  /* pairs per GPU below which dealing a batch out is not worth a thread */
@@ -82,17 +84,23 @@ typedef struct mz_ctx {
     hipEvent_t pplan2[MZ_SETS];
     hipEvent_t ptime[MZ_SETS][8];          /* MZ_TIMING=2: before the upload, uploaded, k_pre done, planned, first DP done, first emit done, (second stage done,) k_fin done */
     int ptime_ready;
-    mz_worker pworker[3];                  /* first launcher, second launcher, collector of mz_preyama_batch() */
-    hipStream_t bstream[MZ_SETS];          /* one stream per set (mz_yama_batch) */
-    hipStream_t ustream[MZ_SETS];          /* and one of high priority for its upload, expansion and plan: a chunk's plan must not queue
-                                            * behind the DP waves of the chunks before it (the launcher waits for its totals) */
-    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS];
+    hipStream_t bstream[MZ_SETS];          /* bstream[0] = `stream`: a call of one chunk (the drop-in yama()) runs there */
+    /* The chunk pipelines' streams (mz_flow.c; created on first use).  Chunk k of a call uses slot k % nq: its staging block -> device
+     * copy (a kernel: mzk_link_copy), expansion and plan on qf[slot]; its DP kernels on qd[slot] -- back to back with the DPs of the
+     * chunks before and after it, as the device-resident pipeline runs them (mz_dev_run_async), forking onto the slot's own lane when
+     * the chunk has several kinds of pairs; walk, script packing and the results -> host copy on qt[slot], behind the DP's event
+     * (bdp).  With two slots and a lane each that is eight streams: the hardware queues the library asks the runtime for -- streams
+     * that share one run in each other's order. */
+    hipStream_t qf[MZ_QS], qd[MZ_QS], qt[MZ_QS];
+    mz_dp_lanes qlane[MZ_QS];
+    int nq, nf, nt;                        /* DP slots (chunk k: qd[k % nq]), front streams (qf[k % nf]), tail streams (qt[k % nt]) */
+    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bprep[MZ_SETS], bdp[MZ_SETS];    /* the chunk's last kernel; its plan's totals; its prep records; its DP kernels */
     hipEvent_t btime[MZ_SETS][6];          /* MZ_TIMING=2: start, uploaded, planned, DP done, results packed, copied back */
     int btime_ready;
     struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
     int ws_victim;
     int copy_threads;                      /* host threads of this context's pack / unpack loops */
-    mz_worker worker[2];                   /* launcher, collector (mz_batch.c) */
+    mz_worker fworker[MZ_FLOW_STAGES];     /* the chunk pipeline's stage threads (mz_flow.c), shared by the two host paths (calls are serialised) */
 } mz_ctx;
 
 extern MZ_INTERNAL mz_ctx g_dev[MZ_MAX_DEV];
@@ -108,6 +116,9 @@ MZ_INTERNAL int mzi_set_err(const char *fmt, ...) __attribute__((format(printf, 
 MZ_INTERNAL int mzi_dev_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_host_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_lazy_stream(hipStream_t *s);
+MZ_INTERNAL unsigned mzi_event_flags(void);              /* of the events nobody takes times from: no timing, release to the DEVICE (mz_host.c) */
+MZ_INTERNAL int mzi_flow_streams(mz_ctx *X);              /* mz_flow.c: the chunk streams and their lanes, on first use */
+MZ_INTERNAL void mzi_flow_sync(mz_ctx *X);                /* ... all of them synchronised (after an error) */
 MZ_INTERNAL int mzi_ensure_init(void);
 extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_warm_start(): its batch prints no MZ_TIMING line */
 MZ_INTERNAL int mzi_sync_scores(void);
@@ -119,12 +130,57 @@ MZ_INTERNAL int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preou
 /* mz_pool.c: the host threads of the batch pipeline (no OpenMP there: see the file), recycled result blocks */
 typedef void (*mz_pfn)(void *ctx, int lo, int hi);
 MZ_INTERNAL void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx);
+/* a loop that is posted and not waited for: fn(ctx, lo, hi) over [0, n) in pieces of `grain` on the pool's threads, then done(arg)
+ * once, on the thread that ran the last piece (next / pending / link are the pool's) */
+typedef struct mz_ajob {
+    mz_pfn fn; void *ctx; int n, grain;
+    void (*done)(void *arg); void *arg;
+    int next, pending; struct mz_ajob *link;
+} mz_ajob;
+MZ_INTERNAL void mzi_post(mz_ajob *job);
+MZ_INTERNAL void mzi_help_until(int (*ready)(void *), void *arg);    /* the caller works on posted pieces until ready(arg) (evaluated under the pool's lock) */
+MZ_INTERNAL void mzi_pool_kick(void);                                  /* ... whoever makes ready() true calls this afterwards */
 MZ_INTERNAL int mzi_pool_threads(void);
 MZ_INTERNAL int mzi_cpu_budget(void);
 MZ_INTERNAL void mzi_pool_stop(void);
 MZ_INTERNAL void *mzi_block_get(size_t need);
 MZ_INTERNAL void mzi_block_put(void *p);
 MZ_INTERNAL void mzi_blocks_drop(void);
+
+/* mz_flow.c: the chunk pipeline of mz_yama_batch() and mz_preyama_batch().  A call is cut into chunks; chunk k lives in buffer set
+ * k % MZ_SETS and goes through
+ *   cut      (the calling thread)   the client lays the chunk out in its set and describes its packing as a loop, which is POSTED to the
+ *                                   pool (mz_pool.c) -- the caller does not wait for it: it cuts the next chunk, and works in the pool
+ *                                   itself when it has nothing to cut;
+ *   stage 1 .. nstage (a persistent thread each, chunks in order)   whatever the client does there -- launches, waits for the device;
+ *                                   the LAST stage may describe one more loop (the assembling of the chunk's results), posted likewise;
+ *   finish   (whichever thread ran that loop's last piece)          the chunk's accounting; its buffer set is free again.
+ * The stage functions return < 0 on an error (mz_last_error() set): the call is aborted, everything in flight is drained. */
+typedef struct mz_flow {
+    /* the client's */
+    mz_ctx *X;
+    void *self;
+    int nstage, threaded;
+    int (*cut)(void *self, int k, int set, mz_ajob *pack);                            /* 1: chunk k laid out; 0: nothing left; < 0: error */
+    int (*stage[MZ_FLOW_STAGES])(void *self, int k, int set, mz_ajob *post);         /* post: NULL except for the last stage */
+    int (*finish)(void *self, int k, int set);                                        /* pairs of the chunk without a result (>= 0); < 0: error */
+    /* the engine's */
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int packed[MZ_SETS], finished[MZ_SETS];          /* chunk index + 1 of the last chunk packed / finished in the set */
+    int through[MZ_FLOW_STAGES + 1];                 /* chunks through stage s, in order */
+    int total, rc, left, jobs_out, failed, chunks;
+    mz_ajob pack[MZ_SETS], post[MZ_SETS];
+    struct mz_flow_arg { struct mz_flow *F; int k; } parg[MZ_SETS], qarg[MZ_SETS], sarg[MZ_FLOW_STAGES];
+    int wait_k;                                      /* what the calling thread is waiting for (flow_ready) */
+    char err[600];
+} mz_flow;
+MZ_INTERNAL int mzi_flow_run(mz_flow *F);            /* pairs without a result, or -1 (mz_last_error()) */
+
+/* dwords of prep records (mz_dev_batch.prep) a pair of N columns can need, whatever kernel the plan gives it: the transposed band of
+ * a MZ_MODE_COL pair, 2 (N + 1), in whole 64-dword groups (kernels/plan.inc: szPrep) -- so the chunk pipelines reserve the prep buffer
+ * before the plan has run and make the records right behind it */
+#define MZ_PREP_BOUND(N) ((2 * ((size_t)(N) + 1) + 63) & ~(size_t)63)
 
 static inline size_t mzi_al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline double mzi_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }

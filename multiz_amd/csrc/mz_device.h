@@ -23,7 +23,13 @@ int mzk_walk(const mz_dev_batch *b, void *stream, int beside_dp);   /* beside_dp
 int mzk_emit(const mz_dev_batch *b, void *stream);
 /* the same three phases on the slice [first, first+count) of the batch */
 int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
+/* ... with the caller's own side streams for the DP kernels of a batch that has several kinds of pairs (n = 0: all on `stream`;
+ * lanes == NULL: the device's own set, one per device) -- hipStream_t / hipEvent_t as void * */
+typedef struct mz_dp_lanes { int n; void *stream[4]; void *fork; void *join[4]; int row_cap; /* > 0: the row-parallel kernels as persistent grids of at most this many blocks */ } mz_dp_lanes;
+int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes);
 int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);
+/* bytes (a multiple of 16, both addresses 16-byte aligned) from src to dst by a kernel on `stream`: either may be pinned host memory */
+int mzk_link_copy(void *dst, const void *src, size_t bytes, void *stream);
 int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream);
 /* device side of pre_yama() around the DP (kernels/prepost.inc): all device pointers */
 typedef struct mz_pre_batch {

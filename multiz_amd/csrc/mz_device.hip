@@ -48,6 +48,14 @@
 #define MODE_IS_COLFAM(m) ((m) == MZ_MODE_COL || (m) == MZ_MODE_COLR)
 #define MODE_IS_TAGGED(m) ((m) == MZ_MODE_FASTT || MODE_IS_ROWFAM(m) || (m) == MZ_MODE_LAG)
 
+// Helper kernels (everything but the DP) raise their waves' issue priority: in the chunk pipelines they run beside five DP waves per
+// SIMD that issue VALU four cycles in five, and a helper wave that only gets what those leave takes 10-30x its time alone -- the plan of
+// chunk k+2 then is not through when the DP of chunk k ends, and the DP stream idles (round 5; -DMZ_HELPER_PRIO=0 for A/B builds).
+#ifndef MZ_HELPER_PRIO
+#define MZ_HELPER_PRIO 3
+#endif
+#define HELPER_PRIO() do { if (MZ_HELPER_PRIO) __builtin_amdgcn_s_setprio(MZ_HELPER_PRIO); } while (0)
+
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; int tstrip_on; };
 __constant__ ScoreConst c_sc;
 
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, 
                                                  const uint8_t *fmt, const uint8_t *packed, const uint8_t *exceptions,
                                                  int32_t *poolLB, int32_t *poolRB)
 {
+    HELPER_PRIO();
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
     const int M = bandLen[p] - 1;                       // entries 0..M (an invalid job carries one dummy entry)
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(WAVE) void k_unband(int n, const int32_t *bandLen, 
 // 8 bytes out; pair boundaries do not matter (every pair's slice is a whole number of 32-byte lines).
 __global__ __launch_bounds__(256) void k_unnib(const uint32_t *src, uint2 *dst, long long ndw)
 {
+    HELPER_PRIO();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= ndw) return;
     const unsigned long long tab = 0x00004e2d54474341ULL;           // "ACGT-N", a byte per class
@@ -448,7 +458,7 @@ static int grid_of(int count, int most, int field)       // waves for a counter 
     if (field > 0 && 8 * field < g) g = 8 * field;
     return g < 1 ? 1 : g;
 }
-extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream)
+extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes)
 {
     if (count <= 0) return 0;
     static int dyn_lds = -1;                      // MZ_DYN_LDS=<bytes>: occupancy experiments (extra, unused LDS per wave)
@@ -479,29 +489,45 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
         CK(hipMemsetAsync(&b->totals[16], 0, 5 * sizeof(int64_t), main_s), "dp counters");
-    DpSide *S = ((b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
+    // The side streams: the caller's own (`lanes`: the chunk pipelines give every chunk stream a set of its own -- one set per
+    // device made the few long wavefront pairs of chunk k+1 wait for those of chunk k on the shared stream, a chain of 12 x 0.55 ms
+    // that WAS a 20 000-pair call with indel bands), else the device's.  Fewer lanes than kinds: several kinds share a lane, in
+    // launch order; none (lanes->n == 0): everything on `stream`.
+    DpSide *S = (!lanes && (b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) ? dp_side() : nullptr;
+    DpSide L;                                         // (the caller's lanes in the same shape)
+    if (lanes && lanes->n > 0 && (b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) {
+        L.ready = 1;
+        for (int i = 0; i < 4; ++i) { L.s[i] = (hipStream_t)lanes->stream[i % lanes->n]; L.join[i] = (hipEvent_t)lanes->join[i % lanes->n]; }
+        L.fork = (hipEvent_t)lanes->fork;
+    }
+    const int nlane = lanes ? (lanes->n < 4 ? lanes->n : 4) : 4;
     // (one set of side streams and events per DEVICE: two host threads on one device -- the tests' MZ_ALLOW_DUP_DEVICES --
     // must not interleave their record / wait sequences; what a wait refers to is fixed when it is enqueued)
     std::unique_lock<std::mutex> side_lock;
     if (S) side_lock = std::unique_lock<std::mutex>(S->mu);
+    if (!S && lanes && lanes->n > 0 && (b->dp_hint & MZ_DP_KNOWN) && nk > 1 && !serial) S = &L;
     if (S) CK(hipEventRecord(S->fork, main_s), "dp fork");
-    int used = 0;
+    int used = 0, sides = 0;
     for (int i = 0; i < 5; ++i) {
         if (!(hint & kinds[i])) continue;
         const bool side = S && i != last;
         hipStream_t s = main_s;
-        if (side) { s = S->s[used]; CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
+        if (side) { s = S->s[sides % nlane]; if (sides < nlane) CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
         // (the row kernels: a block per pair of the batch, or -- whole batch, counts known -- per entry of the plan's list)
+        // (persistent: the caller's cap on the blocks -- the chunk pipelines'; an even share of the items per block, so that the last
+        //  round is as full as the first)
+        const int row_items = rows_listed ? b->dp_rows : count;
+        int row_blocks = row_items;
+        if (lanes && lanes->row_cap > 0 && row_items > lanes->row_cap) { const int rounds = (row_items + lanes->row_cap - 1) / lanes->row_cap; row_blocks = (row_items + rounds - 1) / rounds; }
         if (kinds[i] == MZ_DP_ROW) {
             // few pairs -- a wave or two per SIMD, nothing to hide a latency behind: the latency-tolerant build (kernels/row.inc)
-            const int blocks = rows_listed ? b->dp_rows : count;
-            if ((long long)blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
-                hipLaunchKernelGGL(k_dp_row_lat, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
+            if ((long long)row_blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
+                hipLaunchKernelGGL(k_dp_row_lat, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
             else
-                hipLaunchKernelGGL(k_dp_row, dim3(blocks), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 1);
+                hipLaunchKernelGGL(k_dp_row, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
         }
         else if (kinds[i] == MZ_DP_ROWBIG)
-            hipLaunchKernelGGL(k_dp_row_big, dim3(rows_listed ? b->dp_rows : count), dim3(WAVE), dyn_lds, s, *b, first, count, rows_listed ? 3 : known ? 0 : 2);
+            hipLaunchKernelGGL(k_dp_row_big, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 2);
         // (the counter kernels: no more waves than pairs -- a wave that finds the counter exhausted still had to wait for
         //  its 9-13 KB of LDS beside the other kernels' waves, and the launch is over only when the last one has)
         else if (kinds[i] == MZ_DP_WAVEFRONT)
@@ -515,10 +541,47 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
         }
         else
             hipLaunchKernelGGL(k_dp_lag, dim3(grid_of(count, 4096, (b->dp_grid >> 20) & 1023)), dim3(WAVE), dyn_lds_lag, s, *b, first, count);
-        if (side) { CK(hipEventRecord(S->join[used], s), "dp join"); ++used; }
+        if (side) { ++sides; used = sides < nlane ? sides : nlane; }
     }
-    for (int i = 0; i < used; ++i) CK(hipStreamWaitEvent(main_s, S->join[i], 0), "dp join wait");
+    // (a lane's join is recorded once, behind the last kind it got)
+    for (int i = 0; i < used; ++i) { CK(hipEventRecord(S->join[i], S->s[i]), "dp join"); CK(hipStreamWaitEvent(main_s, S->join[i], 0), "dp join wait"); }
     CK(hipGetLastError(), "dp launch");
+    return 0;
+}
+extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream) { return mzk_dp_range_on(b, first, count, stream, nullptr); }
+
+// ------------------------------------------------------------------------------------------
+// The chunk pipelines' link traffic as KERNELS on the chunk's own stream (round 5).  The staging block lies in pinned host memory,
+// which the GPU reads and writes over PCIe like any other address; a copy kernel in the chunk's stream is ordered with the kernels
+// around it by the stream itself, where a hipMemcpyAsync() goes to an SDMA engine that takes its commands in order across ALL
+// streams -- and on this platform was seen to stand still for 3-8 ms at a time (both directions at once, kernels running on:
+// the "one call in five takes twice as long" of rounds 3 and 4).  16 bytes per lane, four loads in flight per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_link_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16)
+{
+    HELPER_PRIO();
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int mzk_link_copy(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!bytes) return 0;
+    if (((uintptr_t)dst | (uintptr_t)src | bytes) & 15) { snprintf(g_err, sizeof g_err, "link copy: not 16-byte aligned"); return -1; }
+    // Few waves, each with 4 KB in flight: the link holds ~57 GB/s x a few microseconds = a few hundred KB at a time, and a copy wave
+    // waiting for it sits where a DP wave could (MZ_COPY_BLOCKS overrides; 2 048 blocks -- the whole GPU's wave slots -- halved a call's rate)
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("MZ_COPY_BLOCKS"); cap = e && atoi(e) > 0 ? atoi(e) : 32; }
+    const long long n16 = (long long)(bytes / 16);
+    long long blocks = (n16 + 1023) / 1024;              // four 16-byte pieces per lane
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_link_copy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+    CK(hipGetLastError(), "link copy launch");
     return 0;
 }
 extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp)

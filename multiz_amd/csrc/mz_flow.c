@@ -1,0 +1,199 @@
+/* mz_flow.c -- the chunk pipeline shared by mz_yama_batch() (mz_batch.c) and mz_preyama_batch() (mz_prebatch.c); the
+ * interface is in mz_ctx.h.
+ *
+ * Round 4's pipelines had the calling thread pack a chunk (a parallel loop it waited for), then issue that chunk's
+ * upload and plan, then pack the next: the GPU got a chunk every 0.66-0.75 ms whose DP takes 0.4 ms of its time, thirteen
+ * DPs ran strictly one after another (profiles/r4_timeline_host_c2.txt) and the pool's threads stood at a barrier twice
+ * per chunk.  Here nothing on the host waits for a loop: packing and assembling are posted to the pool piece by piece in
+ * chunk order, the calling thread works there too, and issuing is the stage threads' business alone.
+ */
+#include <stdio.h>
+#include <string.h>
+
+#include "mz_ctx.h"
+
+/* The chunk streams (mz_ctx.h): MZ_STREAMS slots (default 2) of three streams each, and MZ_LANES lanes (default 1) per slot for
+ * the DP kernels of chunks with several kinds of pairs. */
+int mzi_flow_streams(mz_ctx *X)
+{
+    int nq, nl, nf, nt, i, l;
+    if (X->nq) return 0;
+    { const char *e = getenv("MZ_STREAMS"); nq = e && atoi(e) > 0 ? atoi(e) : 2; if (nq > MZ_QS) nq = MZ_QS; }
+    { const char *e = getenv("MZ_FRONTS"); nf = e && atoi(e) > 0 ? atoi(e) : 2; if (nf > MZ_QS) nf = MZ_QS; }
+    { const char *e = getenv("MZ_TAILS"); nt = e && atoi(e) > 0 ? atoi(e) : 2; if (nt > MZ_QS) nt = MZ_QS; }
+    { const char *e = getenv("MZ_LANES"); nl = e && atoi(e) >= 0 ? atoi(e) : 1; if (nl > 4) nl = 4; }
+    for (i = 0; i < nq; ++i) {
+        if (mzi_lazy_stream(&X->qd[i])) return -1;
+        X->qlane[i].n = nl;
+        /* the DP of a chunk as a persistent grid: half of the GPU's 5 120 row-parallel wave slots per DP stream (MZ_DP_CAP; 0: a block per pair) */
+        { const char *e = getenv("MZ_DP_CAP"); X->qlane[i].row_cap = e ? atoi(e) : 5120 / nq; }
+        if (nl) HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
+        for (l = 0; l < nl; ++l) {
+            hipStream_t s = NULL;
+            if (mzi_lazy_stream(&s)) return -1;
+            X->qlane[i].stream[l] = (void *)s;
+            HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].join[l], mzi_event_flags()));
+        }
+    }
+    for (i = 0; i < nf; ++i) {
+        /* MZ_FRONT_PRIO=1: the front streams at the highest priority (measurements) */
+        const char *fp = getenv("MZ_FRONT_PRIO");
+        if (fp && fp[0] == '1') {
+            int least = 0, greatest = 0;
+            HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCK(hipStreamCreateWithPriority(&X->qf[i], hipStreamNonBlocking, greatest));
+        }
+        if (mzi_lazy_stream(&X->qf[i])) return -1;
+    }
+    for (i = 0; i < nt; ++i) if (mzi_lazy_stream(&X->qt[i])) return -1;
+    X->nf = nf; X->nt = nt;
+    X->nq = nq;
+    return 0;
+}
+
+/* everything a context's chunk pipelines may have in flight (after an error) */
+void mzi_flow_sync(mz_ctx *X)
+{
+    int s, l;
+    if (X->stream) hipStreamSynchronize(X->stream);
+    for (s = 0; s < X->nf; ++s) hipStreamSynchronize(X->qf[s]);
+    for (s = 0; s < X->nt; ++s) hipStreamSynchronize(X->qt[s]);
+    for (s = 0; s < X->nq; ++s) {
+        hipStreamSynchronize(X->qd[s]);
+        for (l = 0; l < X->qlane[s].n; ++l) hipStreamSynchronize((hipStream_t)X->qlane[s].stream[l]);
+    }
+}
+
+static void flow_abort(mz_flow *F)
+{
+    pthread_mutex_lock(&F->mu);
+    if (F->rc >= 0) { F->rc = -1; snprintf(F->err, sizeof F->err, "%s", mz_last_error()); }
+    pthread_cond_broadcast(&F->cv);
+    pthread_mutex_unlock(&F->mu);
+    mzi_pool_kick();
+}
+
+static void flow_pack_done(void *arg)
+{
+    struct mz_flow_arg *a = (struct mz_flow_arg *)arg;
+    mz_flow *F = a->F;
+    pthread_mutex_lock(&F->mu);
+    F->packed[a->k % MZ_SETS] = a->k + 1;
+    F->jobs_out--;
+    pthread_cond_broadcast(&F->cv);
+    pthread_mutex_unlock(&F->mu);
+    mzi_pool_kick();
+}
+
+static void flow_post_done(void *arg)
+{
+    struct mz_flow_arg *a = (struct mz_flow_arg *)arg;
+    mz_flow *F = a->F;
+    const int k = a->k, r = F->finish(F->self, k, k % MZ_SETS);
+    if (r < 0) flow_abort(F);
+    pthread_mutex_lock(&F->mu);
+    if (r > 0) F->failed += r;
+    __atomic_store_n(&F->finished[k % MZ_SETS], k + 1, __ATOMIC_RELEASE);
+    F->jobs_out--;
+    pthread_cond_broadcast(&F->cv);
+    pthread_mutex_unlock(&F->mu);
+    mzi_pool_kick();
+}
+
+/* stage s = 1 .. nstage: for chunk k = 0, 1, ...: wait until the stage before is through with it, do this one's part */
+static void flow_stage(void *arg)
+{
+    struct mz_flow_arg *a = (struct mz_flow_arg *)arg;
+    mz_flow *F = a->F;
+    const int s = a->k;
+    int k;
+    hipSetDevice(F->X->device);
+    for (k = 0;; ++k) {
+        const int set = k % MZ_SETS, last = s == F->nstage;
+        int rc;
+        pthread_mutex_lock(&F->mu);
+        while (F->rc >= 0 && !(s == 1 ? F->packed[set] == k + 1 : F->through[s - 1] > k) && (F->total < 0 || k < F->total)) pthread_cond_wait(&F->cv, &F->mu);
+        if (F->rc < 0 || (F->total >= 0 && k >= F->total)) { pthread_mutex_unlock(&F->mu); break; }
+        pthread_mutex_unlock(&F->mu);
+        if (last) { memset(&F->post[set], 0, sizeof F->post[set]); F->qarg[set].F = F; F->qarg[set].k = k; }
+        rc = F->stage[s - 1](F->self, k, set, last ? &F->post[set] : NULL);
+        if (rc < 0) { flow_abort(F); break; }
+        pthread_mutex_lock(&F->mu);
+        F->through[s] = k + 1;
+        if (last) F->jobs_out++;
+        pthread_cond_broadcast(&F->cv);
+        pthread_mutex_unlock(&F->mu);
+        if (last) { F->post[set].done = flow_post_done; F->post[set].arg = &F->qarg[set]; mzi_post(&F->post[set]); }
+    }
+    pthread_mutex_lock(&F->mu);                          /* the last thing a stage does with the flow */
+    F->left++;
+    pthread_cond_broadcast(&F->cv);
+    pthread_mutex_unlock(&F->mu);
+    mzi_pool_kick();
+}
+
+/* what the calling thread waits for while it works in the pool (evaluated under the pool's lock: atomics only) */
+static int flow_set_free(void *arg)
+{
+    mz_flow *F = (mz_flow *)arg;
+    return __atomic_load_n(&F->rc, __ATOMIC_ACQUIRE) < 0 || __atomic_load_n(&F->finished[F->wait_k % MZ_SETS], __ATOMIC_ACQUIRE) == F->wait_k + 1;
+}
+static int flow_drained(void *arg)
+{
+    mz_flow *F = (mz_flow *)arg;
+    return __atomic_load_n(&F->left, __ATOMIC_ACQUIRE) == F->nstage && __atomic_load_n(&F->jobs_out, __ATOMIC_ACQUIRE) == 0;
+}
+
+int mzi_flow_run(mz_flow *F)
+{
+    int k, s, rc;
+    F->total = -1; F->rc = 0; F->left = 0; F->jobs_out = 0; F->failed = 0; F->chunks = 0; F->err[0] = 0;
+    memset(F->packed, 0, sizeof F->packed); memset(F->finished, 0, sizeof F->finished); memset(F->through, 0, sizeof F->through);
+    if (F->threaded && (mzi_flow_streams(F->X) || mzi_workers_start(F->X->fworker, F->nstage))) F->threaded = 0;
+    if (!F->threaded) {
+        /* a chunk at a time, everything here (a single yama() call: no thread is woken) */
+        for (k = 0;; ++k) {
+            mz_ajob job;
+            int r;
+            memset(&job, 0, sizeof job);
+            if ((r = F->cut(F->self, k, 0, &job)) <= 0) { if (r < 0) return -1; break; }
+            mzi_parallel_for(job.n, job.grain, job.fn, job.ctx);
+            for (s = 1; s <= F->nstage; ++s) {
+                memset(&job, 0, sizeof job);
+                if (F->stage[s - 1](F->self, k, 0, s == F->nstage ? &job : NULL) < 0) return -1;
+            }
+            if (job.fn) mzi_parallel_for(job.n, job.grain, job.fn, job.ctx);
+            if ((r = F->finish(F->self, k, 0)) < 0) return -1;
+            F->failed += r;
+            F->chunks = k + 1;
+        }
+        return F->failed;
+    }
+    pthread_mutex_init(&F->mu, NULL);
+    pthread_cond_init(&F->cv, NULL);
+    for (s = 1; s <= F->nstage; ++s) { F->sarg[s - 1].F = F; F->sarg[s - 1].k = s; mzi_worker_give(&F->X->fworker[s - 1], flow_stage, &F->sarg[s - 1]); }
+    for (k = 0;; ++k) {
+        const int set = k % MZ_SETS;
+        int r;
+        if (k >= MZ_SETS) { F->wait_k = k - MZ_SETS; mzi_help_until(flow_set_free, F); }      /* its buffer set is still in use */
+        if (__atomic_load_n(&F->rc, __ATOMIC_ACQUIRE) < 0) break;
+        memset(&F->pack[set], 0, sizeof F->pack[set]);
+        if ((r = F->cut(F->self, k, set, &F->pack[set])) <= 0) { if (r < 0) flow_abort(F); break; }
+        F->parg[set].F = F; F->parg[set].k = k;
+        F->pack[set].done = flow_pack_done; F->pack[set].arg = &F->parg[set];
+        pthread_mutex_lock(&F->mu);
+        F->jobs_out++;
+        pthread_mutex_unlock(&F->mu);
+        mzi_post(&F->pack[set]);
+    }
+    pthread_mutex_lock(&F->mu);
+    F->total = k; F->chunks = k;
+    pthread_cond_broadcast(&F->cv);
+    pthread_mutex_unlock(&F->mu);
+    mzi_help_until(flow_drained, F);
+    rc = F->rc < 0 ? -1 : F->failed;
+    if (rc < 0) mzi_set_err("%s", F->err);
+    pthread_mutex_destroy(&F->mu);
+    pthread_cond_destroy(&F->cv);
+    return rc;
+}

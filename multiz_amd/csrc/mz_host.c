@@ -103,6 +103,16 @@ int mzi_host_reserve(gbuf *b, size_t need)
     return 0;
 }
 
+/* Events that only order streams -- or tell the host that results lie in pinned HOST memory, which the GPU writes through -- need no
+ * system-scope release: hipEventRecord() otherwise makes the GPU write its L2 back to memory at every record, a dozen times per chunk
+ * of a call beside DP kernels that dirty 0.5 TB/s of it (MZ_EVENT_SYSTEM=1: the runtime's default, for A/B measurements). */
+unsigned mzi_event_flags(void)
+{
+    static int sys = -1;
+    if (sys < 0) { const char *e = getenv("MZ_EVENT_SYSTEM"); sys = e && e[0] == '1'; }
+    return hipEventDisableTiming | (sys ? 0u : hipEventReleaseToDevice);
+}
+
 void *mz_stream(void) { return G.ready ? (void *)G.stream : NULL; }
 
 static int ctx_open(mz_ctx *X, int device)
@@ -115,9 +125,11 @@ static int ctx_open(mz_ctx *X, int device)
      * ~9 ms of start-up and a short run -- one yama() call, one chunk -- needs none of them */
     X->bstream[0] = X->stream;
     for (i = 0; i < MZ_SETS; ++i) {
-        HIPCK(hipEventCreateWithFlags(&X->bdone[i], hipEventDisableTiming));
-        HIPCK(hipEventCreateWithFlags(&X->bplan[i], hipEventDisableTiming));
-        HIPCK(hipEventCreateWithFlags(&X->pplan2[i], hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&X->bdone[i], mzi_event_flags()));
+        HIPCK(hipEventCreateWithFlags(&X->bplan[i], mzi_event_flags()));
+        HIPCK(hipEventCreateWithFlags(&X->bdp[i], mzi_event_flags()));
+        HIPCK(hipEventCreateWithFlags(&X->bprep[i], mzi_event_flags()));
+        HIPCK(hipEventCreateWithFlags(&X->pplan2[i], mzi_event_flags()));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
     for (i = 0; i <= MZ_SLICES; ++i) HIPCK(hipEventCreateWithFlags(&X->evs[i], hipEventDisableTiming));
@@ -141,10 +153,11 @@ static void ctx_close(mz_ctx *X)
         for (i = 0; i < (int)(sizeof d / sizeof d[0]); ++i) if (d[i]->p) { hipFree(d[i]->p); d[i]->p = NULL; d[i]->cap = 0; }
         for (i = 0; i < (int)(sizeof h / sizeof h[0]); ++i) if (h[i]->p) { hipHostFree(h[i]->p); h[i]->p = NULL; h[i]->cap = 0; }
         if (s >= 1 && X->bstream[s]) hipStreamDestroy(X->bstream[s]);
-        if (X->ustream[s]) { hipStreamSynchronize(X->ustream[s]); hipStreamDestroy(X->ustream[s]); X->ustream[s] = NULL; }
         if (X->btime_ready) for (i = 0; i < 6; ++i) hipEventDestroy(X->btime[s][i]);
         hipEventDestroy(X->bdone[s]);
         hipEventDestroy(X->bplan[s]);
+        hipEventDestroy(X->bdp[s]);
+        hipEventDestroy(X->bprep[s]);
     }
     for (s = 0; s < MZ_SETS; ++s) {
         for (i = 0; i < MZ_PD_N; ++i) if (X->pd[s][i].p) { hipFree(X->pd[s][i].p); X->pd[s][i].p = NULL; X->pd[s][i].cap = 0; }
@@ -152,6 +165,17 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->pplan2[s]);
         if (X->ptime_ready) for (i = 0; i < 8; ++i) hipEventDestroy(X->ptime[s][i]);
     }
+    for (s = 0; s < X->nq; ++s) {                        /* the chunk pipelines' streams and their lanes (mz_flow.c) */
+        for (i = 0; i < X->qlane[s].n; ++i) {
+            hipStreamSynchronize((hipStream_t)X->qlane[s].stream[i]); hipStreamDestroy((hipStream_t)X->qlane[s].stream[i]);
+            hipEventDestroy((hipEvent_t)X->qlane[s].join[i]);
+        }
+        if (X->qlane[s].n) hipEventDestroy((hipEvent_t)X->qlane[s].fork);
+        hipStreamSynchronize(X->qd[s]); hipStreamDestroy(X->qd[s]); X->qd[s] = NULL;
+    }
+    for (s = 0; s < X->nf; ++s) { hipStreamSynchronize(X->qf[s]); hipStreamDestroy(X->qf[s]); X->qf[s] = NULL; }
+    for (s = 0; s < X->nt; ++s) { hipStreamSynchronize(X->qt[s]); hipStreamDestroy(X->qt[s]); X->qt[s] = NULL; }
+    X->nq = X->nf = X->nt = 0;
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);
     for (i = 0; i < MZ_WS_MAX; ++i) if (X->ws[i].used) { hipEventDestroy(X->ws[i].done); X->ws[i].used = 0; }

@@ -1,5 +1,8 @@
-/* mz_pool.c -- the host threads of the batch pipeline (mz_batch.c): one process-wide pool of sleeping workers and a
- * parallel-for that several threads may call at once (the packer and the collector of every GPU's pipeline do).
+/* mz_pool.c -- the host threads of the batch pipeline (mz_batch.c): one process-wide pool of sleeping workers, a
+ * parallel-for that several threads may call at once, and -- round 5 -- loops that are POSTED and not waited for
+ * (mzi_post): the chunk pipeline (mz_flow.c) posts the packing of chunk k+1 while chunk k's is still being worked on and
+ * the assembling of chunk k-3 beside both, so the workers go from piece to piece without a barrier per chunk, and the
+ * calling thread works with them (mzi_help_until) instead of waiting.
  *
  * Why not OpenMP here: a libgomp team spins after every parallel region (GOMP_SPINCOUNT), two or three teams of 24
  * spinning threads burn a container's CPU quota in tens of milliseconds (the GPU boxes of this project give a job
@@ -17,12 +20,10 @@
 
 #include "mz_ctx.h"
 
-typedef struct pjob {
-    mz_pfn fn;
-    void *ctx;
-    int n, grain, next, pending;
-    struct pjob *link;
-} pjob;
+/* (a job is an mz_ajob: mz_ctx.h.  `done` == NULL: somebody waits for it in mzi_parallel_for(); else the thread that
+ * finishes its last piece calls done(arg), outside the pool's lock.  A job leaves the list when its last piece is HANDED
+ * OUT, so the list only ever holds jobs that still have pieces) */
+typedef mz_ajob pjob;
 
 #define POOL_MAX 64
 static struct {
@@ -61,13 +62,31 @@ int mzi_cpu_budget(void)
     return cpus;
 }
 
-static int grab(pjob *j, int *lo, int *hi)
+/* the next piece of the oldest job that has one (pool lock held); the job leaves the list with its last piece */
+static pjob *grab_any(int *lo, int *hi)
 {
-    if (j->next >= j->n) return 0;
+    pjob *j = g_pool.head;
+    if (!j) return NULL;
     *lo = j->next;
     *hi = j->next + j->grain < j->n ? j->next + j->grain : j->n;
     j->next = *hi;
-    return 1;
+    if (j->next >= j->n) { g_pool.head = j->link; j->link = NULL; }
+    return j;
+}
+
+/* a piece [lo, hi) of j has been run (pool lock held on entry and on return; released around a posted job's callback) */
+static void piece_done(pjob *j, int lo, int hi)
+{
+    j->pending -= hi - lo;
+    if (j->pending > 0) return;
+    if (!j->done) { pthread_cond_broadcast(&g_pool.done); return; }
+    {
+        void (*done)(void *) = j->done;
+        void *arg = j->arg;
+        pthread_mutex_unlock(&g_pool.mu);                /* (the callback may free or re-post the job) */
+        done(arg);
+        pthread_mutex_lock(&g_pool.mu);
+    }
 }
 
 /* jobs posted so far: with MZ_POOL_SPIN_US=<n> a worker that has run out of work watches this for n microseconds before
@@ -83,8 +102,7 @@ static void *pool_worker(void *arg)
     while (!g_pool.quit) {
         pjob *j;
         int lo, hi;
-        for (j = g_pool.head; j && j->next >= j->n; j = j->link) ;
-        if (!j) {
+        if (!(j = grab_any(&lo, &hi))) {
             if (g_spin_us > 0) {
                 const unsigned seen = __atomic_load_n(&g_posted, __ATOMIC_RELAXED);
                 struct timespec t0, t1;
@@ -99,19 +117,16 @@ static void *pool_worker(void *arg)
                 }
                 pthread_mutex_lock(&g_pool.mu);
                 if (g_pool.quit) break;
-                for (j = g_pool.head; j && j->next >= j->n; j = j->link) ;
-                if (j) goto work;
+                if ((j = grab_any(&lo, &hi))) goto work;
             }
             pthread_cond_wait(&g_pool.work, &g_pool.mu);
             continue;
         }
 work:
-        grab(j, &lo, &hi);
         pthread_mutex_unlock(&g_pool.mu);
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
-        j->pending -= hi - lo;
-        if (j->pending == 0) pthread_cond_broadcast(&g_pool.done);
+        piece_done(j, lo, hi);
     }
     pthread_mutex_unlock(&g_pool.mu);
     return NULL;
@@ -146,31 +161,74 @@ int mzi_pool_threads(void)
     return n;
 }
 
+static void enqueue(pjob *job)                            /* (pool lock held) jobs in arrival order: the older chunk first */
+{
+    pjob **pp;
+    job->next = 0; job->pending = job->n; job->link = NULL;
+    if (!g_pool.started) pool_start_locked();
+    for (pp = &g_pool.head; *pp; pp = &(*pp)->link) ;
+    *pp = job;
+    __atomic_fetch_add(&g_posted, 1u, __ATOMIC_RELEASE);
+    pthread_cond_broadcast(&g_pool.work);
+}
+
 /* fn(ctx, lo, hi) over [0, n) in pieces of `grain`, on the pool's workers and the calling thread; returns when every
  * piece is done.  Small loops run in the caller alone. */
 void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx)
 {
-    pjob job, **pp;
-    int lo, hi;
+    pjob job;
     if (n <= 0) return;
     if (grain < 1) grain = 1;
     if (n <= grain) { fn(ctx, 0, n); return; }
-    job.fn = fn; job.ctx = ctx; job.n = n; job.grain = grain; job.next = 0; job.pending = n; job.link = NULL;
+    memset(&job, 0, sizeof job);
+    job.fn = fn; job.ctx = ctx; job.n = n; job.grain = grain;
     pthread_mutex_lock(&g_pool.mu);
-    if (!g_pool.started) pool_start_locked();
-    for (pp = &g_pool.head; *pp; pp = &(*pp)->link) ;       /* jobs in arrival order: the older chunk first */
-    *pp = &job;
-    __atomic_fetch_add(&g_posted, 1u, __ATOMIC_RELEASE);
-    pthread_cond_broadcast(&g_pool.work);
-    while (grab(&job, &lo, &hi)) {
+    enqueue(&job);
+    while (job.next < job.n) {                               /* the caller works on ITS loop (older jobs are the workers') */
+        const int lo = job.next, hi = lo + grain < n ? lo + grain : n;
+        job.next = hi;
+        if (hi >= n) { pjob **pp; for (pp = &g_pool.head; *pp != &job; pp = &(*pp)->link) ; *pp = job.link; job.link = NULL; }
         pthread_mutex_unlock(&g_pool.mu);
         fn(ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
         job.pending -= hi - lo;
     }
     while (job.pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
-    for (pp = &g_pool.head; *pp != &job; pp = &(*pp)->link) ;
-    *pp = job.link;
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* The same loop, not waited for: returns at once; job->done(job->arg) is called -- by whichever thread finishes the last
+ * piece -- when all of [0, n) has been run.  The job must stay where it is until then.  n == 0: done() is called here. */
+void mzi_post(mz_ajob *job)
+{
+    if (job->grain < 1) job->grain = 1;
+    if (job->n <= 0) { if (job->done) job->done(job->arg); return; }
+    pthread_mutex_lock(&g_pool.mu);
+    enqueue(job);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+/* The calling thread works on posted pieces until ready(arg) says so.  `ready` is evaluated under the pool's lock and
+ * must not take any other; whoever makes it true calls mzi_pool_kick() afterwards, so a helper asleep for want of
+ * pieces is woken. */
+void mzi_help_until(int (*ready)(void *), void *arg)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    while (!ready(arg)) {
+        pjob *j;
+        int lo, hi;
+        if (!(j = grab_any(&lo, &hi))) { pthread_cond_wait(&g_pool.work, &g_pool.mu); continue; }
+        pthread_mutex_unlock(&g_pool.mu);
+        j->fn(j->ctx, lo, hi);
+        pthread_mutex_lock(&g_pool.mu);
+        piece_done(j, lo, hi);
+    }
+    pthread_mutex_unlock(&g_pool.mu);
+}
+void mzi_pool_kick(void)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    pthread_cond_broadcast(&g_pool.work);
     pthread_mutex_unlock(&g_pool.mu);
 }
 

@@ -11,16 +11,17 @@
  *          band is derived on the device (k_pre: the shared reference row walked base by base, then smooth());
  *   back   a 48-byte record per merge (status, M, N, OM, score), the bases per row, and per merged column one bit per
  *          row group (k_fin) -- the ROWS are put together here, from the caller's own text (mz_assemble_rows);
- *   pipe   a call is cut into chunks that go through four stages on MZ_SETS rotating sets of buffers and streams:
- *            packer     (the calling thread)  classes into pinned memory on the pool's threads; copy, k_unnib, k_pre,
- *                                             the first plan and the copy of its totals;
- *            launcher 1 (helper thread)       waits for the totals, sizes the workspaces, issues DP / walk / emit; for
+ *   pipe   a call is cut into chunks that go through the chunk pipeline of mz_flow.c on MZ_SETS rotating sets of buffers,
+ *          chunk k on chunk stream k % nq, its link traffic as kernels of that stream (mzk_link_copy):
+ *            cut        (the calling thread)  lays the chunk out; its packing -- classes into pinned memory -- is a loop
+ *                                             posted to the pool's threads, among which the caller works;
+ *            sender     (stage thread)        staging block -> device, k_unnib, k_pre, the first plan, its totals -> host;
+ *            launcher 1 (stage thread)        waits for the totals, sizes the workspaces, issues DP / walk / emit; for
  *                                             chunks with two-stage merges k_mid and the second plan, else k_fin;
- *            launcher 2 (helper thread)       chunks with two-stage merges: waits for the second plan's totals, issues
+ *            launcher 2 (stage thread)        chunks with two-stage merges: waits for the second plan's totals, issues
  *                                             the second DP / walk / emit and k_fin;
- *            collector  (helper thread)       waits for k_fin, copies the results back (a copy is only ever issued when
- *                                             what it copies is ready: the copy engine takes its commands in order), takes
- *                                             ONE block for the chunk's rows and assembles them on the pool's threads.
+ *            collector  (stage thread)        waits for the chunk's last kernel (the results -> host copy), takes ONE block
+ *                                             for the chunk's rows; the assembling is a loop posted to the pool.
  *          No stage waits for a copy or a kernel another stage could work beside.  A call of one chunk runs inline.
  */
 #include <limits.h>
@@ -34,18 +35,26 @@
 #include "mz_pack.h"
 #include "../../include/mz_scores.h"
 
+typedef struct ppack { const mz_prejob *jobs; const int64_t *hoT1; uint8_t *hTxt; } ppack;
+struct pasm;
+
 typedef struct pchunk {
     mz_ctx *X;
-    int set, n, index, any0;
+    int set, n, index, any0, lane;         /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk) */
     const mz_prejob *jobs;
     mz_preout *outs;
     mz_dev_batch b, b2;
     mz_pre_batch q;
     mz_fin_batch f;
+    ppack pc;
+    const uint8_t *dNib;
+    size_t txt, nrow_res;
+    struct pasm *a;
+    size_t *where;
     const int64_t *hoRow, *hoMask;         /* host copies (inside the set's pinned staging block) */
     size_t nrow, mask_bytes, in_bytes, res_bytes;
     int64_t cells;
-    double t_pack0, t_pack1, t_up, t_l1a, t_l1b, t_l2a, t_l2b, t_col0, t_col1, t_col2;
+    double t_pack0, t_pack1, t_packed, t_up, t_l1a, t_l1b, t_l2a, t_l2b, t_col0, t_col1, t_col2;
 } pchunk;
 
 static size_t row_stride(int cols) { return ((size_t)cols + 63) & ~(size_t)63; }
@@ -63,8 +72,6 @@ static int pre_grain(int n)
     return g < 1 ? 1 : g > 64 ? 64 : g;
 }
 
-typedef struct ppack { const mz_prejob *jobs; const int64_t *hoT1; uint8_t *hTxt; } ppack;
-
 static void pack_text(void *ctx, int lo, int hi)
 {
     const ppack *q = (const ppack *)ctx;
@@ -80,26 +87,19 @@ static void pack_text(void *ctx, int lo, int hi)
     _mm_sfence();
 }
 
-/* The chunks' streams: MZ_SETS buffer sets rotate, but their kernels go round MZ_STREAMS streams (default 4) -- the HIP runtime
- * maps streams onto a few hardware queues, and two streams that share one run in each other's order: with a stream per set (ten,
- * beside the DP kernels' side streams) a chunk's upload was seen waiting for the kernels of an unrelated chunk. */
-static int pre_streams(void)
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MZ_STREAMS"); v = e && atoi(e) > 0 ? atoi(e) : 4; if (v > MZ_SETS) v = MZ_SETS; }
-    return v;
-}
-#define PSTREAM(X, set) ((X)->bstream[(set) % pre_streams()])
+/* the chunk's streams (mz_ctx.h): front (staging block -> device, k_pre, plan), DP, tail (walk, emit, k_mid + second plan, k_fin, results -> host) */
+static hipStream_t pchunk_front(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qf[c->index % c->X->nf]; }
+static hipStream_t pchunk_dp(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qd[c->lane]; }
+static hipStream_t pchunk_tail(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qt[c->index % c->X->nt]; }
 static int g_ptiming = -1;
 #define PSTAMP(X, set, k, st) do { if (g_ptiming >= 2 && (X)->ptime_ready) HIPCK(hipEventRecord((X)->ptime[set][k], st)); } while (0)
 #define PD(i) (&X->pd[set][i])
 #define PH(i) (&X->ph[set][i])
 
-/* stage 1 (the caller): pack, copy, expand, k_pre, plan */
-static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const mz_prejob *jobs, mz_preout *outs)
+/* the calling thread: chunk `index` = the n merges at `jobs`, laid out in buffer set `set`; its packing as a loop (*pack) */
+static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n, const mz_prejob *jobs, mz_preout *outs, mz_ajob *pack)
 {
-    hipStream_t st;
-    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, nmask = 0, hdr, in_bytes, lds16 = 0, lds32 = 0, res_bytes;
+    size_t txt = 0, szA = 0, szB = 0, szA2 = 0, nband = 0, nscr = 0, nrow = 0, nmask = 0, nprep = 0, nprep2 = 0, hdr, in_bytes, lds16 = 0, lds32 = 0, res_bytes;
     int wmax = 1, cmax = 0;
     int64_t *hT1, *hoA, *hoB, *hoBand, *hoScr, *hoRow, *hoA2, *hoMask;
     int32_t *hK, *hL, *hMa, *hNa, *hRad, *hV;
@@ -109,16 +109,15 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
     int p, any0 = 0;
 
     c->t_pack0 = mzi_now_s();
-    if (mzi_lazy_stream(&PSTREAM(X, set))) return -1;
-    st = PSTREAM(X, set);
-    c->X = X; c->set = set; c->index = index; c->n = n; c->jobs = jobs; c->outs = outs;
+    c->X = X; c->set = set; c->index = index; c->lane = lane; c->n = n; c->jobs = jobs; c->outs = outs; c->cells = 0;
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
         txt += text_bytes(j);
         szA += (size_t)j->K * j->M_all; szB += (size_t)(j->L1 - 1) * j->N_all; szA2 += (size_t)j->M_all + 8;
         nband += (size_t)j->M_all + 1; nscr += 8 * ((size_t)j->M_all + 2) + 6 * ((size_t)j->N_all + 2);
         nrow += (size_t)j->K + j->L1 - 1; nmask += mask_block(j);
-        if (j->v == 0) any0 = 1;
+        nprep += MZ_PREP_BOUND(j->N_all);                                       /* (the first yama(): at most N_all columns) */
+        if (j->v == 0) { any0 = 1; nprep2 += MZ_PREP_BOUND((size_t)j->M_all + j->N_all); }    /* (the second: its B is the first one's result) */
         {   /* what k_pre would need of LDS for this pair (int16 / int32 scratch), the widest merged block, the longest slice */
             const int W = j->K + j->L1 - 1;
             const size_t a = MZ_PRE_LDS(text_bytes(j), j->M_all, j->N_all, W, 2), b32 = MZ_PRE_LDS(text_bytes(j), j->M_all, j->N_all, W, 4);
@@ -141,7 +140,7 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
         c->q.lds_bytes = !lds_on ? 0 : c->q.lds16 ? (lds16 <= 65536 ? (int)lds16 : 0) : (lds32 <= 65536 ? (int)lds32 : 0);
         if (c->q.lds16 && !c->q.lds_bytes && lds_on && lds32 <= 65536) { c->q.lds16 = 0; c->q.lds_bytes = (int)lds32; }
     }
-    res_bytes = 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256(nmask);
+    res_bytes = mzi_al256(64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n) + mzi_al256(4 * nrow) + mzi_al256(nmask));
     if (mzi_host_reserve(PH(MZ_PH_IN), in_bytes) || mzi_dev_reserve(PD(MZ_PD_IN), in_bytes) || (!c->q.lds_bytes && mzi_dev_reserve(PD(MZ_PD_TXT), txt + 256)) ||
         mzi_dev_reserve(PD(MZ_PD_RES), res_bytes) || mzi_host_reserve(PH(MZ_PH_RES), res_bytes) ||
         mzi_dev_reserve(PD(MZ_PD_COLS), mzi_al256(szA) + mzi_al256(szB) + 256) || mzi_dev_reserve(PD(MZ_PD_BAND), 2 * mzi_al256(4 * nband)) ||
@@ -177,21 +176,10 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
             hoMask[p] = (int64_t)om; om += mask_block(j);
         }
     }
-    {
-        ppack pc;
-        pc.jobs = jobs; pc.hoT1 = hT1; pc.hTxt = hTxt;
-        mzi_parallel_for(n, pre_grain(n), pack_text, &pc);
-    }
-    c->t_pack1 = mzi_now_s();
     c->hoRow = hoRow; c->hoMask = hoMask; c->nrow = nrow; c->mask_bytes = nmask; c->in_bytes = in_bytes; c->any0 = any0;
-    PSTAMP(X, set, 0, st);
-    HIPCK(hipMemcpyAsync(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, in_bytes, hipMemcpyHostToDevice, st));
-    PSTAMP(X, set, 1, st);
+    c->dNib = dNib; c->txt = txt;
     c->q.nib = dNib; c->q.stride64 = 1;
-    if (!c->q.lds_bytes) {
-        if (mzk_unnib(dNib, PD(MZ_PD_TXT)->p, (long long)txt, st)) return mzi_set_err("%s", mzk_last_error());
-        c->q.txt = (const uint8_t *)PD(MZ_PD_TXT)->p;
-    }
+    if (!c->q.lds_bytes) c->q.txt = (const uint8_t *)PD(MZ_PD_TXT)->p;
     {   /* the results' device image: 64-byte header, a record per merge, bases per row, the mask blocks (k_pre fills in the
          * counts and rmColDash's verdicts, k_fin the rest) */
         char *dres = (char *)PD(MZ_PD_RES)->p;
@@ -201,7 +189,6 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
         c->f.masks = (uint8_t *)c->f.size + mzi_al256(4 * nrow);
         c->f.cols = MZ_FIN_COLS(wmax); c->f.lds_bytes = MZ_FIN_LDS(wmax);
         c->res_bytes = res_bytes;
-        if (!c->q.lds_bytes) HIPCK(hipMemsetAsync(c->f.size, 0, 4 * nrow, st));      /* (the LDS-free k_pre adds the row counts up in place) */
     }
     c->b.poolA = (const uint8_t *)PD(MZ_PD_COLS)->p; c->b.poolB = c->b.poolA + mzi_al256(szA);
     c->b.poolLB = (const int32_t *)PD(MZ_PD_BAND)->p; c->b.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND)->p + mzi_al256(4 * nband));
@@ -222,30 +209,58 @@ static int pchunk_upload(mz_ctx *X, pchunk *c, int index, int set, int n, const 
         c->b2.poolLB = (const int32_t *)PD(MZ_PD_BAND2)->p; c->b2.poolRB = (const int32_t *)((char *)PD(MZ_PD_BAND2)->p + mzi_al256(4 * nband));
         c->b2.offBand = c->b.offBand;
     }
+    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t)) ||
+        mzi_dev_reserve(&X->d_prep[set], 4 * nprep + 256) || (any0 && mzi_dev_reserve(PD(MZ_PD_PREP2), 4 * nprep2 + 256))) return -1;
+    mz_dev_carve(&c->b, X->d_plan[set].p);
+    c->b.capTb = c->b.capScript = c->b.capOut = INT64_MAX;
+    /* (the prep records' size is bounded by the slices' columns: MZ_PREP_BOUND -- they are made right behind the plan) */
+    c->b.prep = (uint32_t *)X->d_prep[set].p; c->b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
+    c->pc.jobs = jobs; c->pc.hoT1 = hT1; c->pc.hTxt = hTxt;
+    pack->fn = pack_text; pack->ctx = &c->pc; pack->n = n; pack->grain = pre_grain(n);
+    c->t_pack1 = mzi_now_s();
+    return 0;
+}
+
+/* stage 1: the chunk is packed -- staging block -> device (a kernel on the chunk's stream), k_unnib where the text does not fit
+ * the LDS, k_pre, the first plan, its totals -> host */
+static int pchunk_send(pchunk *c)
+{
+    mz_ctx *X = c->X;
+    const int set = c->set;
+    hipStream_t st = pchunk_front(c);
+    c->t_packed = mzi_now_s();
+    PSTAMP(X, set, 0, st);
+    if (mzk_link_copy(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, mzi_al256(c->in_bytes), st)) return mzi_set_err("%s", mzk_last_error());
+    PSTAMP(X, set, 1, st);
+    if (!c->q.lds_bytes) {
+        if (mzk_unnib(c->dNib, PD(MZ_PD_TXT)->p, (long long)c->txt, st)) return mzi_set_err("%s", mzk_last_error());
+        HIPCK(hipMemsetAsync(c->f.size, 0, 4 * c->nrow, st));      /* (the LDS-free k_pre adds the row counts up in place) */
+    }
     if (mzk_pre(&c->q, &c->f, &c->b, st)) return mzi_set_err("%s", mzk_last_error());
     PSTAMP(X, set, 2, st);
-    if (mzi_dev_reserve(&X->d_plan[set], mz_dev_plan_bytes(n)) || mzi_host_reserve(&X->h_tot[set], 16 * sizeof(int64_t))) return -1;
-    mz_dev_carve(&c->b, X->d_plan[set].p);
-    c->b.capTb = c->b.capScript = c->b.capOut = c->b.capPrep = INT64_MAX;
-    if (mzk_plan(&c->b, st)) return mzi_set_err("%s", mzk_last_error());
-    HIPCK(hipMemcpyAsync(X->h_tot[set].p, c->b.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    PSTAMP(X, set, 3, st);
+    if (mzk_plan(&c->b, st) || mzk_link_copy(X->h_tot[set].p, c->b.totals, 16 * sizeof(int64_t), st)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(X->bplan[set], st));
+    if (mzk_prep(&c->b, st)) return mzi_set_err("%s", mzk_last_error());
+    HIPCK(hipEventRecord(X->bprep[set], st));
+    PSTAMP(X, set, 3, st);
     c->t_up = mzi_now_s();
     return 0;
 }
 
-/* size one stage's workspaces from its plan's totals and issue prep / DP / walk / emit */
-static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t st, mz_dev_batch *b, int n, const int64_t *totals, gbuf *tb, gbuf *script, gbuf *prep, gbuf *out)
+/* size one stage's workspaces from its plan's totals and issue DP / walk / emit (the prep records were made behind the plan: bprep) */
+static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t sd, hipStream_t st, int wait_prep, const mz_dp_lanes *lanes, mz_dev_batch *b, int n, const int64_t *totals, gbuf *tb, gbuf *script, gbuf *out)
 {
     if (mzi_dev_reserve(tb, 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(script, (size_t)totals[1] + 256) ||
-        mzi_dev_reserve(out, (size_t)totals[2] + 256) || mzi_dev_reserve(prep, 4 * (size_t)totals[4] + 256)) return -1;
-    b->tbw = (uint32_t *)tb->p; b->script = (uint8_t *)script->p; b->out = (uint8_t *)out->p; b->prep = (uint32_t *)prep->p;
-    b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap; b->capPrep = (int64_t)(prep->cap / 4);
+        mzi_dev_reserve(out, (size_t)totals[2] + 256)) return -1;
+    b->tbw = (uint32_t *)tb->p; b->script = (uint8_t *)script->p; b->out = (uint8_t *)out->p;
+    b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap;
     b->walk_hint = mz_walk_choice(n, totals);
     b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
-    if (mzk_prep(b, st) || mzk_dp(b, st)) return mzi_set_err("%s", mzk_last_error());
-    if (stamp >= 0) PSTAMP(X, set, stamp, st);
+    /* the DP on the slot's DP stream (whatever else it reads is through: the host has seen this plan's totals), the rest behind its event */
+    if (wait_prep) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));
+    if (mzk_dp_range_on(b, 0, n, sd, lanes)) return mzi_set_err("%s", mzk_last_error());
+    if (stamp >= 0) PSTAMP(X, set, stamp, sd);
+    if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
     if (mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
     if (stamp >= 0) PSTAMP(X, set, stamp + 1, st);
     return 0;
@@ -256,13 +271,13 @@ static int pchunk_finish(pchunk *c)
 {
     mz_ctx *X = c->X;
     const int set = c->set;
-    hipStream_t st = PSTREAM(X, set);
+    hipStream_t st = pchunk_tail(c);
     PSTAMP(X, set, 6, st);
     if (mzk_fin(&c->q, &c->f, &c->b, &c->b2, st)) return mzi_set_err("%s", mzk_last_error());
     PSTAMP(X, set, 7, st);
-    /* The copy of the results is NOT issued here: the copy engine takes its commands in order, and a copy that has to wait
-     * for this chunk's kernels would hold up the uploads of the chunks behind it (measured: the H2D of chunk k+3 started when
-     * the results of chunk k were through, the GPU idling in between).  The collector issues it once k_fin is done. */
+    /* the results go home as the chunk's last kernel (round 4 had the collector issue a copy once k_fin was done: a copy engine
+     * takes its commands in order across all streams) */
+    if (mzk_link_copy(PH(MZ_PH_RES)->p, PD(MZ_PD_RES)->p, c->res_bytes, st)) return mzi_set_err("%s", mzk_last_error());
     HIPCK(hipEventRecord(X->bdone[set], st));
     return 0;
 }
@@ -272,20 +287,23 @@ static int pchunk_launch1(pchunk *c)
 {
     mz_ctx *X = c->X;
     const int set = c->set, n = c->n;
-    hipStream_t st = PSTREAM(X, set);
+    hipStream_t st = pchunk_tail(c);
+    const mz_dp_lanes *lanes = c->lane < 0 ? NULL : &X->qlane[c->lane];
     c->t_l1a = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bplan[set]));
-    if (run_stage(X, set, 4, st, &c->b, n, (const int64_t *)X->h_tot[set].p, &X->d_tb[set], &X->d_script[set], &X->d_prep[set], PD(MZ_PD_OUT1))) return -1;
+    if (run_stage(X, set, 4, pchunk_dp(c), st, pchunk_dp(c) != pchunk_front(c), lanes, &c->b, n, (const int64_t *)X->h_tot[set].p, &X->d_tb[set], &X->d_script[set], PD(MZ_PD_OUT1))) return -1;
     if (c->any0) {
         /* the second yama() job of the two-stage merges, derived where the first one's result lies (k_mid) */
         c->b2.poolB = c->b.out;
         if (mzk_mid(&c->q, &c->b, &c->b2, st)) return mzi_set_err("%s", mzk_last_error());
         if (mzi_dev_reserve(PD(MZ_PD_PLAN2), mz_dev_plan_bytes(n)) || mzi_host_reserve(PH(MZ_PH_TOT2), 16 * sizeof(int64_t))) return -1;
         mz_dev_carve(&c->b2, PD(MZ_PD_PLAN2)->p);
-        c->b2.capTb = c->b2.capScript = c->b2.capOut = c->b2.capPrep = INT64_MAX;
-        if (mzk_plan(&c->b2, st)) return mzi_set_err("%s", mzk_last_error());
-        HIPCK(hipMemcpyAsync(PH(MZ_PH_TOT2)->p, c->b2.totals, 16 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        c->b2.capTb = c->b2.capScript = c->b2.capOut = INT64_MAX;
+        c->b2.prep = (uint32_t *)PD(MZ_PD_PREP2)->p; c->b2.capPrep = (int64_t)(PD(MZ_PD_PREP2)->cap / 4);
+        if (mzk_plan(&c->b2, st) || mzk_link_copy(PH(MZ_PH_TOT2)->p, c->b2.totals, 16 * sizeof(int64_t), st)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipEventRecord(X->pplan2[set], st));
+        if (mzk_prep(&c->b2, st)) return mzi_set_err("%s", mzk_last_error());
+        HIPCK(hipEventRecord(X->bprep[set], st));            /* (the first stage's DP has long taken its records) */
     } else if (pchunk_finish(c)) return -1;
     c->t_l1b = mzi_now_s();
     return 0;
@@ -299,7 +317,7 @@ static int pchunk_launch2(pchunk *c)
     c->t_l2a = c->t_l2b = mzi_now_s();
     if (!c->any0) return 0;
     HIPCK(hipEventSynchronize(X->pplan2[set]));
-    if (run_stage(X, set, -1, PSTREAM(X, set), &c->b2, c->n, (const int64_t *)PH(MZ_PH_TOT2)->p, PD(MZ_PD_TB2), PD(MZ_PD_SCRIPT2), PD(MZ_PD_PREP2), PD(MZ_PD_OUT2))) return -1;
+    if (run_stage(X, set, -1, pchunk_dp(c), pchunk_tail(c), pchunk_dp(c) != pchunk_tail(c), c->lane < 0 ? NULL : &X->qlane[c->lane], &c->b2, c->n, (const int64_t *)PH(MZ_PH_TOT2)->p, PD(MZ_PD_TB2), PD(MZ_PD_SCRIPT2), PD(MZ_PD_OUT2))) return -1;
     if (pchunk_finish(c)) return -1;
     c->t_l2b = mzi_now_s();
     return 0;
@@ -374,7 +392,9 @@ static void assemble_merges(void *ctx, int lo, int hi)
     _mm_sfence();
 }
 
-static int pchunk_collect(pchunk *c)
+/* stage 4: wait for the chunk's last kernel (the results are in host memory then), take ONE block for the chunk's rows and base
+ * counts; the assembling itself is the loop *post */
+static int pchunk_collect(pchunk *c, mz_ajob *post)
 {
     mz_ctx *X = c->X;
     const int n = c->n, set = c->set;
@@ -382,16 +402,15 @@ static int pchunk_collect(pchunk *c)
     const mz_pre_rec *rec = (const mz_pre_rec *)(r + 64);
     size_t *where, total = 0;
     uint8_t *block = NULL;
-    pasm a;
+    pasm *a;
     int p;
 
     c->t_col0 = mzi_now_s();
     HIPCK(hipEventSynchronize(X->bdone[set]));
-    /* (on a stream of its own: the chunk's stream already holds the kernels of later chunks) */
-    if (mzi_lazy_stream(&X->stream2)) return -1;
-    HIPCK(hipMemcpyAsync(PH(MZ_PH_RES)->p, PD(MZ_PD_RES)->p, c->res_bytes, hipMemcpyDeviceToHost, X->stream2));
-    HIPCK(hipStreamSynchronize(X->stream2));
     c->t_col1 = mzi_now_s();
+    free(c->where); c->where = NULL;
+    if (!c->a && !(c->a = (pasm *)malloc(sizeof *c->a))) return mzi_set_err("out of memory");
+    a = c->a;
     where = (size_t *)malloc(((size_t)n + 1) * sizeof *where);
     if (!where) return mzi_set_err("out of memory");
     /* ONE allocation for the chunk's rows and base counts; outs[first].block owns it (mz_free_preouts).  Every merge starts on
@@ -409,43 +428,40 @@ static int pchunk_collect(pchunk *c)
         mis = (size_t)(-(intptr_t)block & 63);
         for (p = 0; p < n; ++p) where[p] += mis;
     }
-    a.jobs = c->jobs; a.outs = c->outs; a.rec = rec;
-    a.size = (const int32_t *)(r + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
-    a.masks = (const uint8_t *)a.size + mzi_al256(4 * c->nrow);
-    a.hoRow = c->hoRow; a.hoMask = c->hoMask; a.where = where; a.block = block; a.failed = 0; a.oom = 0; a.cells = 0;
-    mzi_parallel_for(n, pre_grain(n), assemble_merges, &a);
-    c->cells = a.cells;
-    c->outs[0].block = block;
-    free(where);
-    c->t_col2 = mzi_now_s();
-    if (a.oom) return mzi_set_err("out of memory for the merged rows");
-    return a.failed;
+    c->where = where;
+    a->jobs = c->jobs; a->outs = c->outs; a->rec = rec;
+    a->size = (const int32_t *)(r + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
+    a->masks = (const uint8_t *)a->size + mzi_al256(4 * c->nrow);
+    a->hoRow = c->hoRow; a->hoMask = c->hoMask; a->where = where; a->block = block; a->failed = 0; a->oom = 0; a->cells = 0;
+    post->fn = assemble_merges; post->ctx = a; post->n = n; post->grain = pre_grain(n);
+    return 0;
 }
 
-/* ------------------------------------------------------------------------------------------------ the pipeline */
+static int pchunk_done(pchunk *c)
+{
+    const pasm *a = c->a;
+    c->cells = a->cells;
+    c->outs[0].block = a->block;
+    free(c->where); c->where = NULL;
+    c->t_col2 = mzi_now_s();
+    if (a->oom) return mzi_set_err("out of memory for the merged rows");
+    return a->failed;
+}
 
-enum { ST_UP, ST_L1, ST_L2, ST_COL, ST_N };
+/* ------------------------------------------------------------------------------------------------ the pipeline (mz_flow.c) */
+
 typedef struct ppipe {
     mz_ctx *X;
+    int n, up, max_pairs, threaded;
+    size_t max_bytes;
+    const mz_prejob *jobs;
+    mz_preout *outs;
     pchunk ck[MZ_SETS];
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    int through[ST_N];                     /* chunks through each stage */
-    int total;                             /* chunks in all; -1 until the packer has cut the last one */
-    int failed, rc, done;
+    pthread_mutex_t mu;                    /* the sums, the report lines */
     int64_t cells, bytes_up, bytes_down;
     double t0;
     hipEvent_t ev0;                        /* MZ_TIMING=2: recorded on the context's stream when the call starts */
-    char err[600];
 } ppipe;
-
-static void ppipe_abort(ppipe *P)
-{
-    pthread_mutex_lock(&P->mu);
-    if (P->rc >= 0) { P->rc = -1; snprintf(P->err, sizeof P->err, "%s", mz_last_error()); }
-    pthread_cond_broadcast(&P->cv);
-    pthread_mutex_unlock(&P->mu);
-}
 
 static void pchunk_report(const ppipe *P, const pchunk *c)
 {
@@ -454,45 +470,15 @@ static void pchunk_report(const ppipe *P, const pchunk *c)
     if (g_ptiming < 2) return;
     /* GPU time stamps of the chunk's stream against the call's start (ms): upload begins / ends, k_pre done, planned, first DP done,
      * first walk + emit done, k_fin begins / ends */
-    if (c->X->ptime_ready) for (k = 0; k < 8; ++k) hipEventElapsedTime(&g[k], P->ev0, c->X->ptime[c->set][k]);
-    fprintf(stderr, "{\"mz_preyama_batch_chunk\": %d, \"merges\": %d, \"two_stage\": %d, \"cells\": %lld, \"bytes_up\": %zu, \"bytes_down\": %zu, "
-                    "\"host_ms\": {\"pack\": [%.3f, %.3f], \"uploaded\": %.3f, \"launch1\": [%.3f, %.3f], \"launch2\": [%.3f, %.3f], \"result_wait\": [%.3f, %.3f], \"assembled\": %.3f}, "
+    if (c->X->ptime_ready) { hipSetDevice(c->X->device); for (k = 0; k < 8; ++k) hipEventElapsedTime(&g[k], P->ev0, c->X->ptime[c->set][k]); }
+    fprintf(stderr, "{\"mz_preyama_batch_chunk\": %d, \"merges\": %d, \"stream\": %d, \"two_stage\": %d, \"cells\": %lld, \"bytes_up\": %zu, \"bytes_down\": %zu, "
+                    "\"host_ms\": {\"cut\": [%.3f, %.3f], \"packed\": %.3f, \"sent\": %.3f, \"launch1\": [%.3f, %.3f], \"launch2\": [%.3f, %.3f], \"result_wait\": [%.3f, %.3f], \"assembled\": %.3f}, "
                     "\"gpu_ms\": {\"h2d\": [%.3f, %.3f], \"pre_done\": %.3f, \"planned\": %.3f, \"dp_done\": %.3f, \"emit_done\": %.3f, \"fin\": [%.3f, %.3f]}}\n",
-            c->index, c->n, c->any0, (long long)c->cells, c->in_bytes, c->res_bytes,
-            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_up - P->t0), 1e3 * (c->t_l1a - P->t0), 1e3 * (c->t_l1b - P->t0),
+            c->index, c->n, c->lane, c->any0, (long long)c->cells, c->in_bytes, c->res_bytes,
+            1e3 * (c->t_pack0 - P->t0), 1e3 * (c->t_pack1 - P->t0), 1e3 * (c->t_packed - P->t0), 1e3 * (c->t_up - P->t0), 1e3 * (c->t_l1a - P->t0), 1e3 * (c->t_l1b - P->t0),
             1e3 * (c->t_l2a - P->t0), 1e3 * (c->t_l2b - P->t0), 1e3 * (c->t_col0 - P->t0), 1e3 * (c->t_col1 - P->t0), 1e3 * (c->t_col2 - P->t0),
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
 }
-
-/* stage s = ST_L1, ST_L2, ST_COL: for chunk k = 0, 1, ...: wait until the stage before is through with it, do this one's part */
-static void stage_loop(ppipe *P, int s)
-{
-    int k;
-    hipSetDevice(P->X->device);
-    for (k = 0;; ++k) {
-        pchunk *c = &P->ck[k % MZ_SETS];
-        int rc;
-        pthread_mutex_lock(&P->mu);
-        while (P->rc >= 0 && P->through[s - 1] <= k && (P->total < 0 || k < P->total)) pthread_cond_wait(&P->cv, &P->mu);
-        if (P->rc < 0 || (P->total >= 0 && k >= P->total)) { pthread_mutex_unlock(&P->mu); break; }
-        pthread_mutex_unlock(&P->mu);
-        rc = s == ST_L1 ? pchunk_launch1(c) : s == ST_L2 ? pchunk_launch2(c) : pchunk_collect(c);
-        if (rc < 0) { ppipe_abort(P); break; }
-        if (s == ST_COL) pchunk_report(P, c);
-        pthread_mutex_lock(&P->mu);
-        if (s == ST_COL) { P->failed += rc; P->cells += c->cells; P->bytes_up += (int64_t)c->in_bytes; P->bytes_down += (int64_t)c->res_bytes; }
-        P->through[s] = k + 1;
-        pthread_cond_broadcast(&P->cv);
-        pthread_mutex_unlock(&P->mu);
-    }
-    pthread_mutex_lock(&P->mu);                          /* the last thing a stage does with the pipe */
-    P->done++;
-    pthread_cond_broadcast(&P->cv);
-    pthread_mutex_unlock(&P->mu);
-}
-static void stage_l1(void *P) { stage_loop((ppipe *)P, ST_L1); }
-static void stage_l2(void *P) { stage_loop((ppipe *)P, ST_L2); }
-static void stage_col(void *P) { stage_loop((ppipe *)P, ST_COL); }
 
 /* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides): twelve, as mz_yama_batch() -- four when most of the merges are
  * two-stage ones: a chunk of those goes through two plans and two sets of DP / walk / emit, every stage with its wait for the stage
@@ -517,21 +503,52 @@ static int next_pchunk(const mz_prejob *jobs, int n, int first, int limit, size_
     return m;
 }
 
+static int p_cut(void *self, int k, int set, mz_ajob *pack)
+{
+    ppipe *P = (ppipe *)self;
+    /* the first chunks are a quarter and a half of the size: the GPU starts that much earlier */
+    const int ramp = P->threaded && k < 2 && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) ? 2 - k : 0;
+    const int limit = P->max_pairs >> ramp < PRE_MIN_CHUNK / 2 ? PRE_MIN_CHUNK / 2 : P->max_pairs >> ramp;
+    int m;
+    if (P->up >= P->n) return 0;
+    m = next_pchunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp);
+    if (pchunk_cut(P->X, &P->ck[set], k, set, P->threaded ? k % P->X->nq : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    P->up += m;
+    return 1;
+}
+static int p_send(void *self, int k, int set, mz_ajob *post) { (void)k; (void)post; return pchunk_send(&((ppipe *)self)->ck[set]); }
+static int p_l1(void *self, int k, int set, mz_ajob *post) { (void)k; (void)post; return pchunk_launch1(&((ppipe *)self)->ck[set]); }
+static int p_l2(void *self, int k, int set, mz_ajob *post) { (void)k; (void)post; return pchunk_launch2(&((ppipe *)self)->ck[set]); }
+static int p_collect(void *self, int k, int set, mz_ajob *post) { (void)k; return pchunk_collect(&((ppipe *)self)->ck[set], post); }
+static int p_finish(void *self, int k, int set)
+{
+    ppipe *P = (ppipe *)self;
+    pchunk *c = &P->ck[set];
+    const int failed = pchunk_done(c);
+    (void)k;
+    pthread_mutex_lock(&P->mu);
+    pchunk_report(P, c);
+    P->cells += c->cells; P->bytes_up += (int64_t)c->in_bytes; P->bytes_down += (int64_t)c->res_bytes;
+    pthread_mutex_unlock(&P->mu);
+    return failed;
+}
+
 /* A call's share of one GPU, any size: MZ_SETS chunks at most are in flight.  stats: cells, bytes up, bytes down. */
 int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int64_t stats[3])
 {
     ppipe *P;
+    mz_flow *F;
     size_t max_bytes = 0;
-    int k = 0, up = 0, rc = 0, s, threaded, max_pairs, two_stage = 0, parts;
+    int rc, s, max_pairs, two_stage = 0, parts;
     static int env_pairs = -1;
 
     if (env_pairs < 0) { const char *e = getenv("MZ_CHUNK_PAIRS"); env_pairs = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
     P = (ppipe *)calloc(1, sizeof *P);
-    if (!P) return mzi_set_err("out of memory");
-    P->X = X; P->total = -1; P->t0 = mzi_now_s();
+    F = (mz_flow *)calloc(1, sizeof *F);
+    if (!P || !F) { free(P); free(F); return mzi_set_err("out of memory"); }
+    P->X = X; P->n = n; P->jobs = jobs; P->outs = outs; P->t0 = mzi_now_s();
     pthread_mutex_init(&P->mu, NULL);
-    pthread_cond_init(&P->cv, NULL);
     if (g_ptiming >= 2) {
         if (!X->ptime_ready) {
             int a, e, ok = 1;
@@ -550,52 +567,18 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
         const int per = (n + parts - 1) / parts;
         max_pairs = env_pairs ? env_pairs : per < PRE_MIN_CHUNK ? PRE_MIN_CHUNK : per > 16384 ? 16384 : per;
     }
-    threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes) < n && mzi_workers_start(X->pworker, 3) == 0;
-    if (!threaded) {
-        while (up < n) {
-            pchunk *c = &P->ck[0];
-            const int m = next_pchunk(jobs, n, up, max_pairs, max_bytes);
-            int f;
-            if (pchunk_upload(X, c, k, 0, m, jobs + up, outs + up) < 0 || pchunk_launch1(c) < 0 || pchunk_launch2(c) < 0 || (f = pchunk_collect(c)) < 0) { rc = -1; break; }
-            pchunk_report(P, c);
-            P->cells += c->cells; P->bytes_up += (int64_t)c->in_bytes; P->bytes_down += (int64_t)c->res_bytes;
-            P->failed += f; up += m; ++k;
-        }
-        if (rc >= 0) rc = P->failed;
-    } else {
-        mzi_worker_give(&X->pworker[0], stage_l1, P);
-        mzi_worker_give(&X->pworker[1], stage_l2, P);
-        mzi_worker_give(&X->pworker[2], stage_col, P);
-        while (up < n) {
-            const int first_half = k == 0 && (max_pairs >= 2048 || max_bytes >= ((size_t)32 << 20));   /* the GPU starts that much earlier */
-            int m, bad;
-            pthread_mutex_lock(&P->mu);
-            while (P->rc >= 0 && k - P->through[ST_COL] >= MZ_SETS) pthread_cond_wait(&P->cv, &P->mu);    /* its buffer set is still in use */
-            bad = P->rc < 0;
-            pthread_mutex_unlock(&P->mu);
-            if (bad) break;
-            m = next_pchunk(jobs, n, up, first_half ? (max_pairs + 1) / 2 : max_pairs, first_half ? max_bytes / 2 : max_bytes);
-            if (pchunk_upload(X, &P->ck[k % MZ_SETS], k, k % MZ_SETS, m, jobs + up, outs + up) < 0) { ppipe_abort(P); break; }
-            up += m; ++k;
-            pthread_mutex_lock(&P->mu);
-            P->through[ST_UP] = k;
-            pthread_cond_broadcast(&P->cv);
-            pthread_mutex_unlock(&P->mu);
-        }
-        pthread_mutex_lock(&P->mu);
-        P->total = k;
-        pthread_cond_broadcast(&P->cv);
-        while (P->done < 3) pthread_cond_wait(&P->cv, &P->mu);
-        rc = P->rc < 0 ? -1 : P->failed;
-        pthread_mutex_unlock(&P->mu);
-        if (rc < 0) mzi_set_err("%s", P->err);
-    }
-    if (rc < 0) { for (s = 0; s < MZ_SETS; ++s) if (X->bstream[s]) hipStreamSynchronize(X->bstream[s]); if (X->stream2) hipStreamSynchronize(X->stream2); }
+    P->max_pairs = max_pairs; P->max_bytes = max_bytes;
+    P->threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes) < n;
+    F->X = X; F->self = P; F->nstage = 4; F->threaded = P->threaded;
+    F->cut = p_cut; F->stage[0] = p_send; F->stage[1] = p_l1; F->stage[2] = p_l2; F->stage[3] = p_collect; F->finish = p_finish;
+    if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }
+    rc = mzi_flow_run(F);
+    if (rc < 0) mzi_flow_sync(X);
+    for (s = 0; s < MZ_SETS; ++s) { free(P->ck[s].a); free(P->ck[s].where); }
     if (stats) { stats[0] += P->cells; stats[1] += P->bytes_up; stats[2] += P->bytes_down; }
     if (g_ptiming >= 2 && X->ptime_ready) hipEventDestroy(P->ev0);
     pthread_mutex_destroy(&P->mu);
-    pthread_cond_destroy(&P->cv);
-    free(P);
+    free(P); free(F);
     return rc;
 }
 
