@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # The pipelined form keeps up to nine HIP streams busy (DPs of consecutive small batches side by side, plan, walk + emit);
 # the runtime maps streams onto 4 hardware queues by default and streams sharing a queue serialise.  Must be in the
 # environment before the HIP runtime starts (torch starts it here, before the library could).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # VALU issue (tests/tools/ub/ops.hip, raw output in profiles/r2_ub_ops.txt): at two or more waves per SIMD v_add_u32 / v_sub_u32 /

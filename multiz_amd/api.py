@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: see mz_host.c, init_devices()
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # before the HIP runtime starts: see mz_host.c, init_devices()
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MZ_LIB_PATH") or os.path.join(HERE, "libmzamd.so")     # (MZ_LIB_PATH: experimental builds, tests/tools)

@@ -251,10 +251,14 @@ static int chunk_send(chunk *c)
         mzi_parallel_for(n, pack_grain(n), pack_exceptions, &c->pc);
     }
     c->exc_bytes = (int64_t)bytesE;
-    TSTAMP(X, set, 0, st);
-    if (mzk_link_copy(X->d_in[set].p, X->h_in[set].p, mzi_al256((size_t)c->in_bytes), st) ||
-        (nexc && mzk_link_copy(X->d_exc[set].p, X->h_exc[set].p, bytesE, st)) ||
-        mzk_unband(n, c->dLen, c->dLB0, c->dRB0, b->offBand, c->doC, c->dFmt, c->dC, (const uint8_t *)X->d_exc[set].p, (int32_t *)b->poolLB, (int32_t *)b->poolRB, st) ||
+    {
+        hipStream_t sc = c->lane < 0 ? st : X->qc;           /* the link copies: a stream of their own (mz_flow.c: which pipe) */
+        TSTAMP(X, set, 0, sc);
+        if (mzk_link_copy(X->d_in[set].p, X->h_in[set].p, mzi_al256((size_t)c->in_bytes), sc) ||
+            (nexc && mzk_link_copy(X->d_exc[set].p, X->h_exc[set].p, bytesE, sc))) return mzi_set_err("%s", mzk_last_error());
+        if (sc != st) { HIPCK(hipEventRecord(X->bcopy[set], sc)); HIPCK(hipStreamWaitEvent(st, X->bcopy[set], 0)); }
+    }
+    if (mzk_unband(n, c->dLen, c->dLB0, c->dRB0, b->offBand, c->doC, c->dFmt, c->dC, (const uint8_t *)X->d_exc[set].p, (int32_t *)b->poolLB, (int32_t *)b->poolRB, st) ||
         mzk_unnib(c->dA, (void *)b->poolA, (long long)(2 * (mzi_al256(c->eA / 2) + mzi_al256(c->eB / 2))), st))
         return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 1, st);
@@ -295,6 +299,7 @@ static int chunk_launch(chunk *c)
     b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
     b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
+    if (c->lane >= 0 && !X->lanes_made && mz_dp_kinds(b.dp_hint) > 1 && mzi_flow_lanes(X)) return -1;     /* several kinds of pairs: the DP streams' lanes */
 
     dres = (char *)X->d_res[set].p;
     if (sd != chunk_front(c)) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));      /* (the prep records: behind the plan on the front stream) */

@@ -27,7 +27,8 @@ typedef struct gbuf { void *p; size_t cap; } gbuf;
 enum { MZ_PD_IN, MZ_PD_TXT, MZ_PD_COLS, MZ_PD_BAND, MZ_PD_SCR, MZ_PD_META, MZ_PD_OUT1, MZ_PD_OUT2, MZ_PD_A2, MZ_PD_BAND2, MZ_PD_PLAN2, MZ_PD_TB2,
        MZ_PD_SCRIPT2, MZ_PD_PREP2, MZ_PD_RES, MZ_PD_N };
 enum { MZ_PH_IN, MZ_PH_RES, MZ_PH_TOT2, MZ_PH_N };
-#define MZ_QS 4                            /* stream slots of the chunk pipelines at most (MZ_STREAMS; default 2) */
+#define MZ_QS 2                            /* streams of one kind in the chunk pipelines at most */
+#define MZ_QALL 16                         /* ... and in all, fillers included (mz_flow.c creates them in rounds of four) */
 #define MZ_FLOW_STAGES 4                   /* stage threads of a chunk pipeline at most */
 #define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
 #define MZ_MAX_DEV 16
@@ -85,16 +86,15 @@ typedef struct mz_ctx {
     hipEvent_t ptime[MZ_SETS][8];          /* MZ_TIMING=2: before the upload, uploaded, k_pre done, planned, first DP done, first emit done, (second stage done,) k_fin done */
     int ptime_ready;
     hipStream_t bstream[MZ_SETS];          /* bstream[0] = `stream`: a call of one chunk (the drop-in yama()) runs there */
-    /* The chunk pipelines' streams (mz_flow.c; created on first use).  Chunk k of a call uses slot k % nq: its staging block -> device
-     * copy (a kernel: mzk_link_copy), expansion and plan on qf[slot]; its DP kernels on qd[slot] -- back to back with the DPs of the
-     * chunks before and after it, as the device-resident pipeline runs them (mz_dev_run_async), forking onto the slot's own lane when
-     * the chunk has several kinds of pairs; walk, script packing and the results -> host copy on qt[slot], behind the DP's event
-     * (bdp).  With two slots and a lane each that is eight streams: the hardware queues the library asks the runtime for -- streams
-     * that share one run in each other's order. */
-    hipStream_t qf[MZ_QS], qd[MZ_QS], qt[MZ_QS];
+    /* The chunk pipelines' streams (mz_flow.c; created on first use).  Chunk k of a call: its staging block -> device copy (a kernel:
+     * mzk_link_copy) on qc; expansion and plan on qf[0]; its DP kernels on qd[k % 2] -- back to back with the DPs of the chunks
+     * before and after it, as the device-resident pipeline runs them (mz_dev_run_async), forking onto the slot's own lanes when the
+     * chunk has several kinds of pairs; walk, script packing and the results -> host copy on qt[k % nt], behind the DP's event (bdp).
+     * WHICH hardware queue a stream gets matters (mz_flow.c: the queues of one pipe of the command processor hold each other up). */
+    hipStream_t qf[MZ_QS], qd[MZ_QS], qt[MZ_QS], qc, qall[MZ_QALL];
     mz_dp_lanes qlane[MZ_QS];
-    int nq, nf, nt;                        /* DP slots (chunk k: qd[k % nq]), front streams (qf[k % nf]), tail streams (qt[k % nt]) */
-    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bprep[MZ_SETS], bdp[MZ_SETS];    /* the chunk's last kernel; its plan's totals; its prep records; its DP kernels */
+    int nq, nf, nt, nqall, lanes_made;     /* DP slots (chunk k: qd[k % nq]), front streams (qf[k % nf]), tail streams (qt[k % nt]); streams created; the lanes exist */
+    hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bprep[MZ_SETS], bdp[MZ_SETS], bcopy[MZ_SETS];    /* the chunk's last kernel; its plan's totals; its prep records; its DP kernels; its staging block on the device */
     hipEvent_t btime[MZ_SETS][6];          /* MZ_TIMING=2: start, uploaded, planned, DP done, results packed, copied back */
     int btime_ready;
     struct { const void *key; hipEvent_t done; int used; } ws[MZ_WS_MAX];
@@ -118,6 +118,7 @@ MZ_INTERNAL int mzi_host_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_lazy_stream(hipStream_t *s);
 MZ_INTERNAL unsigned mzi_event_flags(void);              /* of the events nobody takes times from: no timing, release to the DEVICE (mz_host.c) */
 MZ_INTERNAL int mzi_flow_streams(mz_ctx *X);              /* mz_flow.c: the chunk streams and their lanes, on first use */
+MZ_INTERNAL int mzi_flow_lanes(mz_ctx *X);                /* ... the DP streams' lanes, when a chunk with several kinds of pairs needs them */
 MZ_INTERNAL void mzi_flow_sync(mz_ctx *X);                /* ... all of them synchronised (after an error) */
 MZ_INTERNAL int mzi_ensure_init(void);
 extern MZ_INTERNAL __thread int mzi_warm_thread;     /* set in the thread of mz_warm_start(): its batch prints no MZ_TIMING line */

@@ -54,6 +54,12 @@
 #ifndef MZ_HELPER_PRIO
 #define MZ_HELPER_PRIO 3
 #endif
+// ... and take no more than the 32 VGPRs five row-parallel DP waves leave of a SIMD's 512 (no LDS either: those take all 160 KB of a CU), so
+// that a helper wave is placed at once instead of waiting for a DP wave to retire and then taking the place of the next one
+#ifndef MZ_HELPER_VGPRS
+#define MZ_HELPER_VGPRS 32
+#endif
+#define HELPER_VGPRS
 #define HELPER_PRIO() do { if (MZ_HELPER_PRIO) __builtin_amdgcn_s_setprio(MZ_HELPER_PRIO); } while (0)
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; int tstrip_on; };
@@ -431,6 +437,14 @@ extern "C" int mz_dp_hint(int n, const int64_t *totals)
            (lag > 0 ? MZ_DP_LAG : 0) | (bit[most] << 8);
 }
 
+extern "C" int mz_dp_kinds(int dp_hint)                 // how many DP kernels a batch with this hint launches
+{
+    int k = 0;
+    if (dp_hint & MZ_DP_ROWBIG) dp_hint &= ~MZ_DP_ROW;
+    for (int bit : { MZ_DP_ROW, MZ_DP_ROWBIG, MZ_DP_WAVEFRONT, MZ_DP_WIDE, MZ_DP_LAG }) k += (dp_hint & bit) != 0;
+    return k;
+}
+
 extern "C" int mz_dp_rows(int n, const int64_t *totals)
 {
     const long long row = (long long)n - totals[3] - (totals[5] & 0xffffffffLL) - (totals[8] & 0xffffffffLL) - (totals[8] >> 32);
@@ -557,14 +571,14 @@ extern "C" int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *s
 // streams -- and on this platform was seen to stand still for 3-8 ms at a time (both directions at once, kernels running on:
 // the "one call in five takes twice as long" of rounds 3 and 4).  16 bytes per lane, four loads in flight per lane.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_link_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16)
+__global__ __launch_bounds__(256) HELPER_VGPRS void k_link_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16)
 {
     HELPER_PRIO();
     const long long stride = (long long)gridDim.x * 256;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (; i + stride < n16; i += 2 * stride) {           // (two loads in flight per lane: 24 VGPRs -- room beside five DP waves)
+        const uint4 a = src[i], b = src[i + stride];
+        dst[i] = a; dst[i + stride] = b;
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
@@ -572,12 +586,12 @@ extern "C" int mzk_link_copy(void *dst, const void *src, size_t bytes, void *str
 {
     if (!bytes) return 0;
     if (((uintptr_t)dst | (uintptr_t)src | bytes) & 15) { snprintf(g_err, sizeof g_err, "link copy: not 16-byte aligned"); return -1; }
-    // Few waves, each with 4 KB in flight: the link holds ~57 GB/s x a few microseconds = a few hundred KB at a time, and a copy wave
-    // waiting for it sits where a DP wave could (MZ_COPY_BLOCKS overrides; 2 048 blocks -- the whole GPU's wave slots -- halved a call's rate)
+    // Few waves, each with 2 KB in flight: the link holds ~57 GB/s x a few microseconds = a few hundred KB at a time, and a copy wave
+    // waiting for it sits where a DP wave could (MZ_COPY_BLOCKS overrides; a 50 000-pair C2 call: 2 / 4 / 8 / 16 / 32 / 64 / 2 048 blocks 13.9 / 8.7 / 8.2 / 8.15 / 8.6 / 9.2 / 11.5 ms)
     static int cap = -1;
-    if (cap < 0) { const char *e = getenv("MZ_COPY_BLOCKS"); cap = e && atoi(e) > 0 ? atoi(e) : 32; }
+    if (cap < 0) { const char *e = getenv("MZ_COPY_BLOCKS"); cap = e && atoi(e) > 0 ? atoi(e) : 16; }
     const long long n16 = (long long)(bytes / 16);
-    long long blocks = (n16 + 1023) / 1024;              // four 16-byte pieces per lane
+    long long blocks = (n16 + 511) / 512;                // two 16-byte pieces per lane at least
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_link_copy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);

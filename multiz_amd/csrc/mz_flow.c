@@ -12,42 +12,75 @@
 
 #include "mz_ctx.h"
 
-/* The chunk streams (mz_ctx.h): MZ_STREAMS slots (default 2) of three streams each, and MZ_LANES lanes (default 1) per slot for
- * the DP kernels of chunks with several kinds of pairs. */
+/* The chunk streams (mz_ctx.h), and which hardware queue each of them gets.
+ *
+ * Measured on MI355X (tests/tools/ub/chain.hip; profiles/r5_pipes.txt): the runtime gives every new stream the next hardware queue
+ * (until GPU_MAX_HW_QUEUES exist; later streams share), hardware queue i belongs to pipe i mod 4 of the GPU's command processor, and
+ * a queue whose pipe-mate has a kernel RUNNING gets each of its own packets started 60-200 us late -- however small the kernel, however
+ * much room the GPU has (a chain of tiny kernels: 3 us per kernel alone or beside kernels that fill the GPU from other pipes, 60-210 us
+ * beside one on the same pipe).  A chunk's front is a chain of a dozen small dependent kernels; with the streams as they came (round 4,
+ * and at first in round 5) it took ~1 ms per chunk beside the DPs, the plan of chunk k+2 was not through when the DP of chunk k ended,
+ * and the DP streams idled a quarter of the time.  So the streams are created in an order that puts on one pipe what can wait for each
+ * other:
+ *        pipe a            pipe b            pipe c              pipe d
+ *        DP stream 0       DP stream 1       the fronts          the link copies (host -> device)
+ *        tail stream 0     tail stream 1
+ *        lane of DP 0      lane of DP 1                          (created when the first chunk with several kinds of pairs comes by;
+ *        2nd lane          2nd lane                               two filler streams complete every round of four)
+ * -- a front's short kernels wait for nothing but each other; the copies, which bound the fronts' rate (a chunk's 13 MB at the link's
+ * ~50 GB/s), wait for nothing at all; a tail's kernels (walk, script packing, results -> host: latency-bound anyway) start late beside
+ * a running DP and may in turn start a DP 0.1 ms late, which the other DP stream's blocks cover.  This needs the hardware queues in a
+ * row: the library asks the runtime for 24 (init_devices()).  If the runtime hands them out differently nothing breaks; the fronts
+ * are slow again.  MZ_TAILS=1, MZ_LANES=0..2 (default 2): fewer streams (measurements). */
+static int flow_new_stream(mz_ctx *X, hipStream_t *s)
+{
+    if (X->nqall >= MZ_QALL) return mzi_set_err("chunk pipeline: out of stream slots");
+    *s = NULL;
+    if (mzi_lazy_stream(s)) return -1;
+    X->qall[X->nqall++] = *s;
+    return 0;
+}
+
 int mzi_flow_streams(mz_ctx *X)
 {
-    int nq, nl, nf, nt, i, l;
+    hipStream_t filler;
+    int i, nt;
+    const double t0 = mzi_now_s();
     if (X->nq) return 0;
-    { const char *e = getenv("MZ_STREAMS"); nq = e && atoi(e) > 0 ? atoi(e) : 2; if (nq > MZ_QS) nq = MZ_QS; }
-    { const char *e = getenv("MZ_FRONTS"); nf = e && atoi(e) > 0 ? atoi(e) : 2; if (nf > MZ_QS) nf = MZ_QS; }
-    { const char *e = getenv("MZ_TAILS"); nt = e && atoi(e) > 0 ? atoi(e) : 2; if (nt > MZ_QS) nt = MZ_QS; }
-    { const char *e = getenv("MZ_LANES"); nl = e && atoi(e) >= 0 ? atoi(e) : 1; if (nl > 4) nl = 4; }
-    for (i = 0; i < nq; ++i) {
-        if (mzi_lazy_stream(&X->qd[i])) return -1;
-        X->qlane[i].n = nl;
-        /* the DP of a chunk as a persistent grid: half of the GPU's 5 120 row-parallel wave slots per DP stream (MZ_DP_CAP; 0: a block per pair) */
-        { const char *e = getenv("MZ_DP_CAP"); X->qlane[i].row_cap = e ? atoi(e) : 5120 / nq; }
-        if (nl) HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
-        for (l = 0; l < nl; ++l) {
-            hipStream_t s = NULL;
-            if (mzi_lazy_stream(&s)) return -1;
+    { const char *e = getenv("MZ_TAILS"); nt = e && atoi(e) == 1 ? 1 : 2; }
+    /* round 0: DP 0, DP 1, fronts, copies; round 1: tail 0, tail 1 (the lanes' rounds: mzi_flow_lanes) */
+    if (flow_new_stream(X, &X->qd[0]) || flow_new_stream(X, &X->qd[1]) || flow_new_stream(X, &X->qf[0]) || flow_new_stream(X, &X->qc) ||
+        flow_new_stream(X, &X->qt[0]) || flow_new_stream(X, nt > 1 ? &X->qt[1] : &filler)) return -1;
+    for (i = 0; i < 2; ++i) {
+        X->qlane[i].n = 0;
+        /* the DP of a chunk as a persistent grid (MZ_DP_CAP blocks at most; default 0: a block per pair) */
+        { const char *e = getenv("MZ_DP_CAP"); X->qlane[i].row_cap = e ? atoi(e) : 0; }
+        HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
+    }
+    X->nf = 1; X->nt = nt; X->nq = 2;
+    if (mzi_timing()) fprintf(stderr, "{\"mz_flow_streams\": {\"created\": %d, \"ms\": %.1f}}\n", X->nqall, 1e3 * (mzi_now_s() - t0));
+    return 0;
+}
+
+/* the DP streams' lanes, when the first chunk with several kinds of pairs needs them (from the launcher's thread; ~5 ms a stream) */
+int mzi_flow_lanes(mz_ctx *X)
+{
+    static int want = -1;
+    hipStream_t filler;
+    int i, l;
+    if (want < 0) { const char *e = getenv("MZ_LANES"); want = e && atoi(e) >= 0 ? atoi(e) : 2; if (want > 2) want = 2; }
+    if (X->lanes_made || !want) { X->lanes_made = 1; return 0; }
+    for (l = 0; l < want; ++l) {
+        while (X->nqall % 4) if (flow_new_stream(X, &filler)) return -1;        /* the next stream: pipe a */
+        for (i = 0; i < 2; ++i) {
+            hipStream_t s;
+            if (flow_new_stream(X, &s)) return -1;
             X->qlane[i].stream[l] = (void *)s;
             HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].join[l], mzi_event_flags()));
         }
     }
-    for (i = 0; i < nf; ++i) {
-        /* MZ_FRONT_PRIO=1: the front streams at the highest priority (measurements) */
-        const char *fp = getenv("MZ_FRONT_PRIO");
-        if (fp && fp[0] == '1') {
-            int least = 0, greatest = 0;
-            HIPCK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIPCK(hipStreamCreateWithPriority(&X->qf[i], hipStreamNonBlocking, greatest));
-        }
-        if (mzi_lazy_stream(&X->qf[i])) return -1;
-    }
-    for (i = 0; i < nt; ++i) if (mzi_lazy_stream(&X->qt[i])) return -1;
-    X->nf = nf; X->nt = nt;
-    X->nq = nq;
+    for (i = 0; i < 2; ++i) X->qlane[i].n = want;
+    X->lanes_made = 1;
     return 0;
 }
 
@@ -56,6 +89,7 @@ void mzi_flow_sync(mz_ctx *X)
 {
     int s, l;
     if (X->stream) hipStreamSynchronize(X->stream);
+    if (X->qc) hipStreamSynchronize(X->qc);
     for (s = 0; s < X->nf; ++s) hipStreamSynchronize(X->qf[s]);
     for (s = 0; s < X->nt; ++s) hipStreamSynchronize(X->qt[s]);
     for (s = 0; s < X->nq; ++s) {

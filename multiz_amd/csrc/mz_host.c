@@ -129,6 +129,7 @@ static int ctx_open(mz_ctx *X, int device)
         HIPCK(hipEventCreateWithFlags(&X->bplan[i], mzi_event_flags()));
         HIPCK(hipEventCreateWithFlags(&X->bdp[i], mzi_event_flags()));
         HIPCK(hipEventCreateWithFlags(&X->bprep[i], mzi_event_flags()));
+        HIPCK(hipEventCreateWithFlags(&X->bcopy[i], mzi_event_flags()));
         HIPCK(hipEventCreateWithFlags(&X->pplan2[i], mzi_event_flags()));
     }
     for (i = 0; i < 5; ++i) HIPCK(hipEventCreate(&X->ev[i]));
@@ -158,6 +159,7 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->bplan[s]);
         hipEventDestroy(X->bdp[s]);
         hipEventDestroy(X->bprep[s]);
+        hipEventDestroy(X->bcopy[s]);
     }
     for (s = 0; s < MZ_SETS; ++s) {
         for (i = 0; i < MZ_PD_N; ++i) if (X->pd[s][i].p) { hipFree(X->pd[s][i].p); X->pd[s][i].p = NULL; X->pd[s][i].cap = 0; }
@@ -165,16 +167,14 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->pplan2[s]);
         if (X->ptime_ready) for (i = 0; i < 8; ++i) hipEventDestroy(X->ptime[s][i]);
     }
-    for (s = 0; s < X->nq; ++s) {                        /* the chunk pipelines' streams and their lanes (mz_flow.c) */
-        for (i = 0; i < X->qlane[s].n; ++i) {
-            hipStreamSynchronize((hipStream_t)X->qlane[s].stream[i]); hipStreamDestroy((hipStream_t)X->qlane[s].stream[i]);
-            hipEventDestroy((hipEvent_t)X->qlane[s].join[i]);
-        }
-        if (X->qlane[s].n) hipEventDestroy((hipEvent_t)X->qlane[s].fork);
-        hipStreamSynchronize(X->qd[s]); hipStreamDestroy(X->qd[s]); X->qd[s] = NULL;
+    for (s = 0; s < X->nq; ++s) {                        /* the chunk pipelines' streams (mz_flow.c) */
+        for (i = 0; i < X->qlane[s].n; ++i) hipEventDestroy((hipEvent_t)X->qlane[s].join[i]);
+        hipEventDestroy((hipEvent_t)X->qlane[s].fork);
+        X->qlane[s].n = 0;
     }
-    for (s = 0; s < X->nf; ++s) { hipStreamSynchronize(X->qf[s]); hipStreamDestroy(X->qf[s]); X->qf[s] = NULL; }
-    for (s = 0; s < X->nt; ++s) { hipStreamSynchronize(X->qt[s]); hipStreamDestroy(X->qt[s]); X->qt[s] = NULL; }
+    X->nqall = X->lanes_made = 0;
+    for (s = 0; s < MZ_QALL; ++s) if (X->qall[s]) { hipStreamSynchronize(X->qall[s]); hipStreamDestroy(X->qall[s]); X->qall[s] = NULL; }
+    memset(X->qd, 0, sizeof X->qd); memset(X->qf, 0, sizeof X->qf); memset(X->qt, 0, sizeof X->qt); X->qc = NULL;
     X->nq = X->nf = X->nt = 0;
     for (i = 0; i < 5; ++i) hipEventDestroy(X->ev[i]);
     for (i = 0; i <= MZ_SLICES; ++i) hipEventDestroy(X->evs[i]);
@@ -194,7 +194,7 @@ static int init_devices(int ngpu, const int *devices, int first)
     /* the pipelined form keeps up to nine streams busy; the HIP runtime multiplexes streams onto 4 hardware queues
      * unless told otherwise, and streams that share a queue run one after the other (C5: 313 -> 381 GCUPS with 8).
      * Effective only if the runtime is not up yet; an application that starts it first sets the variable itself. */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return mzi_set_err("no HIP device available (this library has no CPU path)");
     if (ngpu < 1 || ngpu > MZ_MAX_DEV) return mzi_set_err("mz_init_multi: %d GPUs requested (1..%d supported)", ngpu, MZ_MAX_DEV);

@@ -229,9 +229,13 @@ static int pchunk_send(pchunk *c)
     const int set = c->set;
     hipStream_t st = pchunk_front(c);
     c->t_packed = mzi_now_s();
-    PSTAMP(X, set, 0, st);
-    if (mzk_link_copy(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, mzi_al256(c->in_bytes), st)) return mzi_set_err("%s", mzk_last_error());
-    PSTAMP(X, set, 1, st);
+    {
+        hipStream_t sc = c->lane < 0 ? st : X->qc;           /* the link copy: a stream of its own (mz_flow.c: which pipe) */
+        PSTAMP(X, set, 0, sc);
+        if (mzk_link_copy(PD(MZ_PD_IN)->p, PH(MZ_PH_IN)->p, mzi_al256(c->in_bytes), sc)) return mzi_set_err("%s", mzk_last_error());
+        PSTAMP(X, set, 1, sc);
+        if (sc != st) { HIPCK(hipEventRecord(X->bcopy[set], sc)); HIPCK(hipStreamWaitEvent(st, X->bcopy[set], 0)); }
+    }
     if (!c->q.lds_bytes) {
         if (mzk_unnib(c->dNib, PD(MZ_PD_TXT)->p, (long long)c->txt, st)) return mzi_set_err("%s", mzk_last_error());
         HIPCK(hipMemsetAsync(c->f.size, 0, 4 * c->nrow, st));      /* (the LDS-free k_pre adds the row counts up in place) */
@@ -256,6 +260,7 @@ static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t sd, hipStream_t 
     b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap;
     b->walk_hint = mz_walk_choice(n, totals);
     b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
+    if (lanes && !X->lanes_made && mz_dp_kinds(b->dp_hint) > 1 && mzi_flow_lanes(X)) return -1;      /* several kinds of pairs: the DP streams' lanes */
     /* the DP on the slot's DP stream (whatever else it reads is through: the host has seen this plan's totals), the rest behind its event */
     if (wait_prep) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));
     if (mzk_dp_range_on(b, 0, n, sd, lanes)) return mzi_set_err("%s", mzk_last_error());

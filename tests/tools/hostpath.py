@@ -13,10 +13,18 @@ batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], fir
 jobs, outs = api.host_jobs(batch)
 nb = int(batch["offBand"][-1]) + int(batch["M"][-1]) + 1
 cells = int((batch["poolRB"][:nb].astype(np.int64) - batch["poolLB"][:nb] + 1).sum())
-for rep in range(4):
+import os
+def vm():
+    want = ("numa_hint_faults", "numa_pages_migrated", "pgmigrate_success", "thp_migration_success", "pgfault", "numa_pte_updates")
+    return {k: int(v) for k, v in (l.split() for l in open("/proc/vmstat")) if k in want}
+for rep in range(int(os.environ.get("HOSTPATH_REPS", "4"))):
+    v0 = vm()
     t = time.perf_counter()
     rc = api.yama_batch_records(jobs, outs)
     dt = time.perf_counter() - t
     assert rc == 0
     api.free_outs(outs)
-    print(f"mz_yama_batch({n} {cfg} pairs, host buffers in, merged columns out): {dt*1e3:.2f} ms -> {cells/dt/1e9:.1f} GCUPS", flush=True)
+    v1 = vm()
+    extra = " ".join(f"{k}+{v1[k] - v0[k]}" for k in v0 if v1[k] != v0[k]) if os.environ.get("HOSTPATH_VM") else ""
+    print(f"mz_yama_batch({n} {cfg} pairs, host buffers in, merged columns out): {dt*1e3:.2f} ms -> {cells/dt/1e9:.1f} GCUPS {extra}", flush=True)
+    time.sleep(float(os.environ.get("HOSTPATH_SLEEP", "0")))

@@ -60,8 +60,9 @@ static double chain_us(hipStream_t s, int *buf, int n, int blocks, int reps, int
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool only_multi = argc > 1;
     hipStream_t a, b;
     int *buf, *hb;
     const int n = 1 << 20;
@@ -69,8 +70,9 @@ int main()
     CK(hipMalloc(&buf, n * 4)); CK(hipMalloc(&hb, 4096)); CK(hipMemset(buf, 0, n * 4));
     const long long ms20 = 20LL * 100000;                  // 20 ms of the 100 MHz wall clock
     int *dirty = nullptr;
+    if (only_multi) CK(hipMalloc(&dirty, (1LL << 28) * 4));
     const long long dirty_dw = 1LL << 28;                   // 1 GB
-    for (int with_stores = 0; with_stores < 2; ++with_stores) {
+    for (int with_stores = 0; with_stores < 2 && !only_multi; ++with_stores) {
     if (with_stores) { CK(hipMalloc(&dirty, dirty_dw * 4)); printf("-- the hog now also stores a 256-byte row per wave per round into 1 GB\n"); }
     for (g_prio = 0; g_prio < 2; ++g_prio)
     for (int vg : { 8, 40 })
@@ -92,26 +94,32 @@ int main()
                    g_prio ? "s_setprio 3:" : "            ", blocks, vg, idle, roomy, full, churn);
         }
     }
-    // ---- the chunk pipelines' situation: two hogs side by side, each a stream of 0.4 ms blocks twice as many as fit (two chunks' DPs
-    // abreast), and FOUR chains of tiny dependent kernels (with s_setprio) on four more streams at once
+    // ---- the chunk pipelines' situation: NH hogs side by side (streams of their own) and NC chains of tiny dependent kernels (with
+    // s_setprio) on NC more streams at once.  argv: NH NC waves-per-CU-per-hog persistent(0/1) tiny-blocks
     {
-        hipStream_t hs[2], cs[4];
-        for (auto &x : hs) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
-        for (auto &x : cs) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        const int NH = argc > 1 ? atoi(argv[1]) : 2, NC = argc > 2 ? atoi(argv[2]) : 4, wpc = argc > 3 ? atoi(argv[3]) : 10;
+        const int persistent = argc > 4 ? atoi(argv[4]) : 1, tb = argc > 5 ? atoi(argv[5]) : 64;
+        hipStream_t hs[8], cs[8];
+        for (int i = 0; i < NH; ++i) CK(hipStreamCreateWithFlags(&hs[i], hipStreamNonBlocking));
+        for (int i = 0; i < NC; ++i) CK(hipStreamCreateWithFlags(&cs[i], hipStreamNonBlocking));
         g_prio = 1;
-        for (int mode = 0; mode < 3; ++mode) {
-            // mode 0: no hog; 1: hogs as one block per work item (40 x the slots); 2: hogs as PERSISTENT grids (exactly the slots, each wave working 40 items' time)
-            if (mode == 1) for (auto &x : hs) hipLaunchKernelGGL(hog, dim3(256 * 10 * 40), dim3(64), 8 * 1024, x, hb, ms20 / 50, 2048, dirty, dirty_dw);
-            if (mode == 2) for (auto &x : hs) hipLaunchKernelGGL(hog, dim3(256 * 10), dim3(64), 8 * 1024, x, hb, ms20 * 40 / 50, 2048, dirty, dirty_dw);
+        for (int mode = 0; mode < 2; ++mode) {
+            if (mode == 1) for (int i = 0; i < NH; ++i) {
+                if (persistent) hipLaunchKernelGGL(hog, dim3(256 * wpc), dim3(64), 8 * 1024, hs[i], hb, ms20 * 40 / 50, 2048, dirty, dirty_dw);
+                else hipLaunchKernelGGL(hog, dim3(256 * wpc * 40), dim3(64), 8 * 1024, hs[i], hb, ms20 / 50, 2048, dirty, dirty_dw);
+            }
             auto t0 = std::chrono::steady_clock::now();
             const int reps = 100;
-            for (int r = 0; r < reps; ++r) for (auto &x : cs) hipLaunchKernelGGL((tiny<8, 1>), dim3(64), dim3(64), 0, x, buf, n);
-            for (auto &x : cs) CK(hipStreamSynchronize(x));
+            for (int r = 0; r < reps; ++r) for (int i = 0; i < NC; ++i) hipLaunchKernelGGL((tiny<8, 1>), dim3(tb), dim3(64), 0, cs[i], buf, n);
+            double each[8];
+            for (int i = 0; i < NC; ++i) { CK(hipStreamSynchronize(cs[i])); each[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps; }
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
-            for (auto &x : hs) CK(hipStreamSynchronize(x));
-            printf("four chains of tiny kernels at once, %s: %.1f us per kernel of a chain\n",
-                   mode == 0 ? "GPU idle" : mode == 1 ? "beside two hogs of 40 x the slots' blocks (0.4 ms each)" : "beside two PERSISTENT hogs (a block per slot)", us);
+            if (mode == 1) { printf("   per chain (in the order the streams were created; a chain cannot be seen to end before the ones before it):"); for (int i = 0; i < NC; ++i) printf(" %.1f", each[i]); printf("\n"); }
+            for (int i = 0; i < NH; ++i) CK(hipStreamSynchronize(hs[i]));
+            printf("%d chains of tiny kernels (%d blocks) at once, %s: %.1f us per kernel of a chain\n", NC, tb,
+                   mode == 0 ? "GPU idle" : persistent ? "beside PERSISTENT hogs" : "beside hogs of 40 x the slots' blocks", us);
         }
+        printf("   (%d hogs of %d waves per CU each)\n", NH, wpc);
     }
     return 0;
 }
