@@ -134,11 +134,19 @@ static void pack_exceptions(void *ctx, int lo, int hi)
 static int g_timing = -1;                  /* mzi_timing(): 1 = one JSON line per call, 2 = and one per chunk (stderr) */
 #define TSTAMP(X, set, k, st) do { if (g_timing >= 2 && (X)->btime_ready) HIPCK(hipEventRecord((X)->btime[set][k], st)); } while (0)
 
-static int chunk_parts(void)               /* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides) */
+/* Pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides): chunks of about 5 000 pairs, three to sixteen of them.  A chunk's DP
+ * is a launch of its own, and below ~4 000 waves a launch is latency-bound -- it takes as long as its longest pair whatever their
+ * number -- while every chunk costs a dozen dependent launches at either end; above ~8 000 the first chunk starts late and the last
+ * one ends late.  Measured with the round-5 pipeline (ms per call, parts 3 / 4 / 6 / 8 / 12 / 16): 20 000 pairs with indel bands (c2i)
+ * 5.9 / 5.5 / 6.3 / 6.4 / 7.6; 50 000 C2 pairs - / - / - / 8.7 / 8.2; a guide tree's 125 000 (c4) - / - / - / 17.5 / 16.8 / 15.7. */
+static int chunk_parts(int n)
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 12; }
-    return v;
+    int parts;
+    if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (v) return v;
+    parts = (n + 2500) / 5000;
+    return parts < 3 ? 3 : parts > 16 ? 16 : parts;
 }
 
 /* the chunk's streams (mz_ctx.h): front (staging block -> device, expansion, plan), DP, tail (walk, script packing, results -> host) */
@@ -224,7 +232,7 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
      * step is below 16 (the others are noted and sent apart: chunk_send) */
     c->pc.jobs = jobs; c->pc.hoA = hoA; c->pc.hoB = hoB; c->pc.hoC = hoC; c->pc.hA = hA; c->pc.hB = hB; c->pc.hC = hC; c->pc.hFmt = hFmt; c->pc.hE = NULL;
     c->pc.hLB0 = hLB0; c->pc.hRB0 = hRB0;
-    pack->fn = pack_range; pack->ctx = &c->pc; pack->n = n; pack->grain = pack_grain(n);
+    pack->fn = pack_range; pack->ctx = &c->pc; pack->n = n; pack->grain = pack_grain(n); pack->hedge = 1;
     c->t_cut1 = mzi_now_s();
     return 0;
 }
@@ -330,20 +338,19 @@ typedef struct asm_ctx {
     int64_t cells;
 } asm_ctx;
 
+/* (a piece may be run twice -- mz_pool.c -- so it adds nothing up: results_count() does, afterwards) */
 static void assemble_range(void *ctx, int lo, int hi)
 {
     asm_ctx *q = (asm_ctx *)ctx;
-    int p, failed = 0;
-    int64_t cells = 0;
+    int p;
     for (p = lo; p < hi; ++p) {
         mz_out *o = &q->outs[p];
         const mz_res_rec *r = &q->rec[p];
-        cells += r->cells;
         const mz_job *j = &q->jobs[p];
         o->status = r->status; o->badrow = r->badrow; o->OM = 0; o->cols = NULL; o->block = NULL;
         o->score[0] = o->score[1] = o->score[2] = 0;
         if (r->status == MZ_E_EMIT) { o->OM = r->om; o->score[0] = r->f[0]; o->score[1] = r->f[1]; }   /* i, j of the reference's message */
-        if (r->status != MZ_OK) { failed++; continue; }
+        if (r->status != MZ_OK) continue;
         o->OM = r->om;
         o->score[0] = r->f[0]; o->score[1] = r->f[1]; o->score[2] = r->f[2];
         o->cols = q->block + q->where[p];
@@ -353,9 +360,13 @@ static void assemble_range(void *ctx, int lo, int hi)
         }
         mz_assemble_cols(j->K, j->L, j->M, j->N, j->A, j->B, q->packed + r->off, r->om, o->cols);
     }
-    if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
-    __atomic_fetch_add(&q->cells, cells, __ATOMIC_RELAXED);
     _mm_sfence();
+}
+static void results_count(int n, asm_ctx *q)               /* pairs without a result, band cells */
+{
+    int p;
+    q->failed = 0; q->cells = 0;
+    for (p = 0; p < n; ++p) { q->failed += q->rec[p].status != MZ_OK; q->cells += q->rec[p].cells; }
 }
 
 /* Does the 2-bit script of `om` columns take exactly M columns of A and N of B?  (C = 0 takes both, I = 1 one of B, D = 2 one of A;
@@ -430,6 +441,7 @@ static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char 
     size_t *where;
     if (results_prepare(n, jobs, outs, r, limit, &ac, &where) < 0) return -1;
     mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
+    results_count(n, &ac);
     outs[0].block = ac.block;
     *cells = ac.cells;
     free(where);
@@ -447,16 +459,17 @@ static int chunk_collect(chunk *c, mz_ajob *post)
     HIPCK(hipEventSynchronize(X->bdone[set]));
     c->t_col1 = mzi_now_s();
     if (!c->ac && !(c->ac = (asm_ctx *)malloc(sizeof *c->ac))) return mzi_set_err("out of memory");
+    free(c->where); c->where = NULL;                     /* (of the chunk that had this set before: nobody reads it any more, mz_flow.c) */
     if (results_prepare(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, c->ac, &c->where) < 0) return -1;
-    post->fn = assemble_range; post->ctx = c->ac; post->n = c->n; post->grain = pack_grain(c->n);
+    post->fn = assemble_range; post->ctx = c->ac; post->n = c->n; post->grain = pack_grain(c->n); post->hedge = 1;
     return 0;
 }
 
 static int chunk_finish(chunk *c)
 {
+    results_count(c->n, c->ac);
     c->outs[0].block = c->ac->block;
     c->cells = c->ac->cells;
-    free(c->where); c->where = NULL;
     c->t_col2 = mzi_now_s();
     return c->ac->failed;
 }
@@ -464,6 +477,7 @@ static int chunk_finish(chunk *c)
 /* ------------------------------------------------------------------------------------------------ the pipeline (mz_flow.c) */
 
 typedef struct batch_stats { int64_t cells, bytes_up, bytes_down; } batch_stats;
+static int g_last_hedged;                  /* pieces of the last call's packing / assembling loops that were run twice (mz_pool.c) */
 
 typedef struct ypipe {
     mz_ctx *X;
@@ -525,12 +539,19 @@ static int next_chunk(const mz_job *jobs, int n, int first, int limit, size_t ma
 static int y_cut(void *self, int k, int set, mz_ajob *pack)
 {
     ypipe *P = (ypipe *)self;
-    /* the first chunks are a quarter and a half of the size: the GPU starts that much earlier */
-    const int ramp = P->threaded && k < 2 && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) ? 2 - k : 0;
-    const int limit = P->max_pairs >> ramp < MIN_CHUNK_PAIRS / 2 ? MIN_CHUNK_PAIRS / 2 : P->max_pairs >> ramp;
-    int m;
+    /* the first chunks are smaller: the GPU starts that much earlier (MZ_RAMP: their sizes in eighths of a chunk, e.g. "2,4") */
+    static int ramp_n = -1, ramp8[8];
+    int limit = P->max_pairs, m, shift8 = 8;
+    if (ramp_n < 0) {
+        const char *e = getenv("MZ_RAMP");
+        ramp_n = 0;
+        for (e = e ? e : "2,4"; *e && ramp_n < 8; ) { ramp8[ramp_n++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; }
+    }
+    if (P->threaded && k < ramp_n && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) && ramp8[k] >= 1 && ramp8[k] < 8) shift8 = ramp8[k];
+    limit = (int)((long long)P->max_pairs * shift8 / 8);
+    if (limit < MIN_CHUNK_PAIRS / 2) limit = MIN_CHUNK_PAIRS / 2;
     if (P->up >= P->n) return 0;
-    m = next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp);
+    m = next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes / 8 * (size_t)shift8);
     if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? k % P->X->nq : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
     P->up += m;
     return 1;
@@ -587,7 +608,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     /* chunks by pairs AND by bytes: a call of few long pairs (BASELINE config 5: 1 000 pairs, 1.2 GB) is cut into as many
      * pieces as one of many short ones, at least 8 MB each and at most 1 GB */
     for (s = 0; s < n; ++s) max_bytes += job_bytes(&jobs[s]);
-    max_bytes = max_bytes / (size_t)chunk_parts() + 1;
+    max_bytes = max_bytes / (size_t)chunk_parts(n) + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
     P->max_bytes = max_bytes;
@@ -598,6 +619,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }
     rc = mzi_flow_run(F);
     if (rc < 0) mzi_flow_sync(X);
+    g_last_hedged = F->hedged;
     for (s = 0; s < MZ_SETS; ++s) { free(P->ck[s].pc.esz); free(P->ck[s].ac); free(P->ck[s].where); }
     if (g_timing >= 2 && X->btime_ready) hipEventDestroy(P->ev0);
     if (stats) *stats = P->st;
@@ -687,11 +709,10 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
     use = g_ndev;
     while (use > 1 && n / use < MZ_MULTI_MIN) --use;
     {
-        /* chunk size: a twelfth of a GPU's share (MZ_CHUNKS overrides the divisor; 4 / 6 / 8 / 12 / 16 pieces measured on the
-         * 50 000-pair C2 call: 11.2 / 12.0 / 11.3 / 10.0 / 10.9 ms), so that the copies, the kernels and the host's packing
-         * and assembling of different chunks overlap and the first kernels start early -- but at least 1 Ki pairs (a wave
-         * per SIMD; chunks in flight share the GPU) and at most 16 Ki */
-        const int share = (n + use - 1) / use, parts = chunk_parts(), per = (share + parts - 1) / parts;
+        /* chunk size: a GPU's share in chunk_parts() pieces, so that the copies, the kernels and the host's packing and assembling of
+         * different chunks overlap and the first kernels start early -- but at least 1 Ki pairs (a wave per SIMD; chunks in flight
+         * share the GPU) and at most 16 Ki */
+        const int share = (n + use - 1) / use, parts = chunk_parts(share), per = (share + parts - 1) / parts;
         max_pairs = env_pairs ? env_pairs : per < 1024 ? 1024 : per > 16384 ? 16384 : per;
     }
     if (use == 1) {
@@ -752,7 +773,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
         /* one JSON line per call: pairs, band cells, seconds, GCUPS, bytes over the link each way */
         const double dt = mzi_now_s() - t_call;
         fprintf(stderr, "{\"mz_yama_batch\": {\"pairs\": %d, \"failed\": %d, \"cells\": %lld, \"seconds\": %.6f, \"gcups\": %.2f, \"bytes_up\": %lld, \"bytes_down\": %lld, "
-                        "\"gpus\": %d, \"chunk_pairs\": %d}}\n", n, rc, (long long)st.cells, dt, (double)st.cells / dt / 1e9, (long long)st.bytes_up, (long long)st.bytes_down, use, max_pairs);
+                        "\"gpus\": %d, \"chunk_pairs\": %d, \"pieces_run_twice\": %d}}\n", n, rc, (long long)st.cells, dt, (double)st.cells / dt / 1e9, (long long)st.bytes_up, (long long)st.bytes_down, use, max_pairs, g_last_hedged);
     }
     return rc;
 }

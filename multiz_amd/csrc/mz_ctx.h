@@ -133,12 +133,16 @@ typedef void (*mz_pfn)(void *ctx, int lo, int hi);
 MZ_INTERNAL void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx);
 /* a loop that is posted and not waited for: fn(ctx, lo, hi) over [0, n) in pieces of `grain` on the pool's threads, then done(arg)
  * once, on the thread that ran the last piece (next / pending / link are the pool's) */
+#define MZ_HEDGE_PIECES 512
 typedef struct mz_ajob {
     mz_pfn fn; void *ctx; int n, grain;
     void (*done)(void *arg); void *arg;
-    int next, pending; struct mz_ajob *link;
+    int hedge;                             /* 1: a piece may be run twice (mz_pool.c: a late one is handed out again) -- pieces must be idempotent */
+    int next, pending, active, hedged, npiece; struct mz_ajob *link, *olink;
+    unsigned char state[MZ_HEDGE_PIECES]; double t_start[MZ_HEDGE_PIECES];
 } mz_ajob;
 MZ_INTERNAL void mzi_post(mz_ajob *job);
+MZ_INTERNAL int mzi_job_quiet(mz_ajob *job);                            /* wait until no thread is in a piece of a (complete) posted loop; pieces run twice */
 MZ_INTERNAL void mzi_help_until(int (*ready)(void *), void *arg);    /* the caller works on posted pieces until ready(arg) (evaluated under the pool's lock) */
 MZ_INTERNAL void mzi_pool_kick(void);                                  /* ... whoever makes ready() true calls this afterwards */
 MZ_INTERNAL int mzi_pool_threads(void);
@@ -170,7 +174,7 @@ typedef struct mz_flow {
     pthread_cond_t cv;
     int packed[MZ_SETS], finished[MZ_SETS];          /* chunk index + 1 of the last chunk packed / finished in the set */
     int through[MZ_FLOW_STAGES + 1];                 /* chunks through stage s, in order */
-    int total, rc, left, jobs_out, failed, chunks;
+    int total, rc, left, jobs_out, failed, chunks, hedged;     /* hedged: pieces of the posted loops that were handed out twice */
     mz_ajob pack[MZ_SETS], post[MZ_SETS];
     struct mz_flow_arg { struct mz_flow *F; int k; } parg[MZ_SETS], qarg[MZ_SETS], sarg[MZ_FLOW_STAGES];
     int wait_k;                                      /* what the calling thread is waiting for (flow_ready) */

@@ -181,7 +181,8 @@ static int flow_drained(void *arg)
 int mzi_flow_run(mz_flow *F)
 {
     int k, s, rc;
-    F->total = -1; F->rc = 0; F->left = 0; F->jobs_out = 0; F->failed = 0; F->chunks = 0; F->err[0] = 0;
+    F->total = -1; F->rc = 0; F->left = 0; F->jobs_out = 0; F->failed = 0; F->chunks = 0; F->hedged = 0; F->err[0] = 0;
+    memset(F->pack, 0, sizeof F->pack); memset(F->post, 0, sizeof F->post);
     memset(F->packed, 0, sizeof F->packed); memset(F->finished, 0, sizeof F->finished); memset(F->through, 0, sizeof F->through);
     if (F->threaded && (mzi_flow_streams(F->X) || mzi_workers_start(F->X->fworker, F->nstage))) F->threaded = 0;
     if (!F->threaded) {
@@ -209,7 +210,10 @@ int mzi_flow_run(mz_flow *F)
     for (k = 0;; ++k) {
         const int set = k % MZ_SETS;
         int r;
-        if (k >= MZ_SETS) { F->wait_k = k - MZ_SETS; mzi_help_until(flow_set_free, F); }      /* its buffer set is still in use */
+        if (k >= MZ_SETS) {                                  /* its buffer set is still in use ... */
+            F->wait_k = k - MZ_SETS; mzi_help_until(flow_set_free, F);
+            F->hedged += mzi_job_quiet(&F->pack[set]) + mzi_job_quiet(&F->post[set]);      /* ... or a thread that came late is still writing to it (mz_pool.c) */
+        }
         if (__atomic_load_n(&F->rc, __ATOMIC_ACQUIRE) < 0) break;
         memset(&F->pack[set], 0, sizeof F->pack[set]);
         if ((r = F->cut(F->self, k, set, &F->pack[set])) <= 0) { if (r < 0) flow_abort(F); break; }
@@ -225,6 +229,7 @@ int mzi_flow_run(mz_flow *F)
     pthread_cond_broadcast(&F->cv);
     pthread_mutex_unlock(&F->mu);
     mzi_help_until(flow_drained, F);
+    for (s = 0; s < MZ_SETS && s < k; ++s) F->hedged += mzi_job_quiet(&F->pack[s]) + mzi_job_quiet(&F->post[s]);     /* nobody is writing to the results any more */
     rc = F->rc < 0 ? -1 : F->failed;
     if (rc < 0) mzi_set_err("%s", F->err);
     pthread_mutex_destroy(&F->mu);

@@ -62,38 +62,87 @@ int mzi_cpu_budget(void)
     return cpus;
 }
 
+/* ---- pieces, and pieces run twice.
+ * A posted loop whose pieces may be run more than once (job->hedge: every piece writes the same bytes whoever runs it, and adds
+ * nothing up) is watched after its last piece has been handed out: a piece that has been running for MZ_HEDGE_US (default 400 us --
+ * several times what a piece takes) is handed out AGAIN to a thread that has nothing else to do, and the loop is complete when every
+ * piece has been finished by somebody.  Why: on the GPU boxes of this project a host thread is now and then off the CPU for 1-6 ms
+ * in the middle of a piece (tests/tools/stall_hunt.py: one call in eight of mz_yama_batch() took 1.2-2.4 x the median, and in every
+ * one of them ONE piece of a chunk's packing or assembling came in late -- the chunk, and every chunk behind it, waited).  The thread
+ * that was late still finishes its piece, some time: whoever owns what the pieces write waits for the loop to be QUIET
+ * (mzi_job_quiet) before that is reused or handed on. */
+static int g_hedge_us = -1;
+static pjob *g_out;                                      /* hedged loops with pieces running, all handed out (linked by olink) */
+
+static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * t.tv_sec + 1e-3 * t.tv_nsec; }
+
 /* the next piece of the oldest job that has one (pool lock held); the job leaves the list with its last piece */
-static pjob *grab_any(int *lo, int *hi)
+static pjob *grab_any(int *lo, int *hi, int *piece)
 {
     pjob *j = g_pool.head;
     if (!j) return NULL;
     *lo = j->next;
     *hi = j->next + j->grain < j->n ? j->next + j->grain : j->n;
+    *piece = j->next / j->grain;
     j->next = *hi;
-    if (j->next >= j->n) { g_pool.head = j->link; j->link = NULL; }
+    j->active++;
+    if (j->hedge) { j->state[*piece] = 1; j->t_start[*piece] = now_us(); }
+    if (j->next >= j->n) {
+        g_pool.head = j->link; j->link = NULL;
+        if (j->hedge) { j->olink = g_out; g_out = j; }
+    }
     return j;
 }
 
-/* a piece [lo, hi) of j has been run (pool lock held on entry and on return; released around a posted job's callback) */
-static void piece_done(pjob *j, int lo, int hi)
+/* a piece somebody has been at for too long, to be run once more (pool lock held) */
+static pjob *grab_late(int *lo, int *hi, int *piece)
 {
-    j->pending -= hi - lo;
-    if (j->pending > 0) return;
-    if (!j->done) { pthread_cond_broadcast(&g_pool.done); return; }
-    {
+    pjob *j;
+    const double t = now_us();
+    for (j = g_out; j; j = j->olink) {
+        int i;
+        for (i = 0; i < j->npiece; ++i)
+            if (j->state[i] == 1 && t - j->t_start[i] > g_hedge_us) {
+                j->state[i] = 3;                         /* (twice is enough) */
+                j->active++;
+                j->hedged++;
+                *piece = i; *lo = i * j->grain; *hi = *lo + j->grain < j->n ? *lo + j->grain : j->n;
+                return j;
+            }
+    }
+    return NULL;
+}
+
+/* one run of piece `piece` = [lo, hi) of j has ended (pool lock held on entry and on return; released around a posted job's callback) */
+static void piece_done(pjob *j, int lo, int hi, int piece)
+{
+    int complete = 0;
+    j->active--;
+    if (!j->hedge) { j->pending -= hi - lo; complete = j->pending == 0; }
+    else if (j->state[piece] != 2) { j->state[piece] = 2; j->pending -= hi - lo; complete = j->pending == 0; }
+    if (complete && j->hedge) { pjob **pp; for (pp = &g_out; *pp && *pp != j; pp = &(*pp)->olink) ; if (*pp) *pp = j->olink; j->olink = NULL; }
+    if (j->active == 0 || (complete && !j->done)) pthread_cond_broadcast(&g_pool.done);      /* (somebody may wait for the loop to be quiet) */
+    if (complete && j->done) {
         void (*done)(void *) = j->done;
         void *arg = j->arg;
-        pthread_mutex_unlock(&g_pool.mu);                /* (the callback may free or re-post the job) */
+        pthread_mutex_unlock(&g_pool.mu);                /* (the callback may re-post the job -- once it is quiet) */
         done(arg);
         pthread_mutex_lock(&g_pool.mu);
     }
 }
 
-/* jobs posted so far: with MZ_POOL_SPIN_US=<n> a worker that has run out of work watches this for n microseconds before
- * it goes to sleep.  Off by default: measured on the 50 000-pair C2 call (a job every ~0.3 ms), 0 / 40 / 100 / 300 us all
- * gave 9.4-9.8 ms -- the wake-up of the sleepers is not what the packing waits for */
-static unsigned g_posted;
-static int g_spin_us = -1;
+/* nothing to do (pool lock held): sleep until something is posted -- or, while hedged loops have pieces out, for a fraction of the
+ * hedging time */
+static void idle_wait(void)
+{
+    if (g_out) {
+        struct timespec t;
+        clock_gettime(CLOCK_REALTIME, &t);
+        t.tv_nsec += 1000L * (g_hedge_us / 2 > 50 ? g_hedge_us / 2 : 50);
+        if (t.tv_nsec >= 1000000000L) { t.tv_nsec -= 1000000000L; t.tv_sec++; }
+        pthread_cond_timedwait(&g_pool.work, &g_pool.mu, &t);
+    } else pthread_cond_wait(&g_pool.work, &g_pool.mu);
+}
 
 static void *pool_worker(void *arg)
 {
@@ -101,32 +150,12 @@ static void *pool_worker(void *arg)
     pthread_mutex_lock(&g_pool.mu);
     while (!g_pool.quit) {
         pjob *j;
-        int lo, hi;
-        if (!(j = grab_any(&lo, &hi))) {
-            if (g_spin_us > 0) {
-                const unsigned seen = __atomic_load_n(&g_posted, __ATOMIC_RELAXED);
-                struct timespec t0, t1;
-                pthread_mutex_unlock(&g_pool.mu);
-                clock_gettime(CLOCK_MONOTONIC, &t0);
-                for (;;) {
-                    int k;
-                    for (k = 0; k < 64; ++k) __builtin_ia32_pause();
-                    if (__atomic_load_n(&g_posted, __ATOMIC_ACQUIRE) != seen) break;
-                    clock_gettime(CLOCK_MONOTONIC, &t1);
-                    if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L >= g_spin_us) break;
-                }
-                pthread_mutex_lock(&g_pool.mu);
-                if (g_pool.quit) break;
-                if ((j = grab_any(&lo, &hi))) goto work;
-            }
-            pthread_cond_wait(&g_pool.work, &g_pool.mu);
-            continue;
-        }
-work:
+        int lo, hi, piece;
+        if (!(j = grab_any(&lo, &hi, &piece)) && !(j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
-        piece_done(j, lo, hi);
+        piece_done(j, lo, hi, piece);
     }
     pthread_mutex_unlock(&g_pool.mu);
     return NULL;
@@ -142,7 +171,7 @@ static void pool_start_locked(void)
     if (want > MZ_COPY_THREADS && !(e && atoi(e) > 0)) want = MZ_COPY_THREADS;
     if (want < 1) want = 1;
     if (want > POOL_MAX) want = POOL_MAX;
-    if (g_spin_us < 0) { const char *sp = getenv("MZ_POOL_SPIN_US"); g_spin_us = sp ? atoi(sp) : 0; }
+    if (g_hedge_us < 0) { const char *h = getenv("MZ_HEDGE_US"); g_hedge_us = h ? atoi(h) : 400; }     /* (0: pieces are never run twice) */
     g_pool.started = 1;
     g_pool.nthreads = 0;
     for (i = 0; i < want - 1; ++i) {
@@ -164,11 +193,13 @@ int mzi_pool_threads(void)
 static void enqueue(pjob *job)                            /* (pool lock held) jobs in arrival order: the older chunk first */
 {
     pjob **pp;
-    job->next = 0; job->pending = job->n; job->link = NULL;
+    job->next = 0; job->pending = job->n; job->link = NULL; job->olink = NULL; job->active = 0; job->hedged = 0;
     if (!g_pool.started) pool_start_locked();
+    job->npiece = (job->n + job->grain - 1) / job->grain;
+    if (job->hedge && (!job->done || g_hedge_us <= 0 || job->npiece > MZ_HEDGE_PIECES)) job->hedge = 0;
+    if (job->hedge) memset(job->state, 0, (size_t)job->npiece);
     for (pp = &g_pool.head; *pp; pp = &(*pp)->link) ;
     *pp = job;
-    __atomic_fetch_add(&g_posted, 1u, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&g_pool.work);
 }
 
@@ -187,13 +218,15 @@ void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx)
     while (job.next < job.n) {                               /* the caller works on ITS loop (older jobs are the workers') */
         const int lo = job.next, hi = lo + grain < n ? lo + grain : n;
         job.next = hi;
+        job.active++;
         if (hi >= n) { pjob **pp; for (pp = &g_pool.head; *pp != &job; pp = &(*pp)->link) ; *pp = job.link; job.link = NULL; }
         pthread_mutex_unlock(&g_pool.mu);
         fn(ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
+        job.active--;
         job.pending -= hi - lo;
     }
-    while (job.pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    while (job.pending > 0 || job.active > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
     pthread_mutex_unlock(&g_pool.mu);
 }
 
@@ -202,6 +235,7 @@ void mzi_parallel_for(int n, int grain, mz_pfn fn, void *ctx)
 void mzi_post(mz_ajob *job)
 {
     if (job->grain < 1) job->grain = 1;
+    job->active = 0; job->hedged = 0;
     if (job->n <= 0) { if (job->done) job->done(job->arg); return; }
     pthread_mutex_lock(&g_pool.mu);
     enqueue(job);
@@ -216,14 +250,25 @@ void mzi_help_until(int (*ready)(void *), void *arg)
     pthread_mutex_lock(&g_pool.mu);
     while (!ready(arg)) {
         pjob *j;
-        int lo, hi;
-        if (!(j = grab_any(&lo, &hi))) { pthread_cond_wait(&g_pool.work, &g_pool.mu); continue; }
+        int lo, hi, piece;
+        if (!(j = grab_any(&lo, &hi, &piece)) && !(j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
-        piece_done(j, lo, hi);
+        piece_done(j, lo, hi, piece);
     }
     pthread_mutex_unlock(&g_pool.mu);
+}
+/* wait until nobody is running a piece of a posted loop any more (it is complete: its callback has been called); returns how many
+ * of its pieces were handed out twice */
+int mzi_job_quiet(mz_ajob *job)
+{
+    int h;
+    pthread_mutex_lock(&g_pool.mu);
+    while (job->active > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    h = job->hedged;
+    pthread_mutex_unlock(&g_pool.mu);
+    return h;
 }
 void mzi_pool_kick(void)
 {

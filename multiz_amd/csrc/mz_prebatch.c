@@ -216,7 +216,7 @@ static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n,
     /* (the prep records' size is bounded by the slices' columns: MZ_PREP_BOUND -- they are made right behind the plan) */
     c->b.prep = (uint32_t *)X->d_prep[set].p; c->b.capPrep = (int64_t)(X->d_prep[set].cap / 4);
     c->pc.jobs = jobs; c->pc.hoT1 = hT1; c->pc.hTxt = hTxt;
-    pack->fn = pack_text; pack->ctx = &c->pc; pack->n = n; pack->grain = pre_grain(n);
+    pack->fn = pack_text; pack->ctx = &c->pc; pack->n = n; pack->grain = pre_grain(n); pack->hedge = 1;
     c->t_pack1 = mzi_now_s();
     return 0;
 }
@@ -346,17 +346,15 @@ typedef struct pasm {
 static void assemble_merges(void *ctx, int lo, int hi)
 {
     pasm *q = (pasm *)ctx;
-    int p, failed = 0;
-    int64_t cells = 0;
-    for (p = lo; p < hi; ++p) {
+    int p;
+    for (p = lo; p < hi; ++p) {                          /* (a piece may be run twice -- mz_pool.c -- so it adds nothing up: pchunk_done() does) */
         const mz_prejob *j = &q->jobs[p];
         const mz_pre_rec *r = &q->rec[p];
-        cells += r->cells;
         mz_preout *o = &q->outs[p];
         const int W = j->K + j->L1 - 1, two = j->v == 0;
         memset(o, 0, sizeof *o);
         o->null_result = r->nullres; o->status = r->status; o->badrow = r->badrow; o->stage = r->stage; o->M = r->M; o->N = r->N;
-        if (r->nullres || r->status != MZ_OK) { failed++; continue; }
+        if (r->nullres || r->status != MZ_OK) continue;
         o->OM = r->om;
         o->score = (double)r->score;
         {
@@ -371,7 +369,7 @@ static void assemble_merges(void *ctx, int lo, int hi)
             uint8_t tmp_small[4096 + 16], *tmp = NULL;
             int k;
             if (two || sqB) tmp = longest + 16 <= sizeof tmp_small ? tmp_small : (uint8_t *)malloc(longest + 16);
-            if (!rows || ((two || sqB) && !tmp)) { if (rows != small) free(rows); q->oom = 1; o->status = MZ_E_DEVICE; failed++; continue; }
+            if (!rows || ((two || sqB) && !tmp)) { if (rows != small) free(rows); q->oom = 1; o->status = MZ_E_DEVICE; continue; }
             for (k = 0; k < j->K; ++k) {
                 mz_rowspec *s = &rows[k];
                 s->src = (const uint8_t *)j->rows1[k]; s->n = j->M_all; s->tmp = tmp;
@@ -392,8 +390,6 @@ static void assemble_merges(void *ctx, int lo, int hi)
             if (tmp && tmp != tmp_small) free(tmp);
         }
     }
-    if (failed) __atomic_fetch_add(&q->failed, failed, __ATOMIC_RELAXED);
-    __atomic_fetch_add(&q->cells, cells, __ATOMIC_RELAXED);
     _mm_sfence();
 }
 
@@ -438,16 +434,18 @@ static int pchunk_collect(pchunk *c, mz_ajob *post)
     a->size = (const int32_t *)(r + 64 + mzi_al256(sizeof(mz_pre_rec) * (size_t)n));
     a->masks = (const uint8_t *)a->size + mzi_al256(4 * c->nrow);
     a->hoRow = c->hoRow; a->hoMask = c->hoMask; a->where = where; a->block = block; a->failed = 0; a->oom = 0; a->cells = 0;
-    post->fn = assemble_merges; post->ctx = a; post->n = n; post->grain = pre_grain(n);
+    post->fn = assemble_merges; post->ctx = a; post->n = n; post->grain = pre_grain(n); post->hedge = 1;
     return 0;
 }
 
 static int pchunk_done(pchunk *c)
 {
-    const pasm *a = c->a;
+    pasm *a = c->a;
+    int p;
+    a->failed = 0; a->cells = 0;
+    for (p = 0; p < c->n; ++p) { a->failed += c->outs[p].null_result || c->outs[p].status != MZ_OK; a->cells += a->rec[p].cells; }
     c->cells = a->cells;
     c->outs[0].block = a->block;
-    free(c->where); c->where = NULL;
     c->t_col2 = mzi_now_s();
     if (a->oom) return mzi_set_err("out of memory for the merged rows");
     return a->failed;
@@ -485,15 +483,17 @@ static void pchunk_report(const ppipe *P, const pchunk *c)
             g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
 }
 
-/* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides): twelve, as mz_yama_batch() -- four when most of the merges are
- * two-stage ones: a chunk of those goes through two plans and two sets of DP / walk / emit, every stage with its wait for the stage
- * before, and fewer, larger chunks measured better (C2-shaped text, 50 000 two-stage merges, 4 / 6 / 8 / 12 / 16 pieces: 19.9 / 21.6 /
- * 23.6 / 22.2 / 25.7 ms; one-stage merges: 10.0 / 9.9 / 10.4 / 9.6 / 11.1) */
+/* pieces a GPU's share of a call is cut into (MZ_CHUNKS overrides): chunks of about 5 000 merges, three to sixteen of them, as
+ * mz_yama_batch() (mz_batch.c: chunk_parts) -- of about 10 000 when most of the merges are two-stage ones: a chunk of those goes through
+ * two plans and two sets of DP / walk / emit, every stage with its wait for the stage before */
 static int pre_parts(int n, int two_stage)
 {
     static int v = -1;
+    int parts;
     if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
-    return v ? v : 2 * two_stage >= n ? 4 : 12;
+    if (v) return v;
+    parts = 2 * two_stage >= n ? (n + 5000) / 10000 : (n + 2500) / 5000;
+    return parts < 3 ? 3 : parts > 16 ? 16 : parts;
 }
 
 #define PRE_MIN_CHUNK 1024

@@ -15,8 +15,20 @@ nb = int(batch["offBand"][-1]) + int(batch["M"][-1]) + 1
 cells = int((batch["poolRB"][:nb].astype(np.int64) - batch["poolLB"][:nb] + 1).sum())
 import os
 def vm():
-    want = ("numa_hint_faults", "numa_pages_migrated", "pgmigrate_success", "thp_migration_success", "pgfault", "numa_pte_updates")
-    return {k: int(v) for k, v in (l.split() for l in open("/proc/vmstat")) if k in want}
+    want = ("numa_hint_faults", "numa_pages_migrated", "pgmigrate_success", "thp_migration_success", "numa_pte_updates")
+    d = {k: int(v) for k, v in (l.split() for l in open("/proc/vmstat")) if k in want}
+    try:                                                 # the cgroup's CPU quota: periods in which it ran out, time spent throttled
+        for l in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = l.split()
+            if k in ("nr_throttled", "throttled_usec", "nr_periods"): d[k] = int(v)
+    except OSError:
+        pass
+    try:                                                 # this process: context switches it did not ask for
+        for l in open("/proc/self/status"):
+            if l.startswith("nonvoluntary_ctxt_switches"): d["main_thread_preempted"] = int(l.split()[1])
+    except OSError:
+        pass
+    return d
 for rep in range(int(os.environ.get("HOSTPATH_REPS", "4"))):
     v0 = vm()
     t = time.perf_counter()

@@ -2,7 +2,9 @@
  * waited for (mzi_parallel_for) from several threads at once, loops that are posted (mzi_post) with their completion callbacks, and a
  * caller that works in the pool until a condition holds (mzi_help_until / mzi_pool_kick).  Built with -fsanitize=thread by
  * tests/test_sanitizers.py; prints "pool ok" when every piece of every loop ran exactly once. */
+#define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,6 +23,19 @@ static void body(void *ctx, int lo, int hi)
     volatile unsigned x = 0;
     for (i = lo; i < hi; ++i) { h[i]++; for (int k = 0; k < 50; ++k) x += (unsigned)k; }
 }
+/* a loop whose pieces may be run twice (job.hedge): every piece stores the same values; piece 3 of it dawdles for 3 ms the first time */
+static unsigned char hhit[NITEM];
+static int dawdled, hedge_done;
+static void hbody(void *ctx, int lo, int hi)
+{
+    int i;
+    (void)ctx;
+    if (lo == 3 * 25 && !__atomic_exchange_n(&dawdled, 1, __ATOMIC_ACQ_REL)) { struct timespec t = { 0, 3000000 }; nanosleep(&t, NULL); }
+    for (i = lo; i < hi; ++i) __atomic_store_n(&hhit[i], 1, __ATOMIC_RELAXED);
+}
+static void on_hdone(void *arg) { (void)arg; __atomic_store_n(&hedge_done, 1, __ATOMIC_RELEASE); mzi_pool_kick(); }
+static int hedge_ready(void *arg) { (void)arg; return __atomic_load_n(&hedge_done, __ATOMIC_ACQUIRE); }
+
 static void on_done(void *arg)
 {
     int j = (int)(long)arg;
@@ -61,6 +76,25 @@ int main(void)
             const int n = j % 7 == 3 ? 0 : NITEM - j;
             if (!done_flag[j]) ++bad;
             for (i = 0; i < NITEM; ++i) bad += hit[j][i] != (i < n);
+        }
+    }
+    {   /* the hedged loop: complete well before the dawdler is back (400 us + a piece), quiet only after it */
+        static mz_ajob hj;
+        struct timespec t0, t1, t2;
+        int twice;
+        memset(&hj, 0, sizeof hj);
+        hj.fn = hbody; hj.n = NITEM; hj.grain = 25; hj.done = on_hdone; hj.hedge = 1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        mzi_post(&hj);
+        mzi_help_until(hedge_ready, NULL);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        twice = mzi_job_quiet(&hj);
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        for (i = 0; i < NITEM; ++i) bad += hhit[i] != 1;
+        {
+            const double done_ms = 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), quiet_ms = 1e3 * (t2.tv_sec - t0.tv_sec) + 1e-6 * (t2.tv_nsec - t0.tv_nsec);
+            printf("hedged loop: complete after %.2f ms, quiet after %.2f ms, %d piece(s) run twice\n", done_ms, quiet_ms, twice);
+            if (getenv("MZ_HEDGE_US") == NULL && (twice < 1 || done_ms > 2.5 || quiet_ms < 2.5)) { printf("hedging did not work\n"); ++bad; }
         }
     }
     mzi_pool_stop();
