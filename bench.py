@@ -16,7 +16,7 @@ beside the value.  `--gpus N` without a torch.distributed environment starts the
 
 One JSON line on stdout (rank 0).  `value` is the whole-job rate of the pipelined, device-resident form.  Beside it
 (SURVEY.md section 8d asks for both columns): `value_host` = the same batch through mz_yama_batch() from host
-buffers to malloc()ed merged columns, PCIe both ways included (N=1), and `kernel_gcups` = the phases one after the
+buffers to malloc()ed merged columns, PCIe both ways included (N=1), and `single_batch_gcups` = the phases one after the
 other from HIP events.  Cells are band cells, counted exactly as the reference counts tback_size (mz_yama.c:60-66).
 """
 import argparse
@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) columns")
     ap.add_argument("--no-pre", action="store_true", help="skip the block-text column (value_pre)")
+    ap.add_argument("--host-reps", type=int, default=25, help="timed calls of the host-buffer column (median; the spread is in host_spread)")
     ap.add_argument("--pre-check", type=int, default=300, help="merges per variant the text path's parity gate samples (0: none)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 builds the whole list and deals it out (multiz_amd.shard)")
     ap.add_argument("--pre-v", type=int, default=2, help="--mode pre: 1 one-stage merges, 0 two-stage, 2 alternating")
@@ -631,9 +632,8 @@ def main():
                    "pairs_total": all_pairs, "band_cells_total": all_cells,
                    "parallelism": f"pairs sharded x{world}" + (" (list built on rank 0, RCCL scatter/gather)" if exchange else "")},
         # the second column of SURVEY 8(d): the phases one after the other (HIP events, serial form)
-        "kernel_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
-        # the same figure under the name VERDICT r3 asked for: ONE batch, plan -> DP -> walk -> emit one after the other, nothing of a
-        # neighbouring batch beside it (`value` is the pipelined form: at C5 five batches abreast)
+        # ONE batch, plan -> DP -> walk -> emit one after the other, nothing of a neighbouring batch beside it (`value` is the pipelined
+        # form: at C5 five batches abreast)
         "single_batch_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
         "kernel_ms": {"plan": round(float(kern_ms[0]), 3), "dp": round(dp_ms, 3),
                       "walk": round(float(kern_ms[2]), 3), "emit": round(float(kern_ms[3]), 3)},
@@ -666,6 +666,9 @@ def main():
             v["clock_ghz"] = clock
             v["frac"] = round(pmc["SQ_INSTS_VALU"] * cpi / (SIMDS * cyc), 4)
             assert v["frac"] <= 1.0, f"roofline.valu.frac {v['frac']} > 1: the opcode pricing is wrong"
+            if v["frac"] > out["roofline"]["frac"]:
+                # the roof the launch is nearest to: integer VALU issue, not HBM (frac / achieved / peak stay the HBM figures SURVEY 8d defines)
+                out["roofline"]["bound"] = "valu"
             if clock:
                 v["frac_at_this_runs_dp_time"] = round(pmc["SQ_INSTS_VALU"] * cpi / (SIMDS * clock * 1e9 * dp_ms * 1e-3), 4)
         out["roofline"]["valu"] = v
@@ -705,7 +708,7 @@ def main():
         # (the container's CPU quota is per 100 ms period: let the period the harness's own threads -- generator, checker --
         #  have drawn on run out before the library's host threads are timed)
         time.sleep(0.3)
-        reps, t_host = 9, []
+        reps, t_host = max(3, args.host_reps), []
         os.environ["MZ_TIMING"] = "0"
         thr0 = cpu_throttle()
         for _ in range(reps):
@@ -726,7 +729,8 @@ def main():
         out["value_host"] = round(cells / t_med / 1e9, 2)
         out["host_ms_per_batch"] = round(1e3 * t_med, 2)
         out["host_ms_all"] = [round(1e3 * x, 2) for x in t_host]
-        out["host_spread"] = {"max_over_median": round(max(t_host) / t_med, 3), "min_over_median": round(min(t_host) / t_med, 3),
+        out["host_spread"] = {"calls": reps, "max_over_median": round(max(t_host) / t_med, 3), "min_over_median": round(min(t_host) / t_med, 3),
+                              "calls_above_1.15_median": int(sum(x > 1.15 * t_med for x in t_host)),
                               "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None)}
         link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
         out["host_link_bytes_per_pair"] = {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}

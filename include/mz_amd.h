@@ -219,7 +219,8 @@ typedef struct mz_out {
 } mz_out;
 
 /* Align n independent block pairs on the GPU(s).  Returns the number of failed pairs, or -1 on a device error;
- * in either case every outs[i] is defined: status MZ_E_DEVICE and cols == NULL for pairs without a result.
+ * in either case every outs[i] is defined: status MZ_E_DEVICE and cols == NULL for pairs without a result -- and in either
+ * case the caller releases outs with mz_free_outs(): after -1 the chunks that did come back still own their blocks.
  * What crosses the PCIe link is the byte CLASSES of the columns (two per byte), the band bounds as steps and, back,
  * a 32-byte record and a 2-bit edit script per pair; the merged columns (reference mz_yama.c:293-313) are assembled
  * on the host from the caller's own A and B, which must stay valid until the call returns.
@@ -315,7 +316,8 @@ typedef struct mz_preout {
                                      the rows and base counts of that chunk's merges (mz_free_preouts())     */
 } mz_preout;
 
-/* Returns the number of pairs without a block (refused or NULL), -1 on a device error, -2 when the current score
+/* Returns the number of pairs without a block (refused or NULL), -1 on a device error (mz_free_preouts() all the same: the
+ * chunks that did come back own their blocks), -2 when the current score
  * tables lack the structure the device form of mafScoreRange() needs (symmetric classes): use the host path then.
  * MZ_TIMING=1: one JSON line per call on stderr (merges, band cells, seconds, GCUPS, link bytes); 2: and one per chunk. */
 int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs);

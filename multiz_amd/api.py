@@ -142,19 +142,21 @@ def yama_batch(pairs: Sequence[tuple]) -> List[Result]:
         jobs[i].M, jobs[i].K = A.shape
         jobs[i].N, jobs[i].L = B.shape
         jobs[i].A, jobs[i].B, jobs[i].LB, jobs[i].RB = A.ctypes.data, B.ctypes.data, LB.ctypes.data, RB.ctypes.data
-    rc = lib().mz_yama_batch(n, jobs, outs)
-    _check(rc, "mz_yama_batch")
-    res = []
-    for i in range(n):
-        o = outs[i]
-        cols = None
-        if o.status == 0:
-            w = jobs[i].K + jobs[i].L
-            cols = np.frombuffer(C.string_at(o.cols, o.OM * w), dtype=np.uint8).reshape(o.OM, w).copy()
-        res.append(Result(o.status, o.badrow, o.OM, np.array(list(o.score), dtype=np.int32), cols))
     f = lib().mz_free_outs
     f.argtypes = [C.c_int, C.c_void_p]
-    f(n, C.cast(outs, C.c_void_p))                   # the call's result blocks (one per chunk: mz_out.block)
+    rc = lib().mz_yama_batch(n, jobs, outs)
+    try:
+        _check(rc, "mz_yama_batch")                      # (an error return leaves the blocks of the chunks that did come back: freed below)
+        res = []
+        for i in range(n):
+            o = outs[i]
+            cols = None
+            if o.status == 0:
+                w = jobs[i].K + jobs[i].L
+                cols = np.frombuffer(C.string_at(o.cols, o.OM * w), dtype=np.uint8).reshape(o.OM, w).copy()
+            res.append(Result(o.status, o.badrow, o.OM, np.array(list(o.score), dtype=np.int32), cols))
+    finally:
+        f(n, C.cast(outs, C.c_void_p))                   # the call's result blocks (one per chunk: mz_out.block)
     return res
 
 
@@ -332,21 +334,23 @@ def preyama_batch(jobs: Sequence[tuple]):
         cj[i].rows1, cj[i].rows2 = a1, a2
     f = lib().mz_preyama_batch
     f.argtypes = [C.c_int, C.POINTER(PreJob), C.POINTER(PreOut)]
-    rc = f(n, cj, co)
-    _check(rc, "mz_preyama_batch")
-    out = []
-    for i in range(n):
-        o, W = co[i], cj[i].K + cj[i].L1 - 1
-        d = dict(status=o.status, badrow=o.badrow, null=bool(o.null_result), null_code=o.null_result, stage=o.stage, M=o.M, N=o.N, OM=o.OM,
-                 score=o.score, size=None, rows=None)
-        if o.rows:
-            d["size"] = [o.size[k] for k in range(W)]
-            raw = C.string_at(o.rows, W * o.OM)
-            d["rows"] = [raw[k * o.OM:(k + 1) * o.OM] for k in range(W)]
-        out.append(d)
     fr = lib().mz_free_preouts
     fr.argtypes = [C.c_int, C.POINTER(PreOut)]
-    fr(n, co)                                        # the call's result blocks (one per chunk: mz_preout.block)
+    rc = f(n, cj, co)
+    try:
+        _check(rc, "mz_preyama_batch")                   # (an error return leaves the blocks of the chunks that did come back: freed below)
+        out = []
+        for i in range(n):
+            o, W = co[i], cj[i].K + cj[i].L1 - 1
+            d = dict(status=o.status, badrow=o.badrow, null=bool(o.null_result), null_code=o.null_result, stage=o.stage, M=o.M, N=o.N, OM=o.OM,
+                     score=o.score, size=None, rows=None)
+            if o.rows:
+                d["size"] = [o.size[k] for k in range(W)]
+                raw = C.string_at(o.rows, W * o.OM)
+                d["rows"] = [raw[k * o.OM:(k + 1) * o.OM] for k in range(W)]
+            out.append(d)
+    finally:
+        fr(n, co)                                        # the call's result blocks (one per chunk: mz_preout.block)
     return out
 
 

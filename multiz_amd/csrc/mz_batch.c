@@ -681,6 +681,11 @@ int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where,
     return 0;
 }
 
+/* A planned link image lives in buffer set 0 of the primary context (mz_link_plan): whatever else runs there takes it away, and
+ * mz_link_finish() then refuses instead of aligning somebody else's pools.  Called with g_big held. */
+static int g_link_planned;
+void mzi_link_forget(void) { g_link_planned = 0; }
+
 int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
 {
     static int env_pairs = -1;
@@ -695,6 +700,7 @@ int mz_yama_batch(int n, const mz_job *jobs, mz_out *outs)
         outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
     }
     pthread_mutex_lock(&g_big);
+    mzi_link_forget();
     {
         const int first = !g_ndev && g_timing;
         double t0 = mzi_now_s(), t1;
@@ -896,7 +902,7 @@ int mz_link_expand(const mz_link_desc *d, const void *dev_image, const void *dev
 }
 
 /* the planned image between mz_link_plan() and mz_link_finish() */
-static struct { mz_dev_batch b; int64_t n, res_bytes; int planned; } g_link;
+static struct { mz_dev_batch b; int64_t n, res_bytes, totals[16]; int planned; } g_link;
 
 int mz_link_plan(mz_link_desc *d, const void *dev_image, const void *dev_exc, void *stream)
 {
@@ -917,7 +923,7 @@ int mz_link_plan(mz_link_desc *d, const void *dev_image, const void *dev_exc, vo
     g_link.planned = 0;
     n = (int)d->n;
     d->res_bytes = 64 + (int64_t)mzi_al256(sizeof(mz_res_rec) * (size_t)n) + 64;
-    if (n == 0) { g_link.n = 0; g_link.res_bytes = d->res_bytes; g_link.planned = 1; pthread_mutex_unlock(&g_big); return 0; }
+    if (n == 0) { g_link.n = 0; g_link.res_bytes = d->res_bytes; g_link.planned = 1; g_link_planned = 1; pthread_mutex_unlock(&g_big); return 0; }
     st = stream ? (hipStream_t)stream : X->stream;
     LFAIL(mzi_dev_reserve(&X->d_cols[0], 2 * (mzi_al256((size_t)d->colsA / 2) + mzi_al256((size_t)d->colsB / 2)) + 256) ||
           mzi_dev_reserve(&X->d_band[0], 2 * mzi_al256(4 * (size_t)d->band)) ||
@@ -943,7 +949,8 @@ int mz_link_plan(mz_link_desc *d, const void *dev_image, const void *dev_exc, vo
     }
     totals = (const int64_t *)X->h_tot[0].p;
     d->res_bytes = 64 + (int64_t)mzi_al256(sizeof(mz_res_rec) * (size_t)n) + totals[1] / 4 + 64;
-    g_link.b = b; g_link.n = n; g_link.res_bytes = d->res_bytes; g_link.planned = 1;
+    memcpy(g_link.totals, totals, sizeof g_link.totals);         /* (h_tot[0] is the chunk pipelines' too) */
+    g_link.b = b; g_link.n = n; g_link.res_bytes = d->res_bytes; g_link.planned = 1; g_link_planned = 1;
     pthread_mutex_unlock(&g_big);
     return 0;
 }
@@ -958,16 +965,16 @@ int mz_link_finish(const mz_link_desc *d, void *dev_result, void *stream)
     int n;
 
     pthread_mutex_lock(&g_big);
-    if (!d || !g_link.planned || d->n != g_link.n || d->res_bytes != g_link.res_bytes || !dev_result) {
+    if (!d || !g_link.planned || !g_link_planned || d->n != g_link.n || d->res_bytes != g_link.res_bytes || !dev_result) {
         pthread_mutex_unlock(&g_big);
-        return mzi_set_err("mz_link_finish: not the image mz_link_plan() planned last");
+        return mzi_set_err("mz_link_finish: not the image mz_link_plan() planned last (or another batch call has run since)");
     }
     g_link.planned = 0;
     n = (int)d->n;
     st = stream ? (hipStream_t)stream : X->stream;
     if (n == 0) { pthread_mutex_unlock(&g_big); return 0; }
     b = g_link.b;
-    totals = (const int64_t *)X->h_tot[0].p;
+    totals = g_link.totals;
     LFAIL(mzi_dev_reserve(&X->d_tb[0], 4 * (size_t)totals[0] + 256) || mzi_dev_reserve(&X->d_script[0], (size_t)totals[1] + 256) ||
           mzi_dev_reserve(&X->d_prep[0], 4 * (size_t)totals[4] + 256));
     b.tbw = (uint32_t *)X->d_tb[0].p; b.script = (uint8_t *)X->d_script[0].p; b.out = NULL;

@@ -31,7 +31,7 @@
 #include "mz_device.h"
 
 #define WAVE   64
-#define ROLL_VMAX 90            // kernels/roll.inc: the longest wait (in steps) of a row the rolling form with late starts admits
+#define ROLL_VMAX 64            // kernels/roll.inc: the longest wait (in steps) of a row the rolling form with late starts admits (its rings hold 2 V + 128: static_assert there)
 #define MZ_ROWS_SUM(t11)     ((t11) & ((1LL << 44) - 1))      // totals[11]: rows (K+L) of all valid pairs ...
 #define MZ_TSTRIP_PAIRS(t11) ((t11) >> 44)                    // ... and the number of MZ_MODE_TSTRIP pairs (kernels/plan.inc, scan_load)
 #define BRING  128          // B-profile ring entries (columns) in LDS, 16 B each

@@ -618,6 +618,7 @@ int mz_preyama_batch(int n, const mz_prejob *jobs, mz_preout *outs)
         if (j->v == 0) any0 = 1;
     }
     pthread_mutex_lock(&g_big);
+    mzi_link_forget();
     if (mzi_ensure_init() || mzi_sync_scores()) { pthread_mutex_unlock(&g_big); return -1; }
     for (a = 0; a < 128; ++a)                              /* k_fin's pair sums need ss[x][y] == ss[y][x] */
         for (b = 0; b < a; ++b)

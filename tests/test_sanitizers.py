@@ -74,3 +74,17 @@ def test_host_helpers(san, tmp_path):
     p = subprocess.run([exe], capture_output=True, timeout=300, env=ENV)
     assert p.returncode == 0 and b"san host ok" in p.stdout, p.stderr.decode()[-3000:]
     _clean(p)
+
+
+def test_host_thread_pool_under_tsan_and_asan(tmp_path):
+    """mz_pool.c alone (no GPU): loops waited for and loops posted, from several threads at once, a caller working in the pool, and a
+    posted loop one piece of which dawdles -- it must be complete long before the dawdler is back (the piece is run a second time),
+    and quiet only after."""
+    src = [os.path.join(ROOT, "tests", "tools", "pool_stress.c"), os.path.join(ROOT, "multiz_amd", "csrc", "mz_pool.c")]
+    for flags, name in ((["-fsanitize=thread"], "tsan"), (["-fsanitize=address,undefined"], "asan")):
+        exe = str(tmp_path / ("pool_" + name))
+        subprocess.check_call(["gcc", "-O1", "-g", "-I/opt/rocm/include"] + flags + src + ["-o", exe, "-lpthread"])
+        p = subprocess.run([exe], capture_output=True, timeout=600, env=dict(ENV, MZ_HOST_THREADS="8"))
+        assert p.returncode == 0 and b"pool ok" in p.stdout, (p.stdout + p.stderr).decode()[-3000:]
+        assert b"ThreadSanitizer" not in p.stderr
+        _clean(p)

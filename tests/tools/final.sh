@@ -29,7 +29,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json
     try:
         d = json.load(open(f))
         r = d["roofline"]
-        print(os.path.basename(f), d["value"], "host", d.get("value_host"), d.get("host_ms_per_batch"), "pre", d.get("value_pre"), d.get("value_pre_v0"), "serial", d["kernel_gcups"], d["kernel_ms"],
+        print(os.path.basename(f), d["value"], "host", d.get("value_host"), d.get("host_ms_per_batch"), "pre", d.get("value_pre"), d.get("value_pre_v0"), "serial", d["single_batch_gcups"], d["kernel_ms"],
               "roof", r["frac"], "valu", (r.get("valu") or {}).get("frac"), "traffic", r.get("traffic"), "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("socket_linear"), d.get("vs_cpu"))
     except Exception as e:
         print(f, "unreadable", e)

@@ -123,7 +123,7 @@ int main(void)
         }
     }
     /* link images (mz_link_pack / mz_link_assemble: host only): jobs -> image, a hand-made result image -> merged columns; an image that
-     * is too short or points outside itself is refused */
+     * is too short, points outside itself, or holds a script that does not take the job's columns is refused */
     {
         enum { NJ = 7 };
         typedef struct { int32_t status, badrow, om, f[3]; int64_t off, cells; } res_rec;
@@ -165,6 +165,18 @@ int main(void)
         if (outs[2].status != MZ_E_NARROW || outs[2].cols) { fprintf(stderr, "a refused pair got columns\n"); return 1; }
         mz_free_outs(NJ, outs);
         if (mz_link_assemble(NJ, jobs, res, (int64_t)scripts_at - 8, outs) != -1) { fprintf(stderr, "a short image was accepted\n"); return 1; }
+        {   /* a record of the right size whose script takes a column of A at EVERY step: more columns of A than the job has (the
+             * assembly would read past the caller's A) */
+            const int om = jobs[4].M + jobs[4].N - 20;
+            uint8_t *keep = malloc(((size_t)om + 3) / 4);
+            memcpy(keep, res + scripts_at + rec[4].off, ((size_t)om + 3) / 4);
+            memset(res + scripts_at + rec[4].off, 0xAA, ((size_t)om + 3) / 4);          /* D D D D ... */
+            if (mz_link_assemble(NJ, jobs, res, (int64_t)bytes, outs) != -1) { fprintf(stderr, "a script that does not fit its job was accepted\n"); return 1; }
+            memcpy(res + scripts_at + rec[4].off, keep, ((size_t)om + 3) / 4);
+            free(keep);
+            if (mz_link_assemble(NJ, jobs, res, (int64_t)bytes, outs) != 1) { fprintf(stderr, "the restored image was refused: %s\n", mz_last_error()); return 1; }
+            mz_free_outs(NJ, outs);
+        }
         rec[4].off = (int64_t)bytes;
         if (mz_link_assemble(NJ, jobs, res, (int64_t)bytes, outs) != -1) { fprintf(stderr, "an image that points outside itself was accepted\n"); return 1; }
         free(res); mz_link_free(img); mz_link_free(exc);
