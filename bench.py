@@ -512,20 +512,25 @@ def main():
             t_gather = time.perf_counter() - t0
             exchange = {"format": "pools", "scatter_s": round(t_scatter, 4), "gather_s": round(t_gather, 4), "pairs_this_rank": int(len(my_idx))}
         else:
+            # the exchange in C (include/mz_shard.h): the library deals, packs, sends (RCCL: grouped ncclSend / ncclRecv), aligns where the
+            # image lands and assembles on the root; this script only times the three calls
             t0 = time.perf_counter()
-            (desc, image, exc), my_idx = shard.scatter_link(whole, 0, red)
+            share, my_idx = shard.scatter_link(whole, 0, red)
             torch.cuda.synchronize(dev)
             t_scatter = time.perf_counter() - t0
-            image, exc = image.to(dev), exc.to(dev)
             t0 = time.perf_counter()
-            res_l = shard.link_compute((desc, image, exc), device=dev)
+            res_l = shard.link_compute(share, device=dev)
             torch.cuda.synchronize(dev)
             t_align = time.perf_counter() - t0
+            desc = share.desc
+            h_image, h_exc = share.host_image()                   # (for the timed steps below: the share as a device-resident batch)
+            image, exc = torch.from_numpy(h_image).to(dev), torch.from_numpy(h_exc).to(dev)
             t0 = time.perf_counter()
-            sh = shard.gather_link(res_l, my_idx, whole, 0, red)
+            sh = shard.gather_link(share, my_idx, whole, 0, red)
             torch.cuda.synchronize(dev)
             t_gather = time.perf_counter() - t0
-            exchange = {"format": "link images", "scatter_s": round(t_scatter, 4), "align_s": round(t_align, 4), "gather_s": round(t_gather, 4),
+            exchange = {"format": "link images, exchanged by the library (mz_shard_*: " + ("RCCL" if dist.get_backend() == "nccl" else "the group's send / recv") + ")",
+                        "scatter_s": round(t_scatter, 4), "align_s": round(t_align, 4), "gather_s": round(t_gather, 4),
                         "pairs_this_rank": int(len(my_idx))}
             if rank == 0:
                 ex = shard.last_exchange

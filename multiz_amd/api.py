@@ -286,6 +286,157 @@ def link_assemble(jobs: np.ndarray, result: np.ndarray) -> np.ndarray:
     return outs
 
 
+# ---------------------------------------------------------------------------- include/mz_shard.h: the exchange in C
+# (multiz_amd/csrc/mz_shard.c: scatter / align / gather of a list that exists on one rank, over a table of transport functions)
+
+_SEND_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+_GROUP_T = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class Comm:
+    """an mz_comm of the library: RCCL (`Comm.rccl`), every rank in this process (`Comm.loopback`), or the caller's own blocking
+    send / recv of host bytes (`Comm.custom`: send(buf: np.ndarray uint8, peer), recv(buf, peer))"""
+
+    def __init__(self, ptr, rank, size, keep=()):
+        self.ptr, self.rank, self.size, self._keep = ptr, rank, size, keep
+
+    @staticmethod
+    def loopback(size: int):
+        arr = (C.c_void_p * size)()
+        f = lib().mz_comm_loopback
+        f.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        _check(f(size, arr), "mz_comm_loopback")
+        return [Comm(arr[r], r, size) for r in range(size)]
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        _check(lib().mz_comm_rccl_unique_id(buf), "mz_comm_rccl_unique_id")
+        return bytes(buf)
+
+    @staticmethod
+    def rccl(unique_id: bytes, rank: int, size: int):
+        p = C.c_void_p()
+        f = lib().mz_comm_rccl_create
+        f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _check(f(bytes(unique_id), rank, size, C.byref(p)), "mz_comm_rccl_create")
+        return Comm(p.value, rank, size)
+
+    @staticmethod
+    def custom(rank: int, size: int, send, recv):
+        def view(buf, n):
+            return np.ctypeslib.as_array((C.c_uint8 * n).from_address(buf)) if n else np.zeros(0, np.uint8)
+
+        def c_send(_u, buf, n, peer):
+            try:
+                send(view(buf, n), peer)
+                return 0
+            except Exception:                              # (into the library's error return)
+                return -1
+
+        def c_recv(_u, buf, n, peer):
+            try:
+                recv(view(buf, n), peer)
+                return 0
+            except Exception:
+                return -1
+        cs, cr = _SEND_T(c_send), _SEND_T(c_recv)
+        p = C.c_void_p()
+        f = lib().mz_comm_custom
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, _SEND_T, _SEND_T, _GROUP_T, _GROUP_T, C.POINTER(C.c_void_p)]
+        _check(f(rank, size, None, cs, cr, C.cast(None, _GROUP_T), C.cast(None, _GROUP_T), C.byref(p)), "mz_comm_custom")
+        return Comm(p.value, rank, size, keep=(cs, cr))
+
+    def echo(self, nbytes: int):
+        f = lib().mz_comm_echo
+        f.argtypes = [C.c_void_p, C.c_size_t]
+        _check(f(self.ptr, nbytes), "mz_comm_echo")
+
+    def free(self):
+        if self.ptr:
+            f = lib().mz_comm_free
+            f.argtypes = [C.c_void_p]
+            f(self.ptr)
+            self.ptr = None
+
+
+class Shard:
+    """one rank's share of a scattered list (mz_shard)"""
+
+    def __init__(self, comm: Comm, root: int, jobs: Optional[np.ndarray]):
+        L = lib()
+        self.comm, self.root = comm, root
+        self.jobs = np.ascontiguousarray(jobs) if jobs is not None else None
+        p = C.c_void_p()
+        L.mz_shard_scatter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        _check(L.mz_shard_scatter(comm.ptr, root, len(self.jobs) if self.jobs is not None else 0,
+                                  self.jobs.ctypes.data if self.jobs is not None and len(self.jobs) else None, C.byref(p)), "mz_shard_scatter")
+        self.ptr = p.value
+        L.mz_shard_desc.restype = C.POINTER(LinkDesc)
+        L.mz_shard_desc.argtypes = [C.c_void_p]
+        d = L.mz_shard_desc(self.ptr).contents
+        self.desc = np.array([getattr(d, k) for k, _ in LinkDesc._fields_], dtype=np.int64)
+        self.n = int(d.n)
+        L.mz_shard_index.restype = C.POINTER(C.c_int64)
+        L.mz_shard_index.argtypes = [C.c_void_p]
+        self.index = np.ctypeslib.as_array(L.mz_shard_index(self.ptr), shape=(self.n,)).copy() if self.n else np.zeros(0, np.int64)
+
+    def host_image(self):
+        """(image, exceptions) as numpy copies: for callers that align the share themselves"""
+        img, exc = C.c_void_p(), C.c_void_p()
+        f = lib().mz_shard_host_image
+        f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        _check(f(self.comm.ptr, self.ptr, C.byref(img), C.byref(exc)), "mz_shard_host_image")
+        nb, ne = int(self.desc[1]), int(self.desc[2])
+        image = np.ctypeslib.as_array((C.c_uint8 * nb).from_address(img.value)).copy() if nb else np.zeros(0, np.uint8)
+        excs = np.ctypeslib.as_array((C.c_uint8 * ne).from_address(exc.value)).copy() if ne else np.zeros(0, np.uint8)
+        return image, excs
+
+    def set_result(self, result: np.ndarray):
+        result = np.ascontiguousarray(result, dtype=np.uint8)
+        f = lib().mz_shard_set_result
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        _check(f(self.comm.ptr, self.ptr, result.ctypes.data, result.size), "mz_shard_set_result")
+
+    def align(self):
+        """the product's compute on the share where it lies in HBM (mz_link_plan + mz_link_finish)"""
+        f = lib().mz_shard_align
+        f.argtypes = [C.c_void_p]
+        _check(f(self.ptr), "mz_shard_align")
+
+    def totals(self):
+        """(band cells, pairs without a result) of this rank's share, once it has a result image"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        f = lib().mz_shard_totals
+        f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _check(f(self.comm.ptr, self.ptr, C.byref(a), C.byref(b)), "mz_shard_totals")
+        return a.value, b.value
+
+    def gather(self):
+        """every rank calls; the root gets (outs: OUT_DT records of the whole list in the jobs' order, pairs without a result)"""
+        f = lib().mz_shard_gather
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        is_root = self.comm.rank == self.root
+        outs = np.zeros(len(self.jobs), dtype=OUT_DT) if is_root else None
+        rc = f(self.comm.ptr, self.root, self.ptr, self.jobs.ctypes.data if is_root and len(self.jobs) else None,
+               outs.ctypes.data if is_root and len(outs) else None)
+        _check(rc, "mz_shard_gather")
+        return (outs, rc) if is_root else (None, 0)
+
+    def free(self):
+        if self.ptr:
+            f = lib().mz_shard_free
+            f.argtypes = [C.c_void_p, C.c_void_p]
+            f(self.comm.ptr, self.ptr)
+            self.ptr = None
+
+
+def shard_traffic():
+    a, b = C.c_int64(0), C.c_int64(0)
+    lib().mz_shard_traffic(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def link_expand(desc: np.ndarray, image, exc) -> dict:
     """mz_link_expand(): the image as a device-resident batch's tensors (DevBatch.from_tensors takes them): the header arrays are
     views into the image, the pools are expanded beside it (byte classes as canonical letters, int32 bounds)."""

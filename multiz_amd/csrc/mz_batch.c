@@ -838,7 +838,10 @@ int mz_link_pack(int n, const mz_job *jobs, mz_link_desc *d, void **image, void 
     h = (char *)link_alloc(y.bytes);
     esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *esz);
     if (!h || !esz) { free(h); free(esz); return mzi_set_err("out of memory"); }
-    memset(h, 0, y.steps);                                   /* (the gaps between the header's parts travel too) */
+    memset(h, 0, y.steps);                                   /* (the gaps between the header's parts travel too ... */
+    memset(h + y.steps + bytesC, 0, y.nibA - (y.steps + bytesC));                      /* ... and those behind the steps and the nibbles) */
+    memset(h + y.nibA + eA / 2, 0, y.nibB - (y.nibA + eA / 2));
+    memset(h + y.nibB + eB / 2, 0, y.bytes - (y.nibB + eB / 2));
     hK = (int32_t *)(h + y.K); hL = (int32_t *)(h + y.L); hM = (int32_t *)(h + y.M); hN = (int32_t *)(h + y.N);
     hoA = (int64_t *)(h + y.offA); hoB = (int64_t *)(h + y.offB); hoBand = (int64_t *)(h + y.offBand);
     hLen = (int32_t *)(h + y.len); hLB0 = (int32_t *)(h + y.lb0); hRB0 = (int32_t *)(h + y.rb0); hoC = (int64_t *)(h + y.offC);

@@ -237,66 +237,79 @@ def device_compute(shard: dict, device=None, keep: Optional[list] = None) -> dic
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# The same exchange on LINK IMAGES (include/mz_amd.h, mz_link_*): what leaves the root is what mz_yama_batch() sends over PCIe --
-# byte classes two per byte and band steps, packed by the library straight from the root's pools (no re-packed copy of
-# the pools in between) --, what comes back is a record per pair and the edit scripts at two bits per merged column; the root
-# assembles the merged columns from its own A and B.  C2: 3.1 KB out / 0.53 KB back per pair (pools: 6.0 / 4.3 and more),
-# C4's tree mix: about a third of the pools' 22.8 + 19.5 KB.
+# The same exchange on LINK IMAGES (include/mz_amd.h, mz_link_*), and IN C (include/mz_shard.h, multiz_amd/csrc/mz_shard.c): what
+# leaves the root is what mz_yama_batch() sends over PCIe -- byte classes two per byte and band steps, packed by the library
+# straight from the root's pools --, what comes back is a record per pair and the edit scripts at two bits per merged column; the
+# root assembles the merged columns from its own A and B.  C2: 3.1 KB out / 0.53 KB back per pair (pools: 6.0 / 4.3 and more), C4's
+# tree mix about a third of the pools' 22.8 + 19.5 KB.  Dealing, packing, the grouped sends and receives and the assembly are the
+# library's (mz_shard_scatter / _align / _gather); this module only gives it a transport: RCCL where the process group is "nccl"
+# (ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd inside the library, the communicator made from an id the group broadcasts),
+# the group's own blocking send / recv of host bytes where it is "gloo" (the CPU tests).
 
 last_exchange: Dict[str, int] = {}            # bytes of the last link scatter / gather on this rank (the root's are the totals)
+_comms: Dict[int, object] = {}
 
 
-def scatter_link(batch: Optional[Dict[str, np.ndarray]], src: int = 0, device="cpu", group=None):
-    """Root: partition, pack every rank's jobs as a link image, send.  Every rank: ((desc int64[8], image, exceptions) with the
-    two uint8 tensors on `device`, global indices of its pairs).  One broadcast of the descriptors, ONE batch of point-to-point ops."""
+def comm_for(group=None, device="cpu"):
+    """the library's transport (api.Comm) for a torch.distributed process group: made once per group"""
     import torch
     import torch.distributed as dist
     from . import api
+    key = id(group)
+    if key in _comms:
+        return _comms[key]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    header = torch.zeros((world, 9), dtype=torch.int64, device=device)
-    parts, packed = None, None
-    if rank == src:
-        parts = partition(pair_cost(batch), world)
-        jobs, _ = api.host_jobs(batch)
-        packed = [api.link_pack(jobs[p]) for p in parts]
-        header[:, :8] = torch.from_numpy(np.stack([d for d, _, _ in packed]))
-        header[:, 8] = torch.tensor([len(p) for p in parts], dtype=torch.int64)
-        last_exchange.update(pairs=int(len(batch["K"])), up_bytes=int(sum(8 * 9 + im.size + ex.size + 8 * len(p) for (_, im, ex), p in zip(packed, parts))))
-    dist.broadcast(header, src=src, group=group)
-    mine_h = header[rank].cpu().numpy()
-    desc = mine_h[:8].copy()
-    ops, keep = [], []
-    if rank == src:
-        image = exc = my_idx = None
-        for r in range(world):
-            _, im, ex = packed[r]
-            t_im, t_ex = torch.from_numpy(im).to(device), torch.from_numpy(ex).to(device)
-            t_idx = torch.from_numpy(parts[r].astype(np.int64)).to(device)
-            if r == src:
-                image, exc, my_idx = t_im, t_ex, t_idx
-            else:
-                keep.append((t_im, t_ex, t_idx))
-                ops += [dist.P2POp(dist.isend, t, r, group) for t in (t_im, t_ex, t_idx) if t.numel()]
+    if dist.get_backend(group) == "nccl":
+        t = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(api.Comm.rccl_unique_id()), dtype=torch.uint8).clone()
+        t = t.to(device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        comm = api.Comm.rccl(bytes(t.cpu().numpy().tobytes()), rank, world)
     else:
-        image = torch.empty(int(desc[1]), dtype=torch.uint8, device=device)
-        exc = torch.empty(int(desc[2]), dtype=torch.uint8, device=device)
-        my_idx = torch.empty(int(mine_h[8]), dtype=torch.int64, device=device)
-        ops += [dist.P2POp(dist.irecv, t, src, group) for t in (image, exc, my_idx) if t.numel()]
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    return (desc, image, exc), my_idx.cpu().numpy()
+        def send(buf, peer):
+            dist.send(torch.from_numpy(buf), dst=dist.get_global_rank(group, peer) if group is not None else peer, group=group)
+
+        def recv(buf, peer):
+            dist.recv(torch.from_numpy(buf), src=dist.get_global_rank(group, peer) if group is not None else peer, group=group)
+        comm = api.Comm.custom(rank, world, send, recv)
+    _comms[key] = comm
+    return comm
 
 
-def link_compute(shard, device=None) -> dict:
-    """The product's compute on a link image: mz_link_plan / mz_link_finish where the image lies in HBM (moved only if it arrived
-    elsewhere, as in the gloo tests).  Returns dict(result: uint8 tensor -- the result image --, cells, failed)."""
+def scatter_link(batch: Optional[Dict[str, np.ndarray]], src: int = 0, device="cpu", group=None):
+    """Root: deal, pack every rank's jobs as a link image, send (mz_shard_scatter).  Every rank: (its api.Shard, the global indices
+    of its pairs)."""
+    import torch.distributed as dist
+    from . import api
+    rank = dist.get_rank(group)
+    comm = comm_for(group, device)
+    s0, r0 = api.shard_traffic()
+    jobs = api.host_jobs(batch)[0] if rank == src else None
+    sh = api.Shard(comm, src, jobs)
+    s1, r1 = api.shard_traffic()
+    if rank == src:
+        last_exchange.update(pairs=int(len(batch["K"])), up_bytes=int(s1 - s0))
+    return sh, sh.index
+
+
+def link_compute(sh, device=None) -> dict:
+    """The product's compute on a share: where it arrived in HBM over RCCL, mz_shard_align (mz_link_plan / mz_link_finish on the image
+    where it lies); where it arrived in host memory (the gloo tests on a GPU box), the image is moved first.  -> dict(cells, failed)"""
     import torch
     from . import api
-    desc, image, exc = shard
-    dev = torch.device(device) if device is not None else image.device
-    res = api.link_run(desc, image.to(dev), exc.to(dev))
-    return link_totals(res, int(desc[0]))
+    try:
+        sh.align()
+    except RuntimeError as e:
+        if "host memory" not in str(e):
+            raise
+        dev = torch.device(device if device is not None else "cuda")
+        image, exc = sh.host_image()
+        res = api.link_run(sh.desc, torch.from_numpy(image).to(dev), torch.from_numpy(exc).to(dev))
+        torch.cuda.synchronize(dev)                      # (torch's default stream is the NULL stream: the library then runs on its own)
+        sh.set_result(res.cpu().numpy())
+    cells, failed = sh.totals()
+    return dict(cells=cells, failed=failed)
 
 
 def link_totals(res, n: int) -> dict:
@@ -311,87 +324,69 @@ def link_totals(res, n: int) -> dict:
     return dict(result=res, cells=int(cells.sum().item()), failed=int((status != 0).sum().item()))
 
 
-class ShardedOuts(Sharded):
-    """What the root holds after a link gather: the merged columns assembled from ITS OWN pools -- one block per rank's share
-    (mz_out.block) --, addressed like Sharded's buffers.  release() hands the blocks back to the library."""
+class ShardedOuts:
+    """What the root holds after a link gather: outs of the whole list in the caller's order (OUT_DT records: mz_out), the merged
+    columns assembled from ITS OWN pools in one block per rank's share.  release() hands the blocks back to the library."""
+
+    def __init__(self, outs: np.ndarray, widths: np.ndarray, index_of_rank: Optional[Dict[int, np.ndarray]] = None):
+        self.outs, self.widths = outs, np.asarray(widths, dtype=np.int64)
+        self.om, self.status = outs["OM"], outs["status"]
+        self.owner = np.full(len(outs), -1, dtype=np.int32)
+        for r, idx in (index_of_rank or {}).items():
+            self.owner[idx] = r
+
+    def cols(self, i: int) -> np.ndarray:
+        nb = int(self.om[i]) * int(self.widths[i])
+        return np.ctypeslib.as_array((C.c_uint8 * nb).from_address(int(self.outs["cols"][i]))) if nb else np.zeros(0, np.uint8)
+
+    def __iter__(self):
+        return (self.cols(i) for i in range(len(self.om)))
 
     def release(self):
         from . import api
-        for o in getattr(self, "_outs", []):
-            api.free_outs(o)
-        self._outs, self.bufs = [], {}
+        if self.outs is not None:
+            api.free_outs(self.outs)
+            self.outs = None
 
 
-def gather_link(res: dict, my_idx: np.ndarray, batch: Optional[Dict[str, np.ndarray]], dst: int = 0, device="cpu", group=None):
-    """res: what link_compute returned.  Result images and indices travel to the root in one grouped exchange; the root assembles
-    every share's merged columns from its own pools (mz_link_assemble) and returns a ShardedOuts; the others None."""
-    import ctypes as C
+def gather_link(sh, my_idx: np.ndarray, batch: Optional[Dict[str, np.ndarray]], dst: int = 0, device="cpu", group=None):
+    """Every rank's result image to the root (mz_shard_gather), which assembles every share's merged columns from its own pools and
+    returns a ShardedOuts; the others None."""
     import torch
     import torch.distributed as dist
     from . import api
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    t_res = res["result"].to(device)
-    t_idx = torch.from_numpy(np.ascontiguousarray(my_idx, dtype=np.int64)).to(device)
-    meta = torch.tensor([t_idx.numel(), t_res.numel()], dtype=torch.int64, device=device)
-    metas = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
+    s0, r0 = api.shard_traffic()
+    outs, _failed = sh.gather()
+    s1, r1 = api.shard_traffic()
+    # (who had which pair: for the callers' checks -- one all-gather of the index lists' sizes and one of the lists)
+    n_mine = torch.tensor([len(my_idx)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n_mine, group=group)
+    cap = max(int(x.item()) for x in sizes) if world else 0
+    mine = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=device)
+    mine[: len(my_idx)] = torch.from_numpy(np.ascontiguousarray(my_idx, dtype=np.int64)).to(device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
     if rank != dst:
-        ops = [dist.P2POp(dist.isend, t, dst, group) for t in (t_res, t_idx) if t.numel()]
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
-        last_exchange.update(down_bytes=int(t_res.numel() + 8 * t_idx.numel()))
+        last_exchange.update(down_bytes=int(s1 - s0))
+        sh.free()
         return None
-    bufs, ops = {}, []
-    for r in range(world):
-        if r == dst:
-            bufs[r] = (t_res, t_idx)
-            continue
-        n, nb = (int(x) for x in metas[r].tolist())
-        b = (torch.empty(nb, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.int64, device=device))
-        bufs[r] = b
-        ops += [dist.P2POp(dist.irecv, t, r, group) for t in b if t.numel()]
-    for w in (dist.batch_isend_irecv(ops) if ops else []):
-        w.wait()
-    last_exchange.update(down_bytes=int(sum(b[0].numel() + 8 * b[1].numel() for b in bufs.values())))
-    on_gpu = any(t.is_cuda for b in bufs.values() for t in b)
-    host = {}
-    for r, b in bufs.items():                                   # (pinned destinations, all copies issued before one synchronisation)
-        if on_gpu:
-            h = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in b)
-            for d_, t in zip(h, b):
-                d_.copy_(t, non_blocking=True)
-            host[r] = h
-        else:
-            host[r] = b
-    if on_gpu:
-        torch.cuda.synchronize()
-    n_total = len(batch["K"])
-    sh = ShardedOuts(n_total, batch["K"].astype(np.int64) + batch["L"].astype(np.int64))
-    jobs, _ = api.host_jobs(batch)
-    sh._outs = []
-    for r, (t_r, t_i) in host.items():
-        i = t_i.numpy()
-        if len(i) == 0:
-            continue
-        outs = api.link_assemble(jobs[i], t_r.numpy())
-        sh._outs.append(outs)
-        sh.om[i], sh.status[i], sh.owner[i] = outs["OM"], outs["status"], r
-        base = int(outs["block"][0])                             # (one call, one chunk: the block hangs on the share's first pair)
-        ok = outs["cols"] != 0
-        sh.off[i] = np.where(ok, outs["cols"].astype(np.int64) - base, 0)
-        size = int((sh.off[i] + outs["OM"].astype(np.int64) * sh.widths[i]).max()) if base else 0
-        sh.bufs[r] = np.ctypeslib.as_array((C.c_uint8 * size).from_address(base)) if size else np.zeros(0, np.uint8)
-    return sh
+    last_exchange.update(down_bytes=int(r1 - r0))
+    index_of_rank = {r: every[r][: int(sizes[r].item())].cpu().numpy() for r in range(world)}
+    res = ShardedOuts(outs, batch["K"].astype(np.int64) + batch["L"].astype(np.int64), index_of_rank)
+    sh.free()
+    return res
 
 
 def run_sharded_link(batch: Optional[Dict[str, np.ndarray]], compute: Callable = link_compute, src: int = 0, device="cpu", group=None):
-    """scatter_link -> compute(shard) -> gather_link.  compute takes (desc, image, exceptions) and returns dict(result, cells, failed).
-    Root gets (ShardedOuts, totals); others (None, totals)."""
-    shard, my_idx = scatter_link(batch, src, device, group)
-    res = compute(shard)
-    sh = gather_link(res, my_idx, batch, src, device, group)
+    """scatter_link -> compute(share) -> gather_link.  compute takes the api.Shard, gives it a result image (align() or set_result())
+    and returns dict(cells, failed).  Root gets (ShardedOuts, totals); others (None, totals)."""
+    sh, my_idx = scatter_link(batch, src, device, group)
+    res = compute(sh)
+    out = gather_link(sh, my_idx, batch, src, device, group)
     totals = close_batch(len(my_idx), res["cells"], res["failed"], device, group)
-    return sh, totals
+    return out, totals
 
 
 def run_sharded(batch: Optional[Dict[str, np.ndarray]], compute: Callable = device_compute, src: int = 0, device="cpu", group=None):

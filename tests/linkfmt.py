@@ -107,9 +107,10 @@ def oracle_result_image(desc, image, exc):
     return encode_results(recs), cells, failed
 
 
-def oracle_compute(shard):
-    """stands in for multiz_amd.shard.link_compute on a box without a GPU: same contract"""
-    import torch
-    desc, image, exc = shard
-    res, cells, failed = oracle_result_image(np.asarray(desc), image.cpu().numpy(), exc.cpu().numpy())
-    return dict(result=torch.from_numpy(res), cells=cells, failed=failed)
+def oracle_compute(sh):
+    """stands in for multiz_amd.shard.link_compute on a box without a GPU: same contract -- gives the share (api.Shard) its result
+    image and returns dict(cells, failed)"""
+    image, exc = sh.host_image()
+    res, cells, failed = oracle_result_image(np.asarray(sh.desc), image, exc)
+    sh.set_result(res)
+    return dict(cells=cells, failed=failed)

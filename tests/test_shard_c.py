@@ -1,0 +1,137 @@
+"""The exchange of multiz_amd/csrc/mz_shard.c (include/mz_shard.h) on CPU: a list that exists on one rank is dealt out, every share's
+link image travels, result images come back and the root assembles the merged columns from its own A and B -- the C code itself, over
+its loop-back transport (every rank in this process: one after the other, and as threads) and over a caller-supplied one.  Where the
+product aligns a share on its GPU (mz_shard_align) the oracle fills in the result image (tests/linkfmt.py)."""
+import threading
+
+import numpy as np
+import pytest
+
+import linkfmt
+from multiz_amd import api
+from oracle import mzoracle as mo
+from test_shard_gloo import _batch
+
+
+def _align_with_oracle(sh):
+    image, exc = sh.host_image()
+    res, cells, failed = linkfmt.oracle_result_image(sh.desc, image, exc)
+    sh.set_result(res)
+    return cells, failed
+
+
+def _check_root(outs, failed, batch, pairs, index_sets):
+    assert failed == 0 and (outs["status"] == 0).all()
+    W = batch["K"].astype(np.int64) + batch["L"]
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        want = mo.yama(A, B, LB, RB)
+        got = np.ctypeslib.as_array((api.C.c_uint8 * (int(outs["OM"][i]) * int(W[i]))).from_address(int(outs["cols"][i])))
+        assert int(outs["OM"][i]) == want.OM and np.array_equal(got, want.cols.ravel()), i
+    allidx = np.sort(np.concatenate(index_sets))
+    assert np.array_equal(allidx, np.arange(len(pairs)))          # every pair on exactly one rank
+
+
+@pytest.mark.parametrize("world,n", [(3, 23), (2, 1), (1, 9), (4, 3)])
+def test_loopback_ranks_one_after_the_other(world, n):
+    batch, pairs = _batch(11, n)
+    jobs, _ = api.host_jobs(batch)
+    comms = api.Comm.loopback(world)
+    s0, r0 = api.shard_traffic()
+    root = world - 1 if world > 2 else 0
+    order = [root] + [r for r in range(world) if r != root]      # the root's sends are in the mailbox when the others come to receive
+    shards = {}
+    for r in order:
+        shards[r] = api.Shard(comms[r], root, jobs if r == root else None)
+    assert sum(sh.n for sh in shards.values()) == n
+    for sh in shards.values():
+        _align_with_oracle(sh)
+    outs = None
+    for r in order[1:] + [root]:                                  # ... and theirs when the root comes to gather
+        o, failed = shards[r].gather()
+        if r == root:
+            outs = o
+            _check_root(outs, failed, batch, pairs, [s.index for s in shards.values()])
+    s1, r1 = api.shard_traffic()
+    assert world == 1 or (s1 > s0 and r1 > r0 and s1 - s0 == r1 - r0)      # what was sent arrived, byte for byte
+    api.free_outs(outs)
+    for sh in shards.values():
+        sh.free()
+    for c in comms:
+        c.free()
+
+
+def test_loopback_ranks_as_threads():
+    world, n, root = 3, 40, 1
+    batch, pairs = _batch(5, n)
+    jobs, _ = api.host_jobs(batch)
+    comms = api.Comm.loopback(world)
+    result, errors, idx = {}, [], [None] * world
+
+    def rank(r):
+        try:
+            sh = api.Shard(comms[r], root, jobs if r == root else None)
+            idx[r] = sh.index
+            _align_with_oracle(sh)
+            o, failed = sh.gather()
+            if r == root:
+                result["outs"], result["failed"] = o, failed
+            sh.free()
+        except Exception as e:                                    # noqa: BLE001
+            errors.append((r, repr(e)))
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors, errors
+    _check_root(result["outs"], result["failed"], batch, pairs, idx)
+    api.free_outs(result["outs"])
+    for c in comms:
+        c.free()
+
+
+def test_the_callers_own_transport_and_a_share_nobody_aligned():
+    """mz_comm_custom: two ranks whose send / recv are Python functions over queues (what multiz_amd/shard.py does with
+    torch.distributed where there is no RCCL); a gather before the share has a result is refused"""
+    import queue
+    world, n, root = 2, 12, 0
+    batch, pairs = _batch(2, n)
+    jobs, _ = api.host_jobs(batch)
+    box = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    comms = []
+    for r in range(world):
+        def send(buf, peer, r=r):
+            box[(r, peer)].put(buf.copy())
+
+        def recv(buf, peer, r=r):
+            m = box[(peer, r)].get(timeout=30)
+            assert m.size == buf.size
+            buf[:] = m
+        comms.append(api.Comm.custom(r, world, send, recv))
+    shards = [api.Shard(comms[0], root, jobs), api.Shard(comms[1], root, None)]
+    with pytest.raises(RuntimeError, match="has not been aligned"):
+        shards[1].gather()
+    for sh in shards:
+        _align_with_oracle(sh)
+    shards[1].gather()
+    outs, failed = shards[0].gather()
+    _check_root(outs, failed, batch, pairs, [s.index for s in shards])
+    api.free_outs(outs)
+    for sh in shards:
+        sh.free()
+    for c in comms:
+        c.free()
+
+
+def test_a_result_image_of_another_list_is_refused():
+    batch, pairs = _batch(7, 6)
+    jobs, _ = api.host_jobs(batch)
+    comms = api.Comm.loopback(1)
+    sh = api.Shard(comms[0], 0, jobs)
+    image, exc = sh.host_image()
+    res, _, _ = linkfmt.oracle_result_image(sh.desc, image, exc)
+    sh.set_result(res[: 64 + 8])                                 # too short for six records
+    with pytest.raises(RuntimeError, match="too short"):
+        sh.gather()
+    sh.free()
+    comms[0].free()

@@ -166,3 +166,47 @@ def test_result_image_is_the_oracles():
         c = np.ctypeslib.as_array((api.C.c_uint8 * (w.OM * (A.shape[1] + B.shape[1]))).from_address(int(outs["cols"][p])))
         assert outs["OM"][p] == w.OM and np.array_equal(c, w.cols.ravel()), p
     api.free_outs(outs)
+
+
+RCCL_CODE = r'''
+import sys, numpy as np
+sys.path.insert(0, ".")
+import multiz_amd as mz
+from multiz_amd import api, synth
+from oracle import mzoracle as mo
+api.init(0)
+comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1)                 # librccl is loaded here, by the library
+comm.echo(1 << 20)                                                     # ncclGroupStart; ncclSend + ncclRecv to this rank; ncclGroupEnd
+comm.echo(4096 + 16)
+c = synth.CONFIGS["c2i"]
+n = 1200
+batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=5, indel=c.get("indel", 0))
+jobs, _ = api.host_jobs(batch)
+sh = api.Shard(comm, 0, jobs)                                           # mz_shard_scatter: the one rank's own share, in device memory
+assert sh.n == n and sorted(sh.index.tolist()) == list(range(n))
+sh.align()                                                             # mz_link_plan + mz_link_finish where the image lies
+cells, failed = sh.totals()
+outs, bad = sh.gather()                                                 # mz_shard_gather: assembled from the root's own A and B
+om, hs, want_cells, refbad = mo.yama_batch(batch, variant=1, threads=8)
+assert failed == 0 and bad == 0 and refbad == 0 and cells == want_cells, (failed, bad, cells, want_cells)
+W = batch["K"].astype(np.int64) + batch["L"]
+for i in range(n):
+    m_ = int(outs["OM"][i])
+    got = np.ctypeslib.as_array((api.C.c_uint8 * (m_ * int(W[i]))).from_address(int(outs["cols"][i])))
+    assert m_ == om[i] and mo.fnv1a_np(got, mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
+api.free_outs(outs)
+sh.free()
+comm.free()
+print("rccl ok", api.shard_traffic())
+'''
+
+
+def test_rccl_world_of_one_through_the_c_leg():
+    """The library's RCCL transport with the ranks the test box has -- one: the communicator is made, a grouped ncclSend / ncclRecv to
+    itself moves a megabyte intact (mz_comm_echo), and scatter / align / gather run on it (no peer: the share does not travel, but
+    the buffers are the transport's device buffers and the align runs where they lie).  A child process: RCCL keeps threads."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", RCCL_CODE], cwd=root, capture_output=True, timeout=900)
+    assert p.returncode == 0 and b"rccl ok" in p.stdout, (p.stdout + p.stderr).decode()[-3000:]
