@@ -23,14 +23,14 @@ static void body(void *ctx, int lo, int hi)
     volatile unsigned x = 0;
     for (i = lo; i < hi; ++i) { h[i]++; for (int k = 0; k < 50; ++k) x += (unsigned)k; }
 }
-/* a loop whose pieces may be run twice (job.hedge): every piece stores the same values; piece 3 of it dawdles for 3 ms the first time */
+/* a loop whose pieces may be run twice (job.hedge): every piece stores the same values; piece 3 of it dawdles for 40 ms the first time */
 static unsigned char hhit[NITEM];
 static int dawdled, hedge_done;
 static void hbody(void *ctx, int lo, int hi)
 {
     int i;
     (void)ctx;
-    if (lo == 3 * 25 && !__atomic_exchange_n(&dawdled, 1, __ATOMIC_ACQ_REL)) { struct timespec t = { 0, 3000000 }; nanosleep(&t, NULL); }
+    if (lo == 3 * 25 && !__atomic_exchange_n(&dawdled, 1, __ATOMIC_ACQ_REL)) { struct timespec t = { 0, 40000000 }; nanosleep(&t, NULL); }
     for (i = lo; i < hi; ++i) __atomic_store_n(&hhit[i], 1, __ATOMIC_RELAXED);
 }
 static void on_hdone(void *arg) { (void)arg; __atomic_store_n(&hedge_done, 1, __ATOMIC_RELEASE); mzi_pool_kick(); }
@@ -78,7 +78,7 @@ int main(void)
             for (i = 0; i < NITEM; ++i) bad += hit[j][i] != (i < n);
         }
     }
-    {   /* the hedged loop: complete well before the dawdler is back (400 us + a piece), quiet only after it */
+    {   /* the hedged loop: complete well before the dawdler is back (400 us + a piece; the bound here is lenient: a loaded test machine), quiet only after it */
         static mz_ajob hj;
         struct timespec t0, t1, t2;
         int twice;
@@ -94,7 +94,7 @@ int main(void)
         {
             const double done_ms = 1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), quiet_ms = 1e3 * (t2.tv_sec - t0.tv_sec) + 1e-6 * (t2.tv_nsec - t0.tv_nsec);
             printf("hedged loop: complete after %.2f ms, quiet after %.2f ms, %d piece(s) run twice\n", done_ms, quiet_ms, twice);
-            if (getenv("MZ_HEDGE_US") == NULL && (twice < 1 || done_ms > 2.5 || quiet_ms < 2.5)) { printf("hedging did not work\n"); ++bad; }
+            if (getenv("MZ_HEDGE_US") == NULL && (twice < 1 || done_ms > 20.0 || quiet_ms < 30.0)) { printf("hedging did not work\n"); ++bad; }
         }
     }
     mzi_pool_stop();
