@@ -86,7 +86,7 @@ int main(void)
         hj.fn = hbody; hj.n = NITEM; hj.grain = 25; hj.done = on_hdone; hj.hedge = 1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         mzi_post(&hj);
-        mzi_help_until(hedge_ready, NULL);
+        while (!hedge_ready(NULL)) { struct timespec nap = { 0, 50000 }; nanosleep(&nap, NULL); }      /* (not working in the pool: this thread must not be the dawdler) */
         clock_gettime(CLOCK_MONOTONIC, &t1);
         twice = mzi_job_quiet(&hj);
         clock_gettime(CLOCK_MONOTONIC, &t2);
