@@ -20,6 +20,14 @@ for c in c3 c4 c5 c2i c4i c2w c2s c2g; do python bench.py --config $c --steps 30
 bash tests/tools/profile_pre.sh c2 ${TAG}_pre > $O/${TAG}_pre_profile_c2.txt 2>&1
 MZ_CHUNKS=1 MZ_CHUNK_PAIRS=1000000 bash tests/tools/profile_pre.sh c2 ${TAG}_pre_alone > $O/${TAG}_pre_alone_profile_c2.txt 2>&1
 cp gpurun_out/${TAG}_pre_kernel_stats_c2_v*.csv gpurun_out/${TAG}_pre_alone_kernel_stats_c2_v*.csv $O/ 2>/dev/null
+# the host paths' calls one by one: kernel timelines of one call each (band path, text path), 50 calls per configuration with the slow ones
+# explained (tests/tools/stall_hunt.py), and the command-processor measurements the stream layout rests on (tests/tools/ub/chain.hip)
+python tests/tools/timeline.py $O/tl_host host c2 > $O/${TAG}_timeline_host_c2.txt 2>&1
+python tests/tools/timeline.py $O/tl_host_c2i host c2i > $O/${TAG}_timeline_host_c2i.txt 2>&1
+python tests/tools/timeline.py $O/tl_pre pre c2 1 > $O/${TAG}_timeline_pre_c2_v1.txt 2>&1
+rm -rf $O/tl_host $O/tl_host_c2i $O/tl_pre
+for c in c2 c2i c3; do python tests/tools/stall_hunt.py $c 50; MZ_HEDGE_US=0 python tests/tools/stall_hunt.py $c 50 | sed 's/^/   (pieces never run twice) /'; done > $O/${TAG}_stall_hunt.txt 2>&1
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tests/tools/ub/chain.hip -o /tmp/chain 2>/dev/null && { /tmp/chain; for a in "1 6 20 1 64" "2 6 10 1 64" "1 1 20 1 64" "2 2 10 1 64"; do GPU_MAX_HW_QUEUES=8 /tmp/chain $a | tail -3; done; } > $O/${TAG}_pipes.txt 2>&1
 python tests/tools/roast_bench.py > $O/${TAG}_roast_bench.txt 2>&1
 # the guide-tree-scale run of the tree driver (30 leaves, ~1.9 M merges): per-batch JSON lines and phase times
 timeout 900 python tests/tools/roast_big.py 30 9000 600 > $O/${TAG}_roast30.txt 2>&1
