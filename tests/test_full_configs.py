@@ -102,6 +102,17 @@ def test_c5_full_size_1000_pairs(mz):
     assert len(om) == 1000 and batch["M"].min() >= 95000 and batch["M"].max() <= 105000
 
 
+@pytest.mark.parametrize("cfg", ["c2i", "c2g", "c2w", "c2s", "c4i"])
+def test_builder_configs_at_their_benched_size(mz, cfg):
+    """bench.py's own configurations (not BASELINE's: C2 / C4 shapes whose bands come from blocks with indels, with a heavy tail, at
+    radius 50 and 100 -- the lagged row kernel, the tagged wavefront, the strips, mixes of all of them in one batch) at the size
+    their bench lines are quoted on, every pair against the oracle on both product paths (under -m gpu these
+    kernels were only covered at 1 500 pairs and by the random sweeps)."""
+    from multiz_amd import synth
+    batch, om = _full_config(mz, cfg, ref_sample=200)
+    assert len(om) == synth.CONFIGS[cfg]["pairs"]
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "multiz_ref")), reason="oracle/_ref binaries not built")
 @pytest.mark.parametrize("v", [1, 0])
 def test_c1_two_100_block_mafs_literal(tmp_path, v):

@@ -110,7 +110,7 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert len(d["per_rank_gcups"]) == 2 and min(d["per_rank_gcups"]) > 0 and d["rank_max_over_min"] >= 1.0
     if extra:
         ex = d["exchange"]
-        assert ex["ranks_used"] == 2 and "RCCL" in d["config"]["parallelism"] and ex["format"] == "link images"
+        assert ex["ranks_used"] == 2 and "RCCL" in d["config"]["parallelism"] and ex["format"].startswith("link images")
         bp = ex["bytes_per_pair"]                                # class nibbles + band steps out, records + 2-bit scripts back
         assert bp["out"] < 0.5 * bp["pools_out"] and bp["out"] <= 8192 and bp["back"] <= 1024 and bp["back"] < 0.1 * bp["columns_back"]
         assert ex["checked_pairs"] >= 400                        # the root's assembled columns against the compiled reference
