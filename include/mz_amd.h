@@ -144,7 +144,11 @@ enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
 int mz_walk_choice(int n, const int64_t *totals);
 /* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint; bits 8..15: the one with the most), from the plan's
  * totals (host copy) */
-enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32 };
+enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32,
+       MZ_DP_HELPERS_FIRST = 0x10000 };   /* not a hint, a request (kept whatever hint_gen says): the batch's plan / prep / walk / emit kernels raise their waves'
+                                             issue priority.  For batches whose small kernels must get through beside OTHER batches' DP waves at once (the chunk
+                                             pipelines of mz_yama_batch / mz_preyama_batch: a late plan is an idle DP stream); a loss of 1.5-3 % for device-resident
+                                             batches, whose helpers only have to be done a whole DP later */
 int mz_dp_hint(int n, const int64_t *totals);
 int mz_dp_grid(int n, const int64_t *totals);
 int mz_dp_rows(int n, const int64_t *totals);

@@ -189,6 +189,7 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
 
     memset(&b, 0, sizeof b);
     b.n = n;
+    b.dp_hint = lane >= 0 ? MZ_DP_HELPERS_FIRST : 0;      /* (beside other chunks' DPs: include/mz_amd.h) */
 #define SLICE(hptr, type, field, bytes) do { hptr = (type *)h; b.field = (const type *)d; \
         h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
 #define SLICE2(hptr, dptr, type, bytes) do { hptr = (type *)h; dptr = (const type *)d; \
@@ -304,7 +305,7 @@ static int chunk_launch(chunk *c)
         return -1;
     b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = NULL;     /* (no merged columns on the device) */
     b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
-    b.dp_hint = mz_dp_hint(n, totals);                   /* (nor for DP kernels that have no pairs) */
+    b.dp_hint = mz_dp_hint(n, totals) | (b.dp_hint & MZ_DP_HELPERS_FIRST);      /* (nor for DP kernels that have no pairs) */
     b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
     if (c->lane >= 0 && !X->lanes_made && mz_dp_kinds(b.dp_hint) > 1 && mzi_flow_lanes(X)) return -1;     /* several kinds of pairs: the DP streams' lanes */
@@ -314,8 +315,15 @@ static int chunk_launch(chunk *c)
     if (mzk_dp_range_on(&b, 0, n, sd, c->lane < 0 ? NULL : &X->qlane[c->lane])) return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 3, sd);
     if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
-    if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
-        return mzi_set_err("%s", mzk_last_error());
+    {
+        /* MZ_TAIL_FIRST=0: the walk and the script packing at the DP waves' own priority (the results are needed a chunk later) */
+        static int tail_first = -1;
+        mz_dev_batch bt = b;
+        if (tail_first < 0) { const char *e = getenv("MZ_TAIL_FIRST"); tail_first = e ? atoi(e) : 1; }
+        if (!tail_first) bt.dp_hint &= ~MZ_DP_HELPERS_FIRST;
+        if (mzk_walk(&bt, st, 1) || mzk_script_pack(&bt, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
+            return mzi_set_err("%s", mzk_last_error());
+    }
     TSTAMP(X, set, 4, st);
     /* the results go home as the chunk's last kernel: no copy engine, nothing that could wait for anything but this chunk's
      * own kernels */

@@ -61,6 +61,9 @@
 #endif
 #define HELPER_VGPRS
 #define HELPER_PRIO() do { if (MZ_HELPER_PRIO) __builtin_amdgcn_s_setprio(MZ_HELPER_PRIO); } while (0)
+// ... when their batch asks for it (MZ_DP_HELPERS_FIRST, include/mz_amd.h: the chunk pipelines do; a device-resident pipeline's helpers have a whole DP's time and
+// cost it 1.5-3 % at the raised priority: C2 571 against 579 GCUPS, C4 501 / 517, c4i 399 / 408, same box, alternating)
+#define HELPER_PRIO_OF(b) do { if (MZ_HELPER_PRIO && ((b).dp_hint & MZ_DP_HELPERS_FIRST)) __builtin_amdgcn_s_setprio(MZ_HELPER_PRIO); } while (0)
 
 struct ScoreConst { int S6[36]; int go; int ge; int g1, g2; int tag_ok; int maxS; int row_on; int lag_on; int tstrip_on; };
 __constant__ ScoreConst c_sc;

@@ -72,6 +72,7 @@ int mzi_cpu_budget(void)
  * that was late still finishes its piece, some time: whoever owns what the pieces write waits for the loop to be QUIET
  * (mzi_job_quiet) before that is reused or handed on. */
 static int g_hedge_us = -1;
+static int g_watchers;                                   /* idle threads that look for late pieces (idle_wait) */
 static pjob *g_out;                                      /* hedged loops with pieces running, all handed out (linked by olink) */
 
 static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * t.tv_sec + 1e-3 * t.tv_nsec; }
@@ -89,7 +90,10 @@ static pjob *grab_any(int *lo, int *hi, int *piece)
     if (j->hedge) { j->state[*piece] = 1; j->t_start[*piece] = now_us(); }
     if (j->next >= j->n) {
         g_pool.head = j->link; j->link = NULL;
-        if (j->hedge) { j->olink = g_out; g_out = j; }
+        if (j->hedge) {
+            j->olink = g_out; g_out = j;
+            if (g_watchers < 2) { pthread_cond_signal(&g_pool.work); pthread_cond_signal(&g_pool.work); }     /* (sleepers become the watchers: idle_wait) */
+        }
     }
     return j;
 }
@@ -133,14 +137,19 @@ static void piece_done(pjob *j, int lo, int hi, int piece)
 
 /* nothing to do (pool lock held): sleep until something is posted -- or, while hedged loops have pieces out, for a fraction of the
  * hedging time */
+/* Nothing to take.  While hedged loops are out, TWO of the idle threads look again after half the hedge time (a piece may have
+ * become late meanwhile); the others sleep until there is new work -- with every idle thread polling, 24 threads woke 5 000 times
+ * a second each during a call and a quiet box's calls took 2 % longer than without hedging (C2: 8.41 against 8.26 ms). */
 static void idle_wait(void)
 {
-    if (g_out) {
+    if (g_out && g_watchers < 2) {
         struct timespec t;
         clock_gettime(CLOCK_REALTIME, &t);
         t.tv_nsec += 1000L * (g_hedge_us / 2 > 50 ? g_hedge_us / 2 : 50);
         if (t.tv_nsec >= 1000000000L) { t.tv_nsec -= 1000000000L; t.tv_sec++; }
+        ++g_watchers;
         pthread_cond_timedwait(&g_pool.work, &g_pool.mu, &t);
+        --g_watchers;
     } else pthread_cond_wait(&g_pool.work, &g_pool.mu);
 }
 

@@ -152,6 +152,7 @@ static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n,
         c->q.lds16 = keep16; c->q.lds_bytes = keepb;
     }
     c->b.n = c->b2.n = c->q.n = n;
+    c->b.dp_hint = c->b2.dp_hint = c->lane >= 0 ? MZ_DP_HELPERS_FIRST : 0;      /* (beside other chunks' DPs: include/mz_amd.h) */
 #define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
     SL(hK, int32_t, c->q.K, 4 * (size_t)n); SL(hL, int32_t, c->q.L, 4 * (size_t)n); SL(hMa, int32_t, c->q.Ma, 4 * (size_t)n);
     SL(hNa, int32_t, c->q.Na, 4 * (size_t)n); SL(hRad, int32_t, c->q.rad, 4 * (size_t)n); SL(hV, int32_t, c->q.v, 4 * (size_t)n);
@@ -259,7 +260,7 @@ static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t sd, hipStream_t 
     b->tbw = (uint32_t *)tb->p; b->script = (uint8_t *)script->p; b->out = (uint8_t *)out->p;
     b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap;
     b->walk_hint = mz_walk_choice(n, totals);
-    b->dp_hint = mz_dp_hint(n, totals); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
+    b->dp_hint = mz_dp_hint(n, totals) | (b->dp_hint & MZ_DP_HELPERS_FIRST); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
     if (lanes && !X->lanes_made && mz_dp_kinds(b->dp_hint) > 1 && mzi_flow_lanes(X)) return -1;      /* several kinds of pairs: the DP streams' lanes */
     /* the DP on the slot's DP stream (whatever else it reads is through: the host has seen this plan's totals), the rest behind its event */
     if (wait_prep) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));
