@@ -618,7 +618,7 @@ def main():
     gcups = all_cells * args.steps / elapsed / 1e9
     dp_ms = float(kern_ms[1])
     roof_achieved = total_bytes / (dp_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes over the DP kernel's time
-    modes = np.bincount(res["mode"], minlength=13)
+    modes = np.bincount(res["mode"], minlength=14)
     # the DP kernel that took most of the batch's pairs: the row-parallel one (k_dp_row_big when the batch has blocks of four
     # rows or more), the lagged one, or the wavefront fallbacks
     big = bool((np.maximum(batch["K"], batch["L"]) >= 4).any())
@@ -626,7 +626,7 @@ def main():
     # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat: C5 as one batch)
     row_kernel = "k_dp_row_big" if big else "k_dp_row_lat" if 0 < nrow <= 2048 else "k_dp_row"
     dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
-                          (int(modes[:4].sum()), "k_dp"), (int(modes[4]), "k_dp_tstrip"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
+                          (int(modes[:4].sum()), "k_dp"), (int(modes[4]), "k_dp_tstrip"), (int(modes[13]), "k_dp_duo"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
 
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",

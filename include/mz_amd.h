@@ -89,7 +89,10 @@ enum { MZ_MODE_WF64 = 0, MZ_MODE_STRIP = 1, MZ_MODE_FAST = 2, MZ_MODE_FASTT = 3 
        MZ_MODE_WIDE = 9, MZ_MODE_WIDESTRIP = 10 /* blocks of 128..255 rows: WF64 / STRIP with int16 gap vectors */,
        MZ_MODE_LAG = 11 /* ROW for bands with rows of 65..127 columns: the 64-column periods run a few rows apart (kernels/lag.inc) */,
        MZ_MODE_TROLL = 12 /* FASTT for bands wide AND high: a lane that is still busy when its next row is due starts it late, and every
-                              later row with it (kernels/roll.inc); the strips' traceback layout */ };
+                              later row with it (kernels/roll.inc); the strips' traceback layout */,
+       MZ_MODE_DUO = 13 /* FASTT on a workgroup of TWO waves, 128 rows in flight: bands wide AND high whose anti-diagonals cross at most 128 rows
+                            (RB[r+1] - LB[r+128] <= 126); the rows above across the wave boundaries through LDS, one barrier per step
+                            (kernels/duo.inc); FASTT's traceback layout on 128 lanes */ };
 
 #define MZ_PLAN_FOLD_MAX 4096         /* batches of at most this many pairs: the plan shares a pair's rows out over 16 waves */
 #define MZ_SCAN_AUX_BYTES(n) ((size_t)576 * ((size_t)(n) / 64 + 2) + ((n) <= MZ_PLAN_FOLD_MAX ? (size_t)768 * (size_t)(n) : 0))   /* mz_dev_batch.scanAux */
@@ -126,7 +129,7 @@ typedef struct mz_dev_batch {
     int64_t *offTb, *offScript, *offOut, *offPrep; /* exclusive prefix sums of the above            */
     int64_t *totals;       /* [0..2] totals of tb/script/out, [3] failed pairs, [4] prep total, [5] pairs on the wavefront kernels (lower half) and row-parallel pairs of blocks of four rows or more (upper half), [6], [7] spare,
                               [8] pairs of more than 127 rows (lower half) and pairs on the lagged kernel (upper half), [9] spare, [10] the batch chase's pair counter,
-                              [11] rows (K+L) of all valid pairs in bits 0..43 and the number of MZ_MODE_TSTRIP pairs from bit 44 up, [12] bytes of the packed outputs (host path), [16..20] work counters of k_dp / k_dp_wide / k_dp_lag / k_dp_roll / k_dp_tstrip, [32..95] the pair lists' totals per (kind, size class): 128 ints; MZ_TOTALS entries in all */
+                              [11] rows (K+L) of all valid pairs in bits 0..43 and the number of MZ_MODE_TSTRIP and MZ_MODE_DUO pairs from bit 44 up, [12] bytes of the packed outputs (host path), [16..21] work counters of k_dp / k_dp_wide / k_dp_lag / k_dp_roll / k_dp_tstrip / k_dp_duo, [32..95] the pair lists' totals per (kind, size class): 128 ints; MZ_TOTALS entries in all */
     int32_t *packList;     /* n entries: the pairs of the wavefront kernels, of blocks of 128+ rows, of the lagged kernel and of the row-parallel kernels, one list after the other, each with the pairs of most cells first */
     int64_t *scanAux;      /* scratch of the prefix-sum kernels and the plan: MZ_SCAN_AUX_BYTES(n) bytes (8 sums, then 128 ints of list counts, per 64 pairs; 16 x 12 ints per pair for batches of at most MZ_PLAN_FOLD_MAX pairs) */
     /* workspaces + results (device) */

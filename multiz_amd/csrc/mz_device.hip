@@ -46,7 +46,7 @@
 // row-parallel family (lane = column / transposed: lane = row) and its transposed members
 #define MODE_IS_ROWFAM(m) ((m) >= MZ_MODE_ROW && (m) <= MZ_MODE_COLR)
 #define MODE_IS_COLFAM(m) ((m) == MZ_MODE_COL || (m) == MZ_MODE_COLR)
-#define MODE_IS_TAGGED(m) ((m) == MZ_MODE_FASTT || MODE_IS_ROWFAM(m) || (m) == MZ_MODE_LAG)
+#define MODE_IS_TAGGED(m) ((m) == MZ_MODE_FASTT || MODE_IS_ROWFAM(m) || (m) == MZ_MODE_LAG || (m) == MZ_MODE_DUO)
 
 // Helper kernels (everything but the DP) raise their waves' issue priority: in the chunk pipelines they run beside five DP waves per
 // SIMD that issue VALU four cycles in five, and a helper wave that only gets what those leave takes 10-30x its time alone -- the plan of
@@ -231,6 +231,7 @@ __device__ __forceinline__ int listed_pair(const mz_dev_batch &b, int first, int
 #include "kernels/lag.inc"
 #include "kernels/strip.inc"
 #include "kernels/roll.inc"
+#include "kernels/duo.inc"
 #include "kernels/dispatch.inc"
 #include "kernels/walk.inc"
 #include "kernels/emit.inc"
@@ -262,7 +263,8 @@ extern "C" int mzk_upload_scores(const mz_score_model *m, void *stream)
     { const char *e = getenv("MZ_NO_LAG"); h.lag_on = !(e && e[0] == '1'); }
     // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements); MZ_TROLL=1: the rolling form with late starts
     // (kernels/roll.inc) where its rings hold the band -- off by default: measured no faster than the tagged strips
-    { const char *e = getenv("MZ_NO_TSTRIP"), *r = getenv("MZ_TROLL"); h.tstrip_on = (e && e[0] == '1') ? 0 : (r && r[0] == '1') ? 2 : 1; }       // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements)      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
+    { const char *e = getenv("MZ_NO_TSTRIP"), *r = getenv("MZ_TROLL"); const char *d = getenv("MZ_NO_DUO");      // (bit 0: tagged strips; bit 1: the rolling form; bit 2: the two-wave wavefront, kernels/duo.inc -- MZ_NO_DUO=1: A/B measurements)
+      h.tstrip_on = (e && e[0] == '1') ? 0 : ((r && r[0] == '1') ? 3 : 1) | ((d && d[0] == '1') ? 0 : 4); }       // MZ_NO_TSTRIP=1: wide-and-high bands stay on the exact strips (A/B measurements)      // MZ_NO_LAG=1: bands with wide rows stay on the wavefront kernels (A/B measurements)
     h.tag_ok = (m->g1 > 0 && 2 * m->g1 * 127 <= 32767 && 2 * m->g2 * 127 <= 32767) ? 1 : 0;
     CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_sc), &h, sizeof h, 0, hipMemcpyHostToDevice, (hipStream_t)stream), "upload scores");
     CK(hipStreamSynchronize((hipStream_t)stream), "upload scores sync");
@@ -505,7 +507,7 @@ extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void
     int nk = 0, last = 0;
     for (int i = 0; i < 5; ++i) if (hint & kinds[i]) { ++nk; last = i; }
     if (hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG))
-        CK(hipMemsetAsync(&b->totals[16], 0, 5 * sizeof(int64_t), main_s), "dp counters");
+        CK(hipMemsetAsync(&b->totals[16], 0, 6 * sizeof(int64_t), main_s), "dp counters");
     // The side streams: the caller's own (`lanes`: the chunk pipelines give every chunk stream a set of its own -- one set per
     // device made the few long wavefront pairs of chunk k+1 wait for those of chunk k on the shared stream, a chain of 12 x 0.55 ms
     // that WAS a 20 000-pair call with indel bands), else the device's.  Fewer lanes than kinds: several kinds share a lane, in
@@ -552,6 +554,7 @@ extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void
         else if (kinds[i] == MZ_DP_WIDE) {                // the second list: blocks of 128+ rows, and the rolling form with late starts
             // (three kernels share the list and follow one another on this stream; one without pairs of its own leaves at once -- the
             //  tagged strips first: theirs are the usual ones)
+            hipLaunchKernelGGL(k_dp_duo, dim3(grid_of(count, 1792, (b->dp_grid >> 10) & 1023)), dim3(DUO_T), 0, s, *b, first, count);     // (21 KB of LDS: seven workgroups a CU)
             hipLaunchKernelGGL(k_dp_tstrip, dim3(grid_of(count, 5120, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
             hipLaunchKernelGGL(k_dp_wide, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);
             hipLaunchKernelGGL(k_dp_roll, dim3(grid_of(count, 2048, (b->dp_grid >> 10) & 1023)), dim3(WAVE), 0, s, *b, first, count);

@@ -35,7 +35,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     for fast, row in ((1, 1), (1, 0), (0, 0)):
         mz.lib().mz_enable_fast(fast); mz.lib().mz_enable_row(row)
         db = mz.DevBatch(batch); db.run(); res = db.results(); out = db.out.cpu().numpy()
-        modes += np.bincount(res["mode"], minlength=13)
+        modes += np.bincount(res["mode"], minlength=14)
         for i in range(len(pairs)):
             m_, o0 = int(res["om"][i]), int(res["offOut"][i])
             w = pairs[i][0].shape[1] + pairs[i][1].shape[1]

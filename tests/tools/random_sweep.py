@@ -21,7 +21,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             pairs.append((A, B, LB, RB))
     batch = synth.pack_pairs(pairs)
     db = mz.DevBatch(batch); db.run(); res = db.results(); out = db.out.cpu().numpy()
-    modes += np.bincount(res["mode"], minlength=13)
+    modes += np.bincount(res["mode"], minlength=14)
     om, hs, cells, nbad = mo.yama_batch(batch, variant=1, threads=8)
     for i in range(len(pairs)):
         m_, o0 = int(res["om"][i]), int(res["offOut"][i])

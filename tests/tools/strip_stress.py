@@ -23,7 +23,7 @@ for i in range(n):
     m_, o0 = int(res["om"][i]), int(res["offOut"][i])
     if res["status"][i] != 0 or m_ != om[i] or mo.fnv1a_np(out[o0:o0 + m_ * W], mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8))) != int(hs[i]):
         mism.append((i, int(res["mode"][i]), int(res["status"][i]), pairs[i][0].shape, pairs[i][1].shape))
-print("modes", np.bincount(res["mode"], minlength=13), "oracle-invalid", bad, "mismatches", len(mism), mism[:10])
+print("modes", np.bincount(res["mode"], minlength=14), "oracle-invalid", bad, "mismatches", len(mism), mism[:10])
 if mism and len(sys.argv) > 3:
     sv = {}
     for j, (i, *_ ) in enumerate(mism[:20]):
