@@ -25,7 +25,7 @@ int mzk_emit(const mz_dev_batch *b, void *stream);
 int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
 /* ... with the caller's own side streams for the DP kernels of a batch that has several kinds of pairs (n = 0: all on `stream`;
  * lanes == NULL: the device's own set, one per device) -- hipStream_t / hipEvent_t as void * */
-typedef struct mz_dp_lanes { int n; void *stream[4]; void *fork; void *join[4]; int row_cap; /* > 0: the row-parallel kernels as persistent grids of at most this many blocks */ } mz_dp_lanes;
+typedef struct mz_dp_lanes { int n; void *stream[4]; void *fork; void *join[4]; } mz_dp_lanes;
 int mz_dp_kinds(int dp_hint);          /* DP kernels a batch with this mz_dp_hint() launches */
 int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes);
 int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);

@@ -533,11 +533,7 @@ extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void
         hipStream_t s = main_s;
         if (side) { s = S->s[sides % nlane]; if (sides < nlane) CK(hipStreamWaitEvent(s, S->fork, 0), "dp fork wait"); }
         // (the row kernels: a block per pair of the batch, or -- whole batch, counts known -- per entry of the plan's list)
-        // (persistent: the caller's cap on the blocks -- the chunk pipelines'; an even share of the items per block, so that the last
-        //  round is as full as the first)
-        const int row_items = rows_listed ? b->dp_rows : count;
-        int row_blocks = row_items;
-        if (lanes && lanes->row_cap > 0 && row_items > lanes->row_cap) { const int rounds = (row_items + lanes->row_cap - 1) / lanes->row_cap; row_blocks = (row_items + rounds - 1) / rounds; }
+        const int row_items = rows_listed ? b->dp_rows : count, row_blocks = row_items;
         if (kinds[i] == MZ_DP_ROW) {
             // few pairs -- a wave or two per SIMD, nothing to hide a latency behind: the latency-tolerant build (kernels/row.inc)
             if ((long long)row_blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)

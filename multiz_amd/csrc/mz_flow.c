@@ -53,8 +53,6 @@ int mzi_flow_streams(mz_ctx *X)
         flow_new_stream(X, &X->qt[0]) || flow_new_stream(X, nt > 1 ? &X->qt[1] : &filler)) return -1;
     for (i = 0; i < 2; ++i) {
         X->qlane[i].n = 0;
-        /* the DP of a chunk as a persistent grid (MZ_DP_CAP blocks at most; default 0: a block per pair) */
-        { const char *e = getenv("MZ_DP_CAP"); X->qlane[i].row_cap = e ? atoi(e) : 0; }
         HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
     }
     X->nf = 1; X->nt = nt; X->nq = 2;
