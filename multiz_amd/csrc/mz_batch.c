@@ -146,7 +146,11 @@ static int chunk_parts(int n)
     if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (v) return v;
     parts = (n + 2500) / 5000;
-    return parts < 3 ? 3 : parts > 16 ? 16 : parts;
+    parts = parts < 3 ? 3 : parts > 16 ? 16 : parts;
+    /* few pairs (long ones as likely as not: the chunks are cut by bytes): their DPs are as long as one pair takes however few they hold, and
+     * run two abreast -- an even number of them (1 000 pairs of 100 000 columns, 2 / 3 / 4 chunks: 50.8 / 54.6 / 50.3 ms) */
+    if (n <= 4096 && (parts & 1)) ++parts;
+    return parts;
 }
 
 /* the chunk's streams (mz_ctx.h): front (staging block -> device, expansion, plan), DP, tail (walk, script packing, results -> host) */

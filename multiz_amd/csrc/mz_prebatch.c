@@ -494,7 +494,9 @@ static int pre_parts(int n, int two_stage)
     if (v < 0) { const char *e = getenv("MZ_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (v) return v;
     parts = 2 * two_stage >= n ? (n + 5000) / 10000 : (n + 2500) / 5000;
-    return parts < 3 ? 3 : parts > 16 ? 16 : parts;
+    parts = parts < 3 ? 3 : parts > 16 ? 16 : parts;
+    if (n <= 4096 && (parts & 1)) ++parts;                /* (few merges, long ones as likely as not: an even number of chunks -- mz_batch.c, chunk_parts) */
+    return parts;
 }
 
 #define PRE_MIN_CHUNK 1024
