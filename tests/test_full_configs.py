@@ -98,7 +98,7 @@ def test_c4_one_gpu_share_125000_pairs(mz):
 
 
 def test_c5_full_size_1000_pairs(mz):
-    batch, om = _full_config(mz, "c5", ref_sample=16)
+    batch, om = _full_config(mz, "c5", ref_sample=48)
     assert len(om) == 1000 and batch["M"].min() >= 95000 and batch["M"].max() <= 105000
 
 
