@@ -40,6 +40,11 @@ typedef struct pack_ctx {
     uint8_t *hA, *hB, *hC, *hFmt, *hE;
     int32_t *hLB0, *hRB0;                  /* (NULL: the caller has filled them in) */
     uint32_t *esz;
+    /* Where a pair's band steps go in hC, in memory nobody writes after the chunk is cut (NULL: hoC).  chunk_send() turns hoC[p] -- which
+     * lies in the staging block and goes to the device -- into the pair's offset in the EXCEPTION block for the pairs that have one, and a
+     * piece of the packing that is run a second time (mz_pool.c) may still be at work then: it took that offset for the hC slot, streamed
+     * the pair's steps over somebody else's -- or, the offset being no multiple of 16, faulted (one `bench.py --config c4i` in twenty). */
+    const int64_t *slotC;
 } pack_ctx;
 
 typedef struct chunk {
@@ -86,8 +91,8 @@ static void pack_range(void *ctx, int lo, int hi)
     int p;
     for (p = lo; p < hi; ++p) {
         const mz_job *j = &q->jobs[p];
-        q->esz[p] = 0;
-        q->hFmt[p] = 2;
+        uint32_t esz = 0;                                    /* (written once, at the end: a piece that is run a second time -- mz_pool.c -- while the */
+        uint8_t fmt = 2;                                     /*  chunk is already on its way must not show anybody a value in between) */
         if (p + 1 < hi) {
             /* the next pair's four arrays start on pages of their own, where no hardware stream is running yet: ask for
              * their first lines now (LB and RB of a C2 pair are a 4 KB page each; the demand misses at every array's head
@@ -106,12 +111,13 @@ static void pack_range(void *ctx, int lo, int hi)
             uint32_t steps;
             mz_pack_classes_stream(j->A, (size_t)j->K * j->M, q->hA + q->hoA[p] / 2, cols_padded(j->K, j->M) / 2);
             mz_pack_classes_stream(j->B, (size_t)j->L * j->N, q->hB + q->hoB[p] / 2, cols_padded(j->L, j->N) / 2);
-            steps = mz_pack_band_nib_stream(j->LB, j->RB, j->M, q->hC + q->hoC[p], band_slot(j->M));
+            steps = mz_pack_band_nib_stream(j->LB, j->RB, j->M, q->hC + (q->slotC ? q->slotC[p] : q->hoC[p]), band_slot(j->M));
             if (steps >= 16u) {                              /* two bytes per row, or raw: through the exception block */
-                q->hFmt[p] = steps < 256u ? 1 : 0;
-                q->esz[p] = steps < 256u ? (uint32_t)((8 + 2 * (size_t)j->M + 3) & ~(size_t)3) : (uint32_t)(8 * ((size_t)j->M + 1));
+                fmt = steps < 256u ? 1 : 0;
+                esz = steps < 256u ? (uint32_t)((8 + 2 * (size_t)j->M + 3) & ~(size_t)3) : (uint32_t)(8 * ((size_t)j->M + 1));
             }
         }
+        q->esz[p] = esz; q->hFmt[p] = fmt;
     }
     _mm_sfence();                                            /* the streaming stores are out before the piece is reported done */
 }
@@ -181,9 +187,10 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
     }
     hdr = mzi_al256(4 * (size_t)n) * 7 + mzi_al256(8 * (size_t)n) * 4 + mzi_al256((size_t)n);
     in_bytes = hdr + mzi_al256(bytesC) + mzi_al256(eA / 2) + mzi_al256(eB / 2);
-    free(c->pc.esz);
-    c->pc.esz = (uint32_t *)malloc(((size_t)n + 1) * sizeof *c->pc.esz);
-    if (!c->pc.esz) return mzi_set_err("out of memory");
+    free((void *)c->pc.slotC);                               /* (one block: the slots, then the exception sizes) */
+    c->pc.slotC = (const int64_t *)malloc((size_t)n * sizeof(int64_t) + ((size_t)n + 1) * sizeof *c->pc.esz);
+    if (!c->pc.slotC) { c->pc.esz = NULL; return mzi_set_err("out of memory"); }
+    c->pc.esz = (uint32_t *)(c->pc.slotC + n);
     if (mzi_host_reserve(&X->h_in[set], in_bytes) || mzi_dev_reserve(&X->d_in[set], in_bytes) ||
         mzi_dev_reserve(&X->d_cols[set], 2 * (mzi_al256(eA / 2) + mzi_al256(eB / 2)) + 256) ||
         mzi_dev_reserve(&X->d_band[set], 2 * mzi_al256(4 * nband)) ||
@@ -223,7 +230,7 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
             const int ok = job_ok(j);
             const int nul = !j->A || !j->B || !j->LB || !j->RB;                 /* (reported as MZ_E_SHAPE: the plan sees M = N = 0) */
             hK[p] = j->K; hL[p] = j->L; hM[p] = nul ? 0 : j->M; hN[p] = nul ? 0 : j->N;
-            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc;
+            hoA[p] = (int64_t)oa; hoB[p] = (int64_t)ob; hoBand[p] = (int64_t)oband; hoC[p] = (int64_t)oc; ((int64_t *)c->pc.slotC)[p] = (int64_t)oc;
             hLen[p] = ok ? j->M + 1 : 1;                                        /* (LB[0], RB[0]: pack_range -- the first touch of the pair's arrays is the pool's) */
             if (ok) { oa += cols_padded(j->K, j->M); ob += cols_padded(j->L, j->N); oband += (size_t)j->M + 1; oc += band_slot(j->M); }
             else { oband += 1; }
@@ -359,10 +366,15 @@ static void assemble_range(void *ctx, int lo, int hi)
         mz_out *o = &q->outs[p];
         const mz_res_rec *r = &q->rec[p];
         const mz_job *j = &q->jobs[p];
-        o->status = r->status; o->badrow = r->badrow; o->OM = 0; o->cols = NULL; o->block = NULL;
-        o->score[0] = o->score[1] = o->score[2] = 0;
-        if (r->status == MZ_E_EMIT) { o->OM = r->om; o->score[0] = r->f[0]; o->score[1] = r->f[1]; }   /* i, j of the reference's message */
-        if (r->status != MZ_OK) continue;
+        /* (every field gets its final value in ONE store, and o->block is not this loop's: chunk_finish() hangs the chunk's block on its
+         *  first pair when the loop is complete, and a piece that is run a second time may still be at work then -- mz_pool.c) */
+        o->status = r->status; o->badrow = r->badrow;
+        if (r->status != MZ_OK) {
+            const int emit = r->status == MZ_E_EMIT;        /* i, j of the reference's message */
+            o->OM = emit ? r->om : 0; o->cols = NULL;
+            o->score[0] = emit ? r->f[0] : 0; o->score[1] = emit ? r->f[1] : 0; o->score[2] = 0;
+            continue;
+        }
         o->OM = r->om;
         o->score[0] = r->f[0]; o->score[1] = r->f[1]; o->score[2] = r->f[2];
         o->cols = q->block + q->where[p];
@@ -632,7 +644,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     rc = mzi_flow_run(F);
     if (rc < 0) mzi_flow_sync(X);
     g_last_hedged = F->hedged;
-    for (s = 0; s < MZ_SETS; ++s) { free(P->ck[s].pc.esz); free(P->ck[s].ac); free(P->ck[s].where); }
+    for (s = 0; s < MZ_SETS; ++s) { free((void *)P->ck[s].pc.slotC); free(P->ck[s].ac); free(P->ck[s].where); }
     if (g_timing >= 2 && X->btime_ready) hipEventDestroy(P->ev0);
     if (stats) *stats = P->st;
     pthread_mutex_destroy(&P->mu);
@@ -869,7 +881,7 @@ int mz_link_pack(int n, const mz_job *jobs, mz_link_desc *d, void **image, void 
         else oband += 1;
     }
     pc.jobs = jobs; pc.hoA = hoA; pc.hoB = hoB; pc.hoC = hoC; pc.hA = (uint8_t *)h + y.nibA; pc.hB = (uint8_t *)h + y.nibB;
-    pc.hC = (uint8_t *)h + y.steps; pc.hFmt = (uint8_t *)h + y.fmt; pc.esz = esz; pc.hE = NULL; pc.hLB0 = pc.hRB0 = NULL;
+    pc.hC = (uint8_t *)h + y.steps; pc.hFmt = (uint8_t *)h + y.fmt; pc.esz = esz; pc.hE = NULL; pc.hLB0 = pc.hRB0 = NULL; pc.slotC = NULL;
     mzi_parallel_for(n, pack_grain(n), pack_range, &pc);
     for (p = 0; p < n; ++p) if (esz[p]) { hoC[p] = (int64_t)bytesE; bytesE += esz[p]; }
     if (bytesE) {
@@ -1071,7 +1083,7 @@ double mz_host_pack_probe(int n, const mz_job *jobs, int what, int reps)
         if (job_ok(&jobs[p])) { oa += cols_padded(jobs[p].K, jobs[p].M); ob += cols_padded(jobs[p].L, jobs[p].N); oc += band_slot(jobs[p].M); }
     }
     P.what = what;
-    P.pc.jobs = jobs; P.pc.hoA = hoA; P.pc.hoB = hoB; P.pc.hoC = hoC; P.pc.hFmt = fmt; P.pc.esz = esz; P.pc.hE = NULL; P.pc.hLB0 = P.pc.hRB0 = NULL;
+    P.pc.jobs = jobs; P.pc.hoA = hoA; P.pc.hoB = hoB; P.pc.hoC = hoC; P.pc.hFmt = fmt; P.pc.esz = esz; P.pc.hE = NULL; P.pc.hLB0 = P.pc.hRB0 = NULL; P.pc.slotC = NULL;
     P.pc.hC = buf; P.pc.hA = buf + mzi_al256(bytesC); P.pc.hB = P.pc.hA + mzi_al256(eA / 2);
     mzi_parallel_for(n, pack_grain(n), probe_range, &P);             /* warm: pages, pool */
     t0 = mzi_now_s();

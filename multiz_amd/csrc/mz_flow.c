@@ -60,8 +60,11 @@ int mzi_flow_streams(mz_ctx *X)
     return 0;
 }
 
-/* the DP streams' lanes, when the first chunk with several kinds of pairs needs them (from the launcher's thread; ~5 ms a stream) */
-int mzi_flow_lanes(mz_ctx *X)
+/* the DP streams' lanes, when the first chunk with several kinds of pairs needs them (from a launcher's thread; ~5 ms a stream).  The text
+ * path has TWO launch stages, each on a thread of its own: one at a time in here (an intermittent segmentation fault of
+ * `bench.py --config c4i` -- mixed kinds, two-stage merges -- was two threads creating the lanes at once). */
+static pthread_mutex_t g_lanes_mu = PTHREAD_MUTEX_INITIALIZER;
+static int flow_lanes_locked(mz_ctx *X)
 {
     static int want = -1;
     hipStream_t filler;
@@ -78,8 +81,16 @@ int mzi_flow_lanes(mz_ctx *X)
         }
     }
     for (i = 0; i < 2; ++i) X->qlane[i].n = want;
-    X->lanes_made = 1;
+    __atomic_store_n(&X->lanes_made, 1, __ATOMIC_RELEASE);
     return 0;
+}
+int mzi_flow_lanes(mz_ctx *X)
+{
+    int rc;
+    pthread_mutex_lock(&g_lanes_mu);
+    rc = flow_lanes_locked(X);
+    pthread_mutex_unlock(&g_lanes_mu);
+    return rc;
 }
 
 /* everything a context's chunk pipelines may have in flight (after an error) */
@@ -227,6 +238,11 @@ int mzi_flow_run(mz_flow *F)
     pthread_cond_broadcast(&F->cv);
     pthread_mutex_unlock(&F->mu);
     mzi_help_until(flow_drained, F);
+    /* flow_drained() reads its counters without the flow's lock; the stage thread or pool thread that made it true did so UNDER the lock and
+     * still has to broadcast and unlock -- and the flow goes away when this function returns (its memory back to the system, if malloc() had
+     * mapped it: a segmentation fault in that thread, one `bench.py --config c4i` in twenty).  Through the lock once: they are out. */
+    pthread_mutex_lock(&F->mu);
+    pthread_mutex_unlock(&F->mu);
     for (s = 0; s < MZ_SETS && s < k; ++s) F->hedged += mzi_job_quiet(&F->pack[s]) + mzi_job_quiet(&F->post[s]);     /* nobody is writing to the results any more */
     rc = F->rc < 0 ? -1 : F->failed;
     if (rc < 0) mzi_set_err("%s", F->err);

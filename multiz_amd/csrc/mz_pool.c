@@ -153,6 +153,15 @@ static void idle_wait(void)
     } else pthread_cond_wait(&g_pool.work, &g_pool.mu);
 }
 
+/* MZ_HEDGE_DELAY_US (tests): a piece's SECOND run starts that much later -- long after the first one is through and the chunk's next stages
+ * are at work on what the piece wrote and read: what a second run must not disturb (tests/test_gpu_parity.py) */
+static void late_run_delay(void)
+{
+    static int us = -1;
+    if (us < 0) { const char *e = getenv("MZ_HEDGE_DELAY_US"); us = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (us) { struct timespec t = { us / 1000000, 1000L * (us % 1000000) }; nanosleep(&t, NULL); }
+}
+
 static void *pool_worker(void *arg)
 {
     (void)arg;
@@ -160,8 +169,10 @@ static void *pool_worker(void *arg)
     while (!g_pool.quit) {
         pjob *j;
         int lo, hi, piece;
-        if (!(j = grab_any(&lo, &hi, &piece)) && !(j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
+        int late = 0;
+        if (!(j = grab_any(&lo, &hi, &piece)) && !(late = 1, j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
+        if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
         piece_done(j, lo, hi, piece);
@@ -260,8 +271,10 @@ void mzi_help_until(int (*ready)(void *), void *arg)
     while (!ready(arg)) {
         pjob *j;
         int lo, hi, piece;
-        if (!(j = grab_any(&lo, &hi, &piece)) && !(j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
+        int late = 0;
+        if (!(j = grab_any(&lo, &hi, &piece)) && !(late = 1, j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
+        if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
         piece_done(j, lo, hi, piece);

@@ -264,7 +264,16 @@ static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t sd, hipStream_t 
     if (lanes && !X->lanes_made && mz_dp_kinds(b->dp_hint) > 1 && mzi_flow_lanes(X)) return -1;      /* several kinds of pairs: the DP streams' lanes */
     /* the DP on the slot's DP stream (whatever else it reads is through: the host has seen this plan's totals), the rest behind its event */
     if (wait_prep) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));
-    if (mzk_dp_range_on(b, 0, n, sd, lanes)) return mzi_set_err("%s", mzk_last_error());
+    {
+        /* (the two launch stages run on threads of their own and chunks k and k + 2 share a DP stream's lanes: the fork / launch / join
+         *  sequence of one at a time -- what a wait refers to is fixed when it is enqueued) */
+        static pthread_mutex_t launch_mu = PTHREAD_MUTEX_INITIALIZER;
+        int rc;
+        pthread_mutex_lock(&launch_mu);
+        rc = mzk_dp_range_on(b, 0, n, sd, lanes);
+        pthread_mutex_unlock(&launch_mu);
+        if (rc) return mzi_set_err("%s", mzk_last_error());
+    }
     if (stamp >= 0) PSTAMP(X, set, stamp, sd);
     if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
     if (mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
@@ -353,9 +362,10 @@ static void assemble_merges(void *ctx, int lo, int hi)
         const mz_pre_rec *r = &q->rec[p];
         mz_preout *o = &q->outs[p];
         const int W = j->K + j->L1 - 1, two = j->v == 0;
-        memset(o, 0, sizeof *o);
+        /* (every field gets its final value in one store, and o->block is not this loop's: pchunk_done() hangs the chunk's block on its
+         *  first merge when the loop is complete, and a piece that is run a second time may still be at work then -- mz_pool.c) */
         o->null_result = r->nullres; o->status = r->status; o->badrow = r->badrow; o->stage = r->stage; o->M = r->M; o->N = r->N;
-        if (r->nullres || r->status != MZ_OK) continue;
+        if (r->nullres || r->status != MZ_OK) { o->OM = 0; o->score = 0; o->size = NULL; o->rows = NULL; continue; }
         o->OM = r->om;
         o->score = (double)r->score;
         {

@@ -670,6 +670,23 @@ def test_tagged_strips_random_wide_bands(mz):
     _kernels(mz, 2)
 
 
+def test_host_paths_with_every_late_piece_run_twice():
+    # MZ_HEDGE_US=1: every piece of the host paths' packing and assembling loops that is not back within a microsecond is handed out a
+    # second time (mz_pool.c) -- pieces must give the same result whoever else is at work on their chunk by then.  Round 5 shipped two
+    # that did not for a day: a second run of a packing piece read the slot of a pair's band steps from an array the send stage had
+    # meanwhile turned into exception-block offsets (a fault, or another pair's steps overwritten), and reset a pair's format byte
+    # before setting it again.  The differential sweeps of both paths (bands with nibble, byte and raw steps; chunks of 37 pairs).
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MZ_HEDGE_US="1", MZ_HEDGE_DELAY_US="300", MZ_CHUNK_PAIRS="37")
+    for tool, args, what in (("host_sweep.py", ["700", "702"], "pairs"), ("preyama_sweep.py", ["700", "701"], "merges")):
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", tool)] + args, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        last = p.stdout.strip().splitlines()[-1]
+        assert last.startswith(what) and last.endswith("bad 0"), last
+
+
 def test_rolling_form_with_late_starts_opt_in():
     # MZ_TROLL=1 (read when the score model is uploaded, hence the child): well-formed wide-and-high bands whose rows never wait more
     # than the rings hold run on the tagged wavefront with late starts (MZ_MODE_TROLL = 12, kernels/roll.inc) instead of the strips;
