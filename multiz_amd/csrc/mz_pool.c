@@ -105,8 +105,11 @@ static pjob *grab_late(int *lo, int *hi, int *piece)
     const double t = now_us();
     for (j = g_out; j; j = j->olink) {
         int i;
+        /* late: out for longer than MZ_HEDGE_US AND than three times what this loop's pieces have taken so far (a loop of heavy pieces --
+         * ten-row blocks: 0.4 ms a piece -- is not late at 0.4 ms) */
+        const double avg3 = j->n_done ? 3.0 * j->t_sum / j->n_done : 4.0 * g_hedge_us, late = avg3 > g_hedge_us ? avg3 : g_hedge_us;
         for (i = 0; i < j->npiece; ++i)
-            if (j->state[i] == 1 && t - j->t_start[i] > g_hedge_us) {
+            if (j->state[i] == 1 && t - j->t_start[i] > late) {
                 j->state[i] = 3;                         /* (twice is enough) */
                 j->active++;
                 j->hedged++;
@@ -123,7 +126,7 @@ static void piece_done(pjob *j, int lo, int hi, int piece)
     int complete = 0;
     j->active--;
     if (!j->hedge) { j->pending -= hi - lo; complete = j->pending == 0; }
-    else if (j->state[piece] != 2) { j->state[piece] = 2; j->pending -= hi - lo; complete = j->pending == 0; }
+    else if (j->state[piece] != 2) { j->state[piece] = 2; j->pending -= hi - lo; complete = j->pending == 0; j->t_sum += now_us() - j->t_start[piece]; j->n_done++; }
     if (complete && j->hedge) { pjob **pp; for (pp = &g_out; *pp && *pp != j; pp = &(*pp)->olink) ; if (*pp) *pp = j->olink; j->olink = NULL; }
     if (j->active == 0 || (complete && !j->done)) pthread_cond_broadcast(&g_pool.done);      /* (somebody may wait for the loop to be quiet) */
     if (complete && j->done) {
@@ -170,7 +173,10 @@ static void *pool_worker(void *arg)
         pjob *j;
         int lo, hi, piece;
         int late = 0;
-        if (!(j = grab_any(&lo, &hi, &piece)) && !(late = 1, j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
+        /* a late piece first: it belongs to an older loop than any piece not yet handed out, and that loop's chunk is what the GPU waits for
+         * (late pieces used to be looked for only by threads with nothing else to take: with three chunks' loops queued a stalled piece of
+         * the first waited 3 ms for its second run) */
+        if (!(g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
@@ -213,7 +219,7 @@ int mzi_pool_threads(void)
 static void enqueue(pjob *job)                            /* (pool lock held) jobs in arrival order: the older chunk first */
 {
     pjob **pp;
-    job->next = 0; job->pending = job->n; job->link = NULL; job->olink = NULL; job->active = 0; job->hedged = 0;
+    job->next = 0; job->pending = job->n; job->link = NULL; job->olink = NULL; job->active = 0; job->hedged = 0; job->t_sum = 0; job->n_done = 0;
     if (!g_pool.started) pool_start_locked();
     job->npiece = (job->n + job->grain - 1) / job->grain;
     if (job->hedge && (!job->done || g_hedge_us <= 0 || job->npiece > MZ_HEDGE_PIECES)) job->hedge = 0;
@@ -272,7 +278,10 @@ void mzi_help_until(int (*ready)(void *), void *arg)
         pjob *j;
         int lo, hi, piece;
         int late = 0;
-        if (!(j = grab_any(&lo, &hi, &piece)) && !(late = 1, j = grab_late(&lo, &hi, &piece))) { idle_wait(); continue; }
+        /* a late piece first: it belongs to an older loop than any piece not yet handed out, and that loop's chunk is what the GPU waits for
+         * (late pieces used to be looked for only by threads with nothing else to take: with three chunks' loops queued a stalled piece of
+         * the first waited 3 ms for its second run) */
+        if (!(g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
