@@ -326,15 +326,8 @@ static int chunk_launch(chunk *c)
     if (mzk_dp_range_on(&b, 0, n, sd, c->lane < 0 ? NULL : &X->qlane[c->lane])) return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 3, sd);
     if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
-    {
-        /* MZ_TAIL_FIRST=0: the walk and the script packing at the DP waves' own priority (the results are needed a chunk later) */
-        static int tail_first = -1;
-        mz_dev_batch bt = b;
-        if (tail_first < 0) { const char *e = getenv("MZ_TAIL_FIRST"); tail_first = e ? atoi(e) : 1; }
-        if (!tail_first) bt.dp_hint &= ~MZ_DP_HELPERS_FIRST;
-        if (mzk_walk(&bt, st, 1) || mzk_script_pack(&bt, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
-            return mzi_set_err("%s", mzk_last_error());
-    }
+    if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
+        return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 4, st);
     /* the results go home as the chunk's last kernel: no copy engine, nothing that could wait for anything but this chunk's
      * own kernels */
