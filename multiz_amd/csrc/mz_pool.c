@@ -73,6 +73,7 @@ int mzi_cpu_budget(void)
  * (mzi_job_quiet) before that is reused or handed on. */
 static int g_hedge_us = -1;
 static int g_watchers;                                   /* idle threads that look for late pieces (idle_wait) */
+static int g_dups, g_dups_max = -1, g_late_first = -1;   /* second runs in progress; at most so many at a time (MZ_HEDGE_DUPS, default 2); MZ_HEDGE_FIRST=0: only idle threads take them */
 static pjob *g_out;                                      /* hedged loops with pieces running, all handed out (linked by olink) */
 
 static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * t.tv_sec + 1e-3 * t.tv_nsec; }
@@ -103,6 +104,9 @@ static pjob *grab_late(int *lo, int *hi, int *piece)
 {
     pjob *j;
     const double t = now_us();
+    /* a box under load makes MANY pieces late at once, and every thread running somebody's piece again instead of a new one makes all of
+     * them later still: a few second runs at a time */
+    if (g_dups >= g_dups_max) return NULL;
     for (j = g_out; j; j = j->olink) {
         int i;
         /* late: out for longer than MZ_HEDGE_US AND than three times what this loop's pieces have taken so far (a loop of heavy pieces --
@@ -113,6 +117,7 @@ static pjob *grab_late(int *lo, int *hi, int *piece)
                 j->state[i] = 3;                         /* (twice is enough) */
                 j->active++;
                 j->hedged++;
+                g_dups++;
                 *piece = i; *lo = i * j->grain; *hi = *lo + j->grain < j->n ? *lo + j->grain : j->n;
                 return j;
             }
@@ -176,11 +181,13 @@ static void *pool_worker(void *arg)
         /* a late piece first: it belongs to an older loop than any piece not yet handed out, and that loop's chunk is what the GPU waits for
          * (late pieces used to be looked for only by threads with nothing else to take: with three chunks' loops queued a stalled piece of
          * the first waited 3 ms for its second run) */
-        if (!(g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece))) { idle_wait(); continue; }
+        if (!(g_late_first && g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece)) &&
+            !((j = grab_late(&lo, &hi, &piece)) && (late = 1))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
+        if (late) g_dups--;
         piece_done(j, lo, hi, piece);
     }
     pthread_mutex_unlock(&g_pool.mu);
@@ -198,6 +205,8 @@ static void pool_start_locked(void)
     if (want < 1) want = 1;
     if (want > POOL_MAX) want = POOL_MAX;
     if (g_hedge_us < 0) { const char *h = getenv("MZ_HEDGE_US"); g_hedge_us = h ? atoi(h) : 400; }     /* (0: pieces are never run twice) */
+    if (g_dups_max < 0) { const char *h = getenv("MZ_HEDGE_DUPS"); g_dups_max = h && atoi(h) > 0 ? atoi(h) : 2; }
+    if (g_late_first < 0) { const char *h = getenv("MZ_HEDGE_FIRST"); g_late_first = !(h && h[0] == '0'); }
     g_pool.started = 1;
     g_pool.nthreads = 0;
     for (i = 0; i < want - 1; ++i) {
@@ -281,11 +290,13 @@ void mzi_help_until(int (*ready)(void *), void *arg)
         /* a late piece first: it belongs to an older loop than any piece not yet handed out, and that loop's chunk is what the GPU waits for
          * (late pieces used to be looked for only by threads with nothing else to take: with three chunks' loops queued a stalled piece of
          * the first waited 3 ms for its second run) */
-        if (!(g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece))) { idle_wait(); continue; }
+        if (!(g_late_first && g_out && (j = grab_late(&lo, &hi, &piece)) && (late = 1)) && !(j = grab_any(&lo, &hi, &piece)) &&
+            !((j = grab_late(&lo, &hi, &piece)) && (late = 1))) { idle_wait(); continue; }
         pthread_mutex_unlock(&g_pool.mu);
         if (late) late_run_delay();
         j->fn(j->ctx, lo, hi);
         pthread_mutex_lock(&g_pool.mu);
+        if (late) g_dups--;
         piece_done(j, lo, hi, piece);
     }
     pthread_mutex_unlock(&g_pool.mu);
