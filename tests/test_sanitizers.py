@@ -84,7 +84,9 @@ def test_host_thread_pool_under_tsan_and_asan(tmp_path):
     for flags, name in ((["-fsanitize=thread"], "tsan"), (["-fsanitize=address,undefined"], "asan")):
         exe = str(tmp_path / ("pool_" + name))
         subprocess.check_call(["gcc", "-O1", "-g", "-I/opt/rocm/include"] + flags + src + ["-o", exe, "-lpthread"])
-        p = subprocess.run([exe], capture_output=True, timeout=600, env=dict(ENV, MZ_HOST_THREADS="8"))
-        assert p.returncode == 0 and b"pool ok" in p.stdout, (p.stdout + p.stderr).decode()[-3000:]
-        assert b"ThreadSanitizer" not in p.stderr
-        _clean(p)
+        # as shipped; then with every piece late at once, its second run starting late, and more second runs at a time than the default
+        for extra in ({}, {"MZ_HEDGE_US": "1", "MZ_HEDGE_DELAY_US": "100", "MZ_HEDGE_DUPS": "6"}, {"MZ_HEDGE_FIRST": "0"}):
+            p = subprocess.run([exe], capture_output=True, timeout=600, env=dict(ENV, MZ_HOST_THREADS="8", **extra))
+            assert p.returncode == 0 and b"pool ok" in p.stdout, (p.stdout + p.stderr).decode()[-3000:]
+            assert b"ThreadSanitizer" not in p.stderr
+            _clean(p)
