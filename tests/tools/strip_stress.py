@@ -1,6 +1,6 @@
 """Randomised parity run for the strip kernels (MZ_MODE_TSTRIP / MZ_MODE_STRIP): bands wide AND high -- large radii, long
 indels, drifting wide bands, full matrices --, blocks of 1-6 rows, strip boundaries at 63 / 64 / 65 / 127 / 128 / 129 rows; every
-pair against the oracle by hash.   python tests/tools/strip_stress.py <pairs> <seed> [bad.npz]"""
+pair against the oracle by hash.   python tests/tools/strip_stress.py <pairs> <seed> [bad.npz]     (STRIP_STRESS_ROWS=<n>: up to n rows a block)"""
 import os, sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import inputs
@@ -11,7 +11,7 @@ mz.api.init(0)
 n = int(sys.argv[1]); rng = np.random.default_rng(int(sys.argv[2]))
 pairs = []
 while len(pairs) < n:
-    A, B, LB, RB = inputs.random_wide_pair(rng)
+    A, B, LB, RB = inputs.random_wide_pair(rng, max_rows=int(os.environ.get("STRIP_STRESS_ROWS", "6")))
     if mo.check(A.shape[0], B.shape[0], LB, RB)[0] == 0:
         pairs.append((A, B, LB, RB))
 batch = synth.pack_pairs(pairs)
