@@ -11,7 +11,7 @@ from multiz_amd import synth
 from oracle import mzoracle as mo
 mz.api.init(0)
 tot = bad = 0
-modes = np.zeros(13, dtype=np.int64)
+modes = np.zeros(14, dtype=np.int64)
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng = np.random.default_rng(70_000 + seed)
     pairs = []
