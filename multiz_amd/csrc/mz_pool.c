@@ -163,10 +163,10 @@ static void idle_wait(void)
 
 /* MZ_HEDGE_DELAY_US (tests): a piece's SECOND run starts that much later -- long after the first one is through and the chunk's next stages
  * are at work on what the piece wrote and read: what a second run must not disturb (tests/test_gpu_parity.py) */
+static int g_hedge_delay_us;                              /* (read when the pool starts, under its lock) */
 static void late_run_delay(void)
 {
-    static int us = -1;
-    if (us < 0) { const char *e = getenv("MZ_HEDGE_DELAY_US"); us = e && atoi(e) > 0 ? atoi(e) : 0; }
+    const int us = g_hedge_delay_us;
     if (us) { struct timespec t = { us / 1000000, 1000L * (us % 1000000) }; nanosleep(&t, NULL); }
 }
 
@@ -205,6 +205,7 @@ static void pool_start_locked(void)
     if (want < 1) want = 1;
     if (want > POOL_MAX) want = POOL_MAX;
     if (g_hedge_us < 0) { const char *h = getenv("MZ_HEDGE_US"); g_hedge_us = h ? atoi(h) : 400; }     /* (0: pieces are never run twice) */
+    { const char *h = getenv("MZ_HEDGE_DELAY_US"); g_hedge_delay_us = h && atoi(h) > 0 ? atoi(h) : 0; }
     if (g_dups_max < 0) { const char *h = getenv("MZ_HEDGE_DUPS"); g_dups_max = h && atoi(h) > 0 ? atoi(h) : 2; }
     if (g_late_first < 0) { const char *h = getenv("MZ_HEDGE_FIRST"); g_late_first = !(h && h[0] == '0'); }
     g_pool.started = 1;
