@@ -64,7 +64,8 @@ int mz_shard_scatter(mz_comm *comm, int root, int n, const mz_job *jobs, mz_shar
 /* this rank's share aligned where it lies (mz_link_plan + mz_link_finish: needs the GPU and device buffers); waits for the result */
 int mz_shard_align(mz_shard *shard);
 /* every rank's result image to the root, which assembles outs[0 .. n) of the scattered list, in the jobs' own order, from its own A
- * and B (release with mz_free_outs()).  Root: the jobs it scattered, outs; the others: NULL, NULL.  Returns the pairs without a result. */
+ * and B (release with mz_free_outs() -- also after -1: the shares assembled before the one that failed own their blocks, every other pair
+ * is left MZ_E_DEVICE with cols == NULL).  Root: the jobs it scattered, outs; the others: NULL, NULL.  Returns the pairs without a result. */
 int mz_shard_gather(mz_comm *comm, int root, mz_shard *shard, const mz_job *jobs, mz_out *outs);
 void mz_shard_free(mz_comm *comm, mz_shard *shard);
 /* what a share holds (for callers that align it themselves -- the CPU tests put the oracle there): its descriptor, pairs, the global

@@ -420,7 +420,12 @@ class Shard:
         outs = np.zeros(len(self.jobs), dtype=OUT_DT) if is_root else None
         rc = f(self.comm.ptr, self.root, self.ptr, self.jobs.ctypes.data if is_root and len(self.jobs) else None,
                outs.ctypes.data if is_root and len(outs) else None)
-        _check(rc, "mz_shard_gather")
+        try:
+            _check(rc, "mz_shard_gather")
+        except RuntimeError:
+            if is_root and len(outs):                      # (shares assembled before the one that failed own their blocks: include/mz_shard.h)
+                free_outs(outs)
+            raise
         return (outs, rc) if is_root else (None, 0)
 
     def free(self):

@@ -403,10 +403,11 @@ static int script_fits(const uint8_t *s, int om, int M, int N)
 
 /* outs[] of n jobs from their result image in host memory (64-byte header, a record per pair, the packed scripts): ONE block for the
  * merged columns, assembled on the pool threads from the caller's own A and B.  `limit`: bytes of the image when it came from
- * somewhere else (a link image: every record AND every script is checked against the jobs), 0 for the pipeline's own.
+ * somewhere else (`foreign`: a link image -- every record AND every script is checked against the jobs; an image of no bytes at all
+ * is too short, not "trusted"); the pipeline's own images are not `foreign` and `limit` is not looked at.
  * results_prepare(): the block and where every pair's columns go (*ac for assemble_range over [0, n)); results_close(): what hangs
  * on outs[0] afterwards; returns the failed pairs. */
-static int results_prepare(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, asm_ctx *ac, size_t **where_out)
+static int results_prepare(int n, const mz_job *jobs, mz_out *outs, const char *r, int foreign, size_t limit, asm_ctx *ac, size_t **where_out)
 {
     const mz_res_rec *rec = (const mz_res_rec *)(r + 64);
     const size_t scripts_at = 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n);
@@ -416,7 +417,7 @@ static int results_prepare(int n, const mz_job *jobs, mz_out *outs, const char *
     int p;
 
     *where_out = NULL;
-    if (limit) {
+    if (foreign) {
         if (limit < scripts_at) return mzi_set_err("result image of %zu bytes is too short for %d pairs", limit, n);
         for (p = 0; p < n; ++p) {
             const mz_res_rec *q = &rec[p];
@@ -452,11 +453,11 @@ static int results_prepare(int n, const mz_job *jobs, mz_out *outs, const char *
     return 0;
 }
 
-static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char *r, size_t limit, int64_t *cells)
+static int results_assemble(int n, const mz_job *jobs, mz_out *outs, const char *r, int foreign, size_t limit, int64_t *cells)
 {
     asm_ctx ac;
     size_t *where;
-    if (results_prepare(n, jobs, outs, r, limit, &ac, &where) < 0) return -1;
+    if (results_prepare(n, jobs, outs, r, foreign, limit, &ac, &where) < 0) return -1;
     mzi_parallel_for(n, pack_grain(n), assemble_range, &ac);
     results_count(n, &ac);
     outs[0].block = ac.block;
@@ -477,7 +478,7 @@ static int chunk_collect(chunk *c, mz_ajob *post)
     c->t_col1 = mzi_now_s();
     if (!c->ac && !(c->ac = (asm_ctx *)malloc(sizeof *c->ac))) return mzi_set_err("out of memory");
     free(c->where); c->where = NULL;                     /* (of the chunk that had this set before: nobody reads it any more, mz_flow.c) */
-    if (results_prepare(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, c->ac, &c->where) < 0) return -1;
+    if (results_prepare(c->n, c->jobs, c->outs, (const char *)X->h_res[set].p, 0, 0, c->ac, &c->where) < 0) return -1;
     post->fn = assemble_range; post->ctx = c->ac; post->n = c->n; post->grain = pack_grain(c->n); post->hedge = 1;
     return 0;
 }
@@ -675,8 +676,9 @@ static int64_t g_last_up, g_last_down;
 int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where, int *cnt, int *start)
 {
     unsigned char *cls = (unsigned char *)malloc((size_t)(n ? n : 1));
-    int ccount[64], cstart[64], fill[MZ_MAX_DEV], pos, c, d, p;
+    int ccount[64], cstart[64], pos, c, d, p;
     if (!cls) return mzi_set_err("out of memory");
+    if (use < 1) { free(cls); return mzi_set_err("mzi_deal_snake: nobody to deal to"); }
     memset(ccount, 0, sizeof ccount);
     for (p = 0; p < n; ++p) {                                /* half-octave class of the weight: 2 * log2 */
         int e = 0;
@@ -692,8 +694,11 @@ int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where,
         owner[p] = (rnd & 1) ? use - 1 - k : k;
         cnt[owner[p]]++;
     }
-    for (d = 0, pos = 0; d < use; ++d) { start[d] = fill[d] = pos; pos += cnt[d]; }
-    for (p = 0; p < n; ++p) where[p] = fill[owner[p]]++;
+    /* (`use` is a rank count when mz_shard_scatter() deals -- any number, not at most MZ_MAX_DEV GPUs of one process: start[] itself is
+     *  the running fill pointer and is put back afterwards; a fixed array of MZ_MAX_DEV on the stack was overrun by a world of 17) */
+    for (d = 0, pos = 0; d < use; ++d) { start[d] = pos; pos += cnt[d]; }
+    for (p = 0; p < n; ++p) where[p] = start[owner[p]]++;
+    for (d = 0; d < use; ++d) start[d] -= cnt[d];
     free(cls);
     return 0;
 }
@@ -1011,6 +1016,9 @@ int mz_link_finish(const mz_link_desc *d, void *dev_result, void *stream)
     return 0;
 }
 
+/* the least a result image of n pairs can be: its 64-byte header and the records (the scripts follow) */
+int64_t mzi_result_image_min(int n) { return n > 0 ? 64 + (int64_t)mzi_al256(sizeof(mz_res_rec) * (size_t)n) : 0; }
+
 int mz_link_assemble(int n, const mz_job *jobs, const void *result, int64_t res_bytes, mz_out *outs)
 {
     int64_t cells = 0;
@@ -1021,7 +1029,8 @@ int mz_link_assemble(int n, const mz_job *jobs, const void *result, int64_t res_
         outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL;
         outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0;
     }
-    return results_assemble(n, jobs, outs, (const char *)result, (size_t)res_bytes, &cells);
+    if ((uint64_t)res_bytes < (uint64_t)mzi_result_image_min(n)) return mzi_set_err("mz_link_assemble: a result image of %lld bytes is too short for the records of %d pairs (%lld bytes at least)", (long long)res_bytes, n, (long long)mzi_result_image_min(n));
+    return results_assemble(n, jobs, outs, (const char *)result, 1, (size_t)res_bytes, &cells);
 }
 
 void mz_link_bytes(int64_t *up, int64_t *down) { if (up) *up = g_last_up; if (down) *down = g_last_down; }

@@ -126,6 +126,7 @@ MZ_INTERNAL int mzi_sync_scores(void);
 MZ_INTERNAL int mzi_timing(void);                       /* MZ_TIMING, parsed once: 0 quiet, 1 per call, 2 per chunk */
 MZ_INTERNAL void mzi_workers_stop(mz_ctx *X);           /* mz_batch.c: ctx_close() ends the context's helper threads */
 MZ_INTERNAL int mzi_deal_snake(int n, const double *weight, int use, int *owner, int *where, int *cnt, int *start);    /* mz_batch.c */
+MZ_INTERNAL int64_t mzi_result_image_min(int n);         /* mz_batch.c: bytes of the header and the records of a result image of n pairs */
 MZ_INTERNAL void mzi_link_forget(void);                 /* mz_batch.c: a planned link image (set 0 of the primary context) is gone */
 MZ_INTERNAL int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int64_t stats[3]);   /* mz_prebatch.c */
 

@@ -30,9 +30,22 @@ static struct {
     pthread_mutex_t mu;
     pthread_cond_t work, done;
     pjob *head;
-    int nthreads, started, quit;
+    int nthreads, started, quit, cv_ready;
     pthread_t th[POOL_MAX];
-} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, { 0 } };
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, 0, 0, 0, { 0 } };
+
+/* `work` is also waited on with a deadline (idle_wait): on the MONOTONIC clock -- a step of the wall clock would stretch or swallow the
+ * poll -- which a condition variable has to be told when it is made.  (Pool lock held; before anybody has waited on it.) */
+static void pool_cv_locked(void)
+{
+    pthread_condattr_t a;
+    if (g_pool.cv_ready) return;
+    pthread_condattr_init(&a);
+    pthread_condattr_setclock(&a, CLOCK_MONOTONIC);
+    pthread_cond_init(&g_pool.work, &a);
+    pthread_condattr_destroy(&a);
+    g_pool.cv_ready = 1;
+}
 
 /* CPUs this process may use at once: the affinity mask, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs_quota) */
 int mzi_cpu_budget(void)
@@ -152,7 +165,7 @@ static void idle_wait(void)
 {
     if (g_out && g_watchers < 2) {
         struct timespec t;
-        clock_gettime(CLOCK_REALTIME, &t);
+        clock_gettime(CLOCK_MONOTONIC, &t);                  /* (the clock `work` was made for: pool_cv_locked) */
         t.tv_nsec += 1000L * (g_hedge_us / 2 > 50 ? g_hedge_us / 2 : 50);
         if (t.tv_nsec >= 1000000000L) { t.tv_nsec -= 1000000000L; t.tv_sec++; }
         ++g_watchers;
@@ -201,6 +214,7 @@ static void pool_start_locked(void)
 {
     const char *e = getenv("MZ_HOST_THREADS");
     int want = e && atoi(e) > 0 ? atoi(e) : (int)sysconf(_SC_NPROCESSORS_ONLN), i;
+    pool_cv_locked();
     if (want > MZ_COPY_THREADS && !(e && atoi(e) > 0)) want = MZ_COPY_THREADS;
     if (want < 1) want = 1;
     if (want > POOL_MAX) want = POOL_MAX;
@@ -284,6 +298,7 @@ void mzi_post(mz_ajob *job)
 void mzi_help_until(int (*ready)(void *), void *arg)
 {
     pthread_mutex_lock(&g_pool.mu);
+    pool_cv_locked();
     while (!ready(arg)) {
         pjob *j;
         int lo, hi, piece;
@@ -316,6 +331,7 @@ int mzi_job_quiet(mz_ajob *job)
 void mzi_pool_kick(void)
 {
     pthread_mutex_lock(&g_pool.mu);
+    pool_cv_locked();
     pthread_cond_broadcast(&g_pool.work);
     pthread_mutex_unlock(&g_pool.mu);
 }

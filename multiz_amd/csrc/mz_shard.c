@@ -22,8 +22,14 @@
 #include "mz_ctx.h"
 #include "../../include/mz_shard.h"
 
-static int64_t g_sent, g_received;
-void mz_shard_traffic(int64_t *sent, int64_t *received) { if (sent) *sent = g_sent; if (received) *received = g_received; }
+static int64_t g_sent, g_received;         /* (ranks may be threads of one process -- the loop-back tests: atomic adds) */
+#define SENT(b) __atomic_fetch_add(&g_sent, (int64_t)(b), __ATOMIC_RELAXED)
+#define RECEIVED(b) __atomic_fetch_add(&g_received, (int64_t)(b), __ATOMIC_RELAXED)
+void mz_shard_traffic(int64_t *sent, int64_t *received)
+{
+    if (sent) *sent = __atomic_load_n(&g_sent, __ATOMIC_RELAXED);
+    if (received) *received = __atomic_load_n(&g_received, __ATOMIC_RELAXED);
+}
 
 /* ------------------------------------------------------------------------------------------------ host buffers (loop-back, custom) */
 
@@ -57,7 +63,7 @@ static int lb_recv(mz_comm *c, void *buf, size_t bytes, int peer)
 {
     lb_world *w = (lb_world *)c->self;
     struct timespec until;
-    clock_gettime(CLOCK_REALTIME, &until);
+    clock_gettime(CLOCK_MONOTONIC, &until);                  /* (ten seconds of the monotonic clock, whatever the wall clock does meanwhile) */
     until.tv_sec += 10;
     pthread_mutex_lock(&w->mu);
     for (;;) {
@@ -99,7 +105,8 @@ int mz_comm_loopback(int size, mz_comm **ranks)
     if (size < 1 || !ranks) return mzi_set_err("mz_comm_loopback: bad arguments");
     w = (lb_world *)calloc(1, sizeof *w);
     if (!w) return mzi_set_err("out of memory");
-    pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL);
+    pthread_mutex_init(&w->mu, NULL);
+    { pthread_condattr_t a; pthread_condattr_init(&a); pthread_condattr_setclock(&a, CLOCK_MONOTONIC); pthread_cond_init(&w->cv, &a); pthread_condattr_destroy(&a); }   /* (lb_recv's deadline) */
     for (r = 0; r < size; ++r) {
         mz_comm *c = (mz_comm *)calloc(1, sizeof *c);
         if (!c) { while (r-- > 0) free(ranks[r]); free(w); return mzi_set_err("out of memory"); }
@@ -161,12 +168,15 @@ static pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static int rccl_load(void)
 {
+    char why[300] = "";
     int ok;
     pthread_mutex_lock(&g_rccl_mu);
     if (!R.lib) {
+        const char *e;
         void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { e = dlerror(); snprintf(why, sizeof why, "%s", e ? e : "dlopen failed"); }      /* (dlerror() clears what it returns: asked once) */
         if (h) {
 #define SYM(field, name) *(void **)&R.field = dlsym(h, name)
             SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
@@ -174,11 +184,12 @@ static int rccl_load(void)
             SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
             if (R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.GroupStart && R.GroupEnd && R.Send && R.Recv) R.lib = h;
+            else { snprintf(why, sizeof why, "it lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv"); memset(&R, 0, sizeof R); dlclose(h); }
         }
     }
     ok = R.lib != NULL;
     pthread_mutex_unlock(&g_rccl_mu);
-    return ok ? 0 : mzi_set_err("librccl.so cannot be loaded: %s", dlerror() ? dlerror() : "a symbol is missing");
+    return ok ? 0 : mzi_set_err("librccl.so cannot be loaded: %s", why);
 }
 #define NCK(call) do { const int r_ = (call); if (r_ != 0) return mzi_set_err("%s failed: %s", #call, R.GetErrorString ? R.GetErrorString(r_) : "?"); } while (0)
 
@@ -245,7 +256,7 @@ int mz_comm_echo(mz_comm *c, size_t bytes)
     if (c->group_start(c) || c->send(c, b0, bytes, c->rank) || c->recv(c, b1, bytes, c->rank) || c->group_end(c)) goto out;
     if (c->get(c, h1, b1, bytes)) goto out;
     rc = memcmp(h0, h1, bytes) == 0 ? 0 : mzi_set_err("mz_comm_echo: what came back differs");
-    g_sent += (int64_t)bytes; g_received += (int64_t)bytes;
+    SENT(bytes); RECEIVED(bytes);
 out:
     if (b0) c->release(c, b0);
     if (b1) c->release(c, b1);
@@ -354,7 +365,7 @@ int mz_shard_scatter(mz_comm *c, int root, int n, const mz_job *jobs, mz_shard *
             if (c->send(c, s_img[r], (size_t)descs[r].image_bytes, r)) goto done;
             if (descs[r].exc_bytes && c->send(c, s_exc[r], (size_t)descs[r].exc_bytes, r)) goto done;
             if (sh->cnt[r] && c->send(c, s_idx[r], 8 * (size_t)sh->cnt[r], r)) goto done;
-            g_sent += (int64_t)sizeof hdr + descs[r].image_bytes + descs[r].exc_bytes + 8 * (int64_t)sh->cnt[r];
+            SENT((int64_t)sizeof hdr + descs[r].image_bytes + descs[r].exc_bytes + 8 * (int64_t)sh->cnt[r]);
         }
         if (c->group_end(c)) goto done;
     } else {
@@ -374,7 +385,7 @@ int mz_shard_scatter(mz_comm *c, int root, int n, const mz_job *jobs, mz_shard *
             (sh->n_share && c->recv(c, ibuf, 8 * (size_t)sh->n_share, root)) || c->group_end(c) ||
             (sh->n_share && c->get(c, sh->index, ibuf, 8 * (size_t)sh->n_share))) { c->release(c, ibuf); goto done; }
         c->release(c, ibuf);
-        g_received += (int64_t)sizeof hdr + sh->desc.image_bytes + sh->desc.exc_bytes + 8 * sh->n_share;
+        RECEIVED((int64_t)sizeof hdr + sh->desc.image_bytes + sh->desc.exc_bytes + 8 * sh->n_share);
     }
     rc = 0;
 done:
@@ -400,6 +411,8 @@ int mz_shard_host_image(mz_comm *c, mz_shard *sh, const void **image, const void
 int mz_shard_set_result(mz_comm *c, mz_shard *sh, const void *result, int64_t bytes)
 {
     if (!c || !sh || !result || bytes < 0) return mzi_set_err("mz_shard_set_result: bad arguments");
+    if (bytes < mzi_result_image_min((int)sh->n_share))
+        return mzi_set_err("mz_shard_set_result: %lld bytes cannot be the result image of %lld pairs (header and records alone: %lld)", (long long)bytes, (long long)sh->n_share, (long long)mzi_result_image_min((int)sh->n_share));
     if (sh->result) c->release(c, sh->result);
     sh->result = c->alloc(c, (size_t)bytes);
     if (!sh->result) return mzi_set_err("out of memory");
@@ -453,7 +466,7 @@ int mz_shard_gather(mz_comm *c, int root, mz_shard *sh, const mz_job *jobs, mz_o
         if (c->put(c, hb, hdr, sizeof hdr) || c->group_start(c) || c->send(c, hb, sizeof hdr, root) || c->group_end(c)) { c->release(c, hb); return -1; }
         c->release(c, hb);
         if (sh->res_bytes && (c->group_start(c) || c->send(c, sh->result, (size_t)sh->res_bytes, root) || c->group_end(c))) return -1;
-        g_sent += (int64_t)sizeof hdr + sh->res_bytes;
+        SENT((int64_t)sizeof hdr + sh->res_bytes);
         return 0;
     }
     if (sh->n_total && (!jobs || !outs)) return mzi_set_err("mz_shard_gather: the root needs the jobs it scattered and outs");
@@ -472,13 +485,15 @@ int mz_shard_gather(mz_comm *c, int root, mz_shard *sh, const mz_job *jobs, mz_o
             if (r == root) { rbytes[r] = sh->res_bytes; continue; }
             if (c->get(c, hdr, hb[r], sizeof hdr)) goto rdone;
             if (hdr[0] != sh->cnt[r] || hdr[1] < 0) { mzi_set_err("mz_shard_gather: rank %d answers for %lld pairs, it was given %d", r, (long long)hdr[0], sh->cnt[r]); goto rdone; }
+            /* (an image too short for its own records -- none at all, say -- is not read: the records would come from whatever lies behind it) */
+            if (hdr[1] < mzi_result_image_min(sh->cnt[r])) { mzi_set_err("mz_shard_gather: rank %d sends a result image of %lld bytes for %d pairs (their records alone take %lld)", r, (long long)hdr[1], sh->cnt[r], (long long)mzi_result_image_min(sh->cnt[r])); goto rdone; }
             rbytes[r] = hdr[1];
             if (rbytes[r] && !(rb[r] = c->alloc(c, (size_t)rbytes[r]))) { mzi_set_err("out of memory for rank %d's results", r); goto rdone; }
         }
         if (c->group_start(c)) goto rdone;                   /* group 4: the result images, every peer's at once */
         for (r = 0; r < W; ++r) if (r != root && rbytes[r] && c->recv(c, rb[r], (size_t)rbytes[r], r)) goto rdone;
         if (c->group_end(c)) goto rdone;
-        for (r = 0; r < W; ++r) if (r != root) g_received += (int64_t)sizeof hdr + rbytes[r];
+        for (r = 0; r < W; ++r) if (r != root) RECEIVED((int64_t)sizeof hdr + rbytes[r]);
         /* every share's merged columns from the root's own A and B; every pair's result to its place in the list */
         for (r = 0; r < W; ++r) {
             void *host;

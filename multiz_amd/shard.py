@@ -247,17 +247,32 @@ def device_compute(shard: dict, device=None, keep: Optional[list] = None) -> dic
 # the group's own blocking send / recv of host bytes where it is "gloo" (the CPU tests).
 
 last_exchange: Dict[str, int] = {}            # bytes of the last link scatter / gather on this rank (the root's are the totals)
-_comms: Dict[int, object] = {}
+_comms: Dict[int, tuple] = {}                  # id(group object) -> (weak reference to that object, its api.Comm)
+
+
+def drop_comms():
+    """free the transports made so far (before dist.destroy_process_group(): an RCCL communicator must not outlive its job)"""
+    for _ref, comm in _comms.values():
+        comm.free()
+    _comms.clear()
 
 
 def comm_for(group=None, device="cpu"):
-    """the library's transport (api.Comm) for a torch.distributed process group: made once per group"""
+    """the library's transport (api.Comm) for a torch.distributed process group: made once per group OBJECT -- the key is the
+    group's id() together with a weak reference to it, so a new group that happens to get a collected one's id (or the default group
+    after destroy_process_group() + init_process_group()) makes a new transport and the stale one is freed"""
+    import weakref
     import torch
     import torch.distributed as dist
     from . import api
-    key = id(group)
-    if key in _comms:
-        return _comms[key]
+    obj = group if group is not None else dist.distributed_c10d._get_default_group()
+    key = id(obj)
+    hit = _comms.get(key)
+    if hit is not None:
+        if hit[0]() is obj:
+            return hit[1]
+        hit[1].free()                                        # (the id belonged to a group that is gone)
+        del _comms[key]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
         t = torch.zeros(128, dtype=torch.uint8)
@@ -273,7 +288,11 @@ def comm_for(group=None, device="cpu"):
         def recv(buf, peer):
             dist.recv(torch.from_numpy(buf), src=dist.get_global_rank(group, peer) if group is not None else peer, group=group)
         comm = api.Comm.custom(rank, world, send, recv)
-    _comms[key] = comm
+    try:
+        ref = weakref.ref(obj)
+    except TypeError:                                        # (a group type without weak references: keep it alive instead)
+        ref = (lambda o: (lambda: o))(obj)
+    _comms[key] = (ref, comm)
     return comm
 
 

@@ -130,8 +130,61 @@ def test_a_result_image_of_another_list_is_refused():
     sh = api.Shard(comms[0], 0, jobs)
     image, exc = sh.host_image()
     res, _, _ = linkfmt.oracle_result_image(sh.desc, image, exc)
-    sh.set_result(res[: 64 + 8])                                 # too short for six records
-    with pytest.raises(RuntimeError, match="too short"):
+    for short in (res[: 64 + 8], res[:0]):                       # too short for six records; no image at all (read as "trusted" once)
+        with pytest.raises(RuntimeError, match="cannot be the result image"):
+            sh.set_result(short)
+    bad = res.copy()
+    bad[64: 64 + 40 * 6].view(api.RES_DT)["off"][2] = 1 << 40    # records that point outside the image
+    sh.set_result(bad)
+    with pytest.raises(RuntimeError, match="does not belong"):
         sh.gather()
     sh.free()
     comms[0].free()
+
+
+def test_a_peer_that_answers_with_no_image_is_refused():
+    """the root checks what a PEER says about its result image before it reads any of it: a header of [pairs, 0 bytes] used to be taken
+    for "the pipeline's own image" and its records read from a one-byte block"""
+    batch, pairs = _batch(5, 8)
+    jobs, _ = api.host_jobs(batch)
+    state = {"share": None}
+
+    def send(buf, peer):
+        pass                                                     # (whatever the root scatters is dropped: the peer is this test)
+
+    def recv(buf, peer):
+        if buf.size == 16:                                       # the gather's header: [pairs of the share, bytes of its result image]
+            buf.view(np.int64)[:] = [state["share"], 0]
+        else:
+            buf[:] = 0
+
+    comm = api.Comm.custom(0, 2, send, recv)
+    sh = api.Shard(comm, 0, jobs)
+    state["share"] = len(jobs) - sh.n
+    _align_with_oracle(sh)
+    with pytest.raises(RuntimeError, match="result image of 0 bytes"):
+        sh.gather()
+    sh.free()
+    comm.free()
+
+
+def test_more_ranks_than_gpus_fit_a_node():
+    """the dealing rule is shared with mz_yama_batch()'s GPUs of one process (at most 16); ranks are any number (a world of 17
+    overran a stack array)"""
+    world, n = 40, 53
+    batch, pairs = _batch(3, n)
+    jobs, _ = api.host_jobs(batch)
+    comms = api.Comm.loopback(world)
+    shards = [api.Shard(comms[0], 0, jobs)] + [api.Shard(comms[r], 0, None) for r in range(1, world)]
+    assert sum(sh.n for sh in shards) == n and max(sh.n for sh in shards) <= 2
+    for sh in shards:
+        _align_with_oracle(sh)
+    for sh in shards[1:]:
+        sh.gather()
+    outs, failed = shards[0].gather()
+    _check_root(outs, failed, batch, pairs, [s.index for s in shards])
+    api.free_outs(outs)
+    for sh in shards:
+        sh.free()
+    for c in comms:
+        c.free()
