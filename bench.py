@@ -4,20 +4,32 @@
     python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--scatter]
 
 A "step" is one pass of the whole hot path -- validity/plan, banded DP with traceback, traceback walk,
-merged-column emit (reference mz_yama.c:58-313) -- over one batch of synthetic block pairs that is already
-resident in HBM.  Workload at N=1: BASELINE.json configs[1] ("50k synthetic block pairs, 2+2 rows, ~1k x 1k
-cols, banded yama DP on 1 MI355X"); --config picks another BASELINE configuration (c3 deep sum-of-pairs, c4 one
-GPU's share of the 30-leaf guide-tree workload, c5 long blocks).  With N > 1 every rank runs its own shard of the
-same generator (weak scaling, no data-path collective: block pairs are independent; one all-reduce of three
-scalars closes the batch).  --scatter instead builds the WHOLE list on rank 0 and deals it out through
-multiz_amd.shard (RCCL point-to-point scatter, device compute on the received tensors, gather) before the timed
-steps -- BASELINE configs[3]'s "sharded over 8 x MI355X via RCCL" as one command; the exchange times are reported
-beside the value.  `--gpus N` without a torch.distributed environment starts the N ranks itself.
+merged columns (reference mz_yama.c:58-313) -- over one batch of synthetic block pairs.  Workload at N=1:
+BASELINE.json configs[1] ("50k synthetic block pairs, 2+2 rows, ~1k x 1k cols, banded yama DP on 1 MI355X");
+--config picks another BASELINE configuration (c3 deep sum-of-pairs, c4 one GPU's share of the 30-leaf guide-tree
+workload, c5 long blocks).  With N > 1 every rank runs its own shard of the same generator (weak scaling, no
+data-path collective: block pairs are independent; one all-reduce of three scalars closes the batch).  --scatter
+instead builds the WHOLE list on rank 0 and deals it out through the library's exchange (include/mz_shard.h: RCCL
+grouped send / recv, chunks of the list packed, moved, aligned and assembled side by side) before the timed steps --
+BASELINE configs[3]'s "sharded over 8 x MI355X via RCCL" as one command; the exchange times are reported beside the
+value.  `--gpus N` without a torch.distributed environment starts the N ranks itself.
 
-One JSON line on stdout (rank 0).  `value` is the whole-job rate of the pipelined, device-resident form.  Beside it
-(SURVEY.md section 8d asks for both columns): `value_host` = the same batch through mz_yama_batch() from host
-buffers to malloc()ed merged columns, PCIe both ways included (N=1), and `single_batch_gcups` = the phases one after the
-other from HIP events.  Cells are band cells, counted exactly as the reference counts tback_size (mz_yama.c:60-66).
+One JSON line on stdout (rank 0).  SURVEY.md section 8(d) defines the metric's wall time as "H2D of packed jobs +
+kernels + D2H of packed outputs (report kernel-only as a second column)", so -- since round 6 --
+
+    value / ms_per_step   K calls of mz_yama_batch(): the batch from HOST buffers to malloc()ed merged columns, packing,
+                          PCIe both ways and the host-side assembly included -- what the reference's drivers get;
+                          every call timed on its own between synchronisations (max over ranks), 50 ms apart (the GPU
+                          boxes give a job 16 CPUs' worth of time per 100 ms and a call spends 0.15 s of CPU: calls
+                          issued back to back run into that quota, `back_to_back` has that rate), value = cells x K /
+                          the sum of the K times.  (`value_host`: the same number under its old name.)
+    value_resident        the second column: the batch already in HBM, the pipelined device-resident form
+                          (mz_dev_run_async), `resident_steps` steps -- what rounds 1-5 printed as `value`.
+    single_batch_gcups    one resident batch, its phases one after the other from HIP events; `roofline` is the DP launch
+                          of that form.
+    value_pre / _v0       the same work as block TEXT through mz_preyama_batch() (what mz_multiz / mz_roast use).
+
+Cells are band cells, counted exactly as the reference counts tback_size (mz_yama.c:60-66).
 """
 import argparse
 import json
@@ -403,15 +415,17 @@ def algorithmic_bytes(batch, om):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)   # (a c2 step is ~5.4 ms; the pipeline's fill and drain cost ~2.5 ms per run)
+    ap.add_argument("--steps", type=int, default=25)    # timed calls of mz_yama_batch() (the headline: SURVEY 8d's transfer-inclusive wall time)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--resident-steps", type=int, default=0,     # (a c2 step is ~5.1 ms; the pipeline's fill and drain cost ~2.5 ms per run)
+                    help="timed steps of the device-resident pipeline (value_resident); default 100, with --no-host: --steps")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "c2i", "c4i", "c2w", "c2s", "c2g"])
     ap.add_argument("--pairs", type=int, default=0, help="override pairs per GPU (default: the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) columns")
     ap.add_argument("--no-pre", action="store_true", help="skip the block-text column (value_pre)")
-    ap.add_argument("--host-reps", type=int, default=25, help="timed calls of the host-buffer column (median; the spread is in host_spread)")
+    ap.add_argument("--host-gap-ms", type=float, default=50.0, help="pause between the timed host-path calls (outside the timed brackets; 0: back to back)")
     ap.add_argument("--pre-check", type=int, default=300, help="merges per variant the text path's parity gate samples (0: none)")
     ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 builds the whole list and deals it out (multiz_amd.shard)")
     ap.add_argument("--pre-v", type=int, default=2, help="--mode pre: 1 one-stage merges, 0 two-stage, 2 alternating")
@@ -484,6 +498,10 @@ def main():
     import multiz_amd as mz
     from multiz_amd import api, shard, synth
 
+    if world > 1:
+        # the ranks of a node share its cores: every rank's packing / assembling pool (mz_pool.c: 24 threads by default, for one process
+        # on a 16-CPU quota) gets its share of one and a half times the CPUs this job may use
+        os.environ.setdefault("MZ_HOST_THREADS", str(max(4, min(24, cpu_budget()[0] * 3 // 2 // world))))
     api.init(local)
     cfg = dict(synth.CONFIGS[args.config])
     pairs = args.pairs or cfg["pairs"]
@@ -532,21 +550,45 @@ def main():
             exchange = {"format": "link images, exchanged by the library (mz_shard_*: " + ("RCCL" if dist.get_backend() == "nccl" else "the group's send / recv") + ")",
                         "scatter_s": round(t_scatter, 4), "align_s": round(t_align, 4), "gather_s": round(t_gather, 4),
                         "pairs_this_rank": int(len(my_idx))}
+            def check_sample(sh_, label):
+                """every sampled pair's merged columns (the bytes the root assembled from ITS pools) against the compiled reference"""
+                from oracle import mzoracle as mo
+                idx = np.linspace(0, pairs * world - 1, num=min(400, pairs * world)).astype(np.int64)
+                sub = shard.take(whole, idx)
+                om_r, hs_r, _, bad_r = mo.ref_batch(sub, threads=8) if mo.have_reference() else mo.yama_batch(sub, variant=1, threads=8)
+                mism = sum(int(sh_.om[i]) != int(om_r[k]) or
+                           mo.fnv1a_np(sh_.cols(int(i)), mo.fnv1a_np(np.array([sh_.om[i]], dtype=np.int32).view(np.uint8))) != int(hs_r[k]) for k, i in enumerate(idx))
+                assert bad_r == 0 and mism == 0, f"{label}: {mism} of {len(idx)} gathered pairs differ from the reference"
+                return int(len(idx))
             if rank == 0:
-                ex = shard.last_exchange
+                ex = dict(shard.last_exchange)
                 exchange["bytes_per_pair"] = {"out": round(ex["up_bytes"] / ex["pairs"], 1), "back": round(ex["down_bytes"] / ex["pairs"], 1),
                                               "pools_out": round(sum(whole[k].nbytes for k in ("poolA", "poolB", "poolLB", "poolRB")) / ex["pairs"], 1),
                                               "columns_back": round(float((sh.om.astype(np.int64) * sh.widths).sum()) / ex["pairs"], 1)}
-                # every pair's merged columns against the compiled reference on a sample (the bytes the root assembled from ITS pools)
                 if not args.no_cpu:
-                    from oracle import mzoracle as mo
-                    idx = np.linspace(0, pairs * world - 1, num=min(400, pairs * world)).astype(np.int64)
-                    sub = shard.take(whole, idx)
-                    om_r, hs_r, _, bad_r = mo.ref_batch(sub, threads=8) if mo.have_reference() else mo.yama_batch(sub, variant=1, threads=8)
-                    mism = sum(int(sh.om[i]) != int(om_r[k]) or
-                               mo.fnv1a_np(sh.cols(int(i)), mo.fnv1a_np(np.array([sh.om[i]], dtype=np.int32).view(np.uint8))) != int(hs_r[k]) for k, i in enumerate(idx))
-                    assert bad_r == 0 and mism == 0, f"{mism} of {len(idx)} gathered pairs differ from the reference"
-                    exchange["checked_pairs"] = int(len(idx))
+                    exchange["checked_pairs"] = check_sample(sh, "three phases")
+            # ---- the same list through the exchange IN CHUNKS (mz_shard_run, round 6): the root packs chunk t+1 and assembles chunk t-3
+            # while the transport moves chunk t down and chunk t-2's results up and every GPU aligns chunk t-1 -- one call on every rank
+            sync_early = (lambda: (torch.cuda.synchronize(dev), dist.barrier()))
+            sync_early()
+            t0 = time.perf_counter()
+            sh2, totals2, times2 = shard.run_sharded_chunks(whole, None, 0, red)
+            torch.cuda.synchronize(dev)
+            t_chunked = time.perf_counter() - t0
+            tt = torch.tensor([t_chunked, times2["align_s"]], dtype=torch.float64, device=red)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            three = exchange["scatter_s"] + exchange["align_s"] + exchange["gather_s"]
+            exchange["chunked"] = {"wall_s": round(float(tt[0].item()), 4), "chunks": int(times2["chunks"]), "steps": int(times2["steps"]),
+                                   "root_sums_s": {k: round(times2[k], 4) for k in ("pack_s", "comm_s", "align_s", "assemble_s")},
+                                   "align_s_max_over_ranks": round(float(tt[1].item()), 4),
+                                   "three_phases_sum_s": round(three, 4),
+                                   "wall_over_longest_phase": round(float(tt[0].item()) / max(exchange["scatter_s"], exchange["align_s"], exchange["gather_s"], 1e-9), 3),
+                                   "totals": list(totals2)}
+            if rank == 0:
+                assert (sh2.status == 0).all(), "a pair came back without a result from the chunked exchange"
+                if not args.no_cpu:
+                    exchange["chunked"]["checked_pairs"] = check_sample(sh2, "chunked")
+                sh2.release()
             tens = api.link_expand(desc, image, exc)              # the timed steps run on the shard as it arrived: the image, expanded in HBM
             db = mz.DevBatch.from_tensors(tens, device=dev)
         batch = {k: v.cpu().numpy() for k, v in tens.items()}                 # host copy for the byte accounting below
@@ -575,7 +617,8 @@ def main():
     # per-kernel durations for the roofline: the batch with the phases serialised and a HIP event pair around
     # each, on the stream the kernels are launched on (outside the timed region; doubles as extra warm-up)
     kern_ms = np.zeros(4)
-    kreps = max(3, min(args.steps, 20))
+    rsteps = args.resident_steps if args.resident_steps > 0 else max(1, args.steps) if args.no_host else 100
+    kreps = max(3, min(rsteps, 20))
     db.run()                                                     # (first use creates the library's helper streams)
     for _ in range(kreps):
         kern_ms += np.array(db.run(timed=True))
@@ -591,13 +634,13 @@ def main():
     db.wait()
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(rsteps):
         ring[(args.warmup + i) % nws].run_async()
     db.wait()
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
-    workspaces = ring[:min(nws, args.warmup + args.steps)]
+    workspaces = ring[:min(nws, args.warmup + rsteps)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -614,8 +657,8 @@ def main():
     if all_failed:
         raise SystemExit(f"{all_failed} block pairs failed on the device -- number void")
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    gcups = all_cells * args.steps / elapsed / 1e9
+    resident_ms = 1e3 * elapsed / rsteps
+    resident_gcups = all_cells * rsteps / elapsed / 1e9
     dp_ms = float(kern_ms[1])
     roof_achieved = total_bytes / (dp_ms * 1e-3) / 1e9          # GB/s, algorithmic bytes over the DP kernel's time
     modes = np.bincount(res["mode"], minlength=14)
@@ -628,17 +671,84 @@ def main():
     dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
                           (int(modes[:4].sum()), "k_dp"), (int(modes[4]), "k_dp_tstrip"), (int(modes[13]), "k_dp_duo"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
 
+    # ---- THE HEADLINE, the first column of SURVEY 8(d): host buffers in, malloc()ed merged columns out, through mz_yama_batch() -- pack,
+    # H2D, kernels, D2H, assembly on the host; chunks pipelined.  Every rank runs it on its own batch (its own PCIe
+    # link; the host's cores are shared); every call is bracketed by a barrier + synchronize on both sides and counts with the MAX over ranks.
+    host_hash = None
+    host = None
+    if not args.no_host:
+        jobs, outs = api.host_jobs(batch)
+        for _ in range(max(2, args.warmup)):                     # warm-up: the rotating staging buffers and result blocks grow to size
+            api.yama_batch_records(jobs, outs)
+            host_om = outs["OM"].copy()
+            api.free_outs(outs)
+        # (the container's CPU quota is per 100 ms period: let the period the harness's own threads -- generator, checker --
+        #  have drawn on run out before the library's host threads are timed)
+        time.sleep(0.3)
+        t_host = []
+        os.environ["MZ_TIMING"] = "0"
+        thr0 = cpu_throttle()
+        for _ in range(args.steps):
+            sync_all()
+            t = time.perf_counter()
+            api.yama_batch_records(jobs, outs)
+            torch.cuda.synchronize(dev)
+            t_host.append(time.perf_counter() - t)
+            api.free_outs(outs)
+            if args.host_gap_ms > 0:
+                time.sleep(args.host_gap_ms * 1e-3)
+        thr1 = cpu_throttle()
+        t_host = np.array(t_host, dtype=np.float64)
+        if world > 1:                                            # a step ends when the slowest rank's call has
+            tt = torch.from_numpy(t_host.copy()).to(red)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_host = tt.cpu().numpy()
+        # the same calls back to back (no pause): what a caller that streams batches gets under this box's CPU quota
+        sync_all()
+        nb2b = min(args.steps, 12)
+        t = time.perf_counter()
+        for _ in range(nb2b):
+            api.yama_batch_records(jobs, outs)
+            api.free_outs(outs)
+        sync_all()
+        t_b2b = (time.perf_counter() - t) / nb2b
+        thr2 = cpu_throttle()
+        if cpu is not None:                                      # the host path's BYTES, hashed like the CPU leg's (checker code; untimed call)
+            from oracle import mzoracle as mo
+            api.yama_batch_records(jobs, outs)
+            assert np.array_equal(outs["OM"], host_om)
+            host_hash = mo.hash_cols(outs["cols"], outs["OM"], batch["K"] + batch["L"])
+            api.free_outs(outs)
+        assert np.array_equal(host_om, res["om"]), "host path and device-resident path disagree"
+        t_med, t_sum = float(np.median(t_host)), float(t_host.sum())
+        link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
+        host = {"gcups": all_cells * args.steps / t_sum / 1e9, "ms": 1e3 * t_sum / args.steps,
+                "median_gcups": round(all_cells / t_med / 1e9, 2), "median_ms": round(1e3 * t_med, 2),
+                "ms_all": [round(1e3 * x, 2) for x in t_host],
+                "spread": {"calls": int(args.steps), "max_over_median": round(float(t_host.max()) / t_med, 3), "min_over_median": round(float(t_host.min()) / t_med, 3),
+                           "calls_above_1.15_median": int((t_host > 1.15 * t_med).sum()),
+                           "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None)},
+                "back_to_back": {"calls": nb2b, "ms_per_call": round(1e3 * t_b2b, 2), "gcups": round(all_cells / t_b2b / 1e9, 2),
+                                 "cgroup_throttled_during_the_calls": ({"periods": thr2[0] - thr1[0], "usec": thr2[1] - thr1[1]} if thr1 and thr2 else None)},
+                "link_bytes_per_pair": {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}}
+
     out = {
         "metric": "GCUPS (DP cell updates/s) on yama block-pair merge",
-        "value": round(gcups, 3), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        # value: K calls of mz_yama_batch(), host buffers in, merged columns out, transfers included (SURVEY 8d's wall time; --no-host:
+        # the resident rate, and the line says so)
+        "value": round(host["gcups"] if host else resident_gcups, 3), "unit": "GCUPS", "n_gpus": world,
+        "steps": args.steps if host else rsteps, "warmup": args.warmup,
+        "ms_per_step": round(host["ms"] if host else resident_ms, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "value_is": ("mz_yama_batch(): host buffers in, merged columns out -- packing, H2D, kernels, D2H and host-side assembly inside every timed call (SURVEY.md 8d)"
+                     if host else "device-resident pipeline (--no-host)"),
         "config": {"workload": synth.describe(args.config, pairs),
                    "pairs_total": all_pairs, "band_cells_total": all_cells,
                    "parallelism": f"pairs sharded x{world}" + (" (list built on rank 0, RCCL scatter/gather)" if exchange else "")},
-        # the second column of SURVEY 8(d): the phases one after the other (HIP events, serial form)
-        # ONE batch, plan -> DP -> walk -> emit one after the other, nothing of a neighbouring batch beside it (`value` is the pipelined
-        # form: at C5 five batches abreast)
+        # the second column of SURVEY 8(d): the batch already in HBM, the pipelined device-resident form (rounds 1-5 printed this as `value`)
+        "value_resident": round(resident_gcups, 3), "resident_ms_per_step": round(resident_ms, 3), "resident_steps": rsteps,
+        # ONE resident batch, plan -> DP -> walk -> emit one after the other (HIP events), nothing of a neighbouring batch beside it
+        # (`value_resident` is the pipelined form: at C5 five batches abreast)
         "single_batch_gcups": round(cells / (float(kern_ms.sum()) * 1e-3) / 1e9, 1),
         "kernel_ms": {"plan": round(float(kern_ms[0]), 3), "dp": round(dp_ms, 3),
                       "walk": round(float(kern_ms[2]), 3), "emit": round(float(kern_ms[3]), 3)},
@@ -678,6 +788,14 @@ def main():
                 v["frac_at_this_runs_dp_time"] = round(pmc["SQ_INSTS_VALU"] * cpi / (SIMDS * clock * 1e9 * dp_ms * 1e-3), 4)
         out["roofline"]["valu"] = v
         out["roofline"]["pmc"] = {"source": pmc["source"], "stale": pmc["stale"], "kernel_avg_ms_in_stats_run": round(pmc.get("avg_ns", 0) / 1e6, 3)}
+    if host:
+        out["value_host"] = round(host["gcups"], 2)              # (the headline under its old name; rounds 3-5 printed the median of the calls)
+        out["host_ms_per_batch"] = round(host["ms"], 2)
+        out["host_median"] = {"gcups": host["median_gcups"], "ms": host["median_ms"]}
+        out["host_ms_all"] = host["ms_all"]
+        out["host_spread"] = host["spread"]
+        out["back_to_back"] = host["back_to_back"]
+        out["host_link_bytes_per_pair"] = host["link_bytes_per_pair"]
     if exchange:
         out["exchange"] = exchange
     if world > 1:
@@ -690,55 +808,16 @@ def main():
         mine = mine.to(red)
         all_id = [torch.zeros(128, dtype=torch.uint8, device=red) for _ in range(world)]
         dist.all_gather(all_id, mine)
-        mine_rate = torch.tensor([cells * args.steps / max(elapsed_local, 1e-9) / 1e9, float(cells)], dtype=torch.float64, device=red)
+        mine_rate = torch.tensor([cells * rsteps / max(elapsed_local, 1e-9) / 1e9, float(cells)], dtype=torch.float64, device=red)
         all_rate = [torch.zeros(2, dtype=torch.float64, device=red) for _ in range(world)]
         dist.all_gather(all_rate, mine_rate)
         idents = [bytes(t.cpu().tolist()).rstrip(b"\0").decode() for t in all_id]
         rates = [round(float(t[0].item()), 2) for t in all_rate]
         out["devices"] = idents
         out["distinct_devices"] = len(set(idents))
-        out["per_rank_gcups"] = rates
+        out["per_rank_gcups"] = rates                            # (of the resident pipeline: every rank's own GPU, nothing shared)
         out["rank_max_over_min"] = round(max(rates) / max(min(rates), 1e-9), 3)
         out["backend"] = "gloo (ranks share GPU 0: development switch, not a scaling measurement)" if share else "nccl (RCCL)"
-
-    # ---- the first column of SURVEY 8(d): host buffers in, malloc()ed merged columns out, through mz_yama_batch()
-    # (pack, H2D, kernels, D2H, unpack; chunks pipelined four deep).  N = 1 only: it measures one GPU's PCIe link.
-    host_hash = None
-    if rank == 0 and world == 1 and not args.no_host:
-        jobs, outs = api.host_jobs(batch)
-        for _ in range(2):                                       # warm-up: the rotating staging buffers and result blocks grow to size
-            api.yama_batch_records(jobs, outs)
-            host_om = outs["OM"].copy()
-            api.free_outs(outs)
-        # (the container's CPU quota is per 100 ms period: let the period the harness's own threads -- generator, checker --
-        #  have drawn on run out before the library's host threads are timed)
-        time.sleep(0.3)
-        reps, t_host = max(3, args.host_reps), []
-        os.environ["MZ_TIMING"] = "0"
-        thr0 = cpu_throttle()
-        for _ in range(reps):
-            t = time.perf_counter()
-            api.yama_batch_records(jobs, outs)
-            t_host.append(time.perf_counter() - t)
-            api.free_outs(outs)
-            time.sleep(0.05)
-        thr1 = cpu_throttle()
-        if cpu is not None:                                      # the host path's BYTES, hashed like the CPU leg's (checker code; untimed call)
-            from oracle import mzoracle as mo
-            api.yama_batch_records(jobs, outs)
-            assert np.array_equal(outs["OM"], host_om)
-            host_hash = mo.hash_cols(outs["cols"], outs["OM"], batch["K"] + batch["L"])
-            api.free_outs(outs)
-        assert np.array_equal(host_om, res["om"]), "host path and device-resident path disagree"
-        t_med = float(np.median(t_host))
-        out["value_host"] = round(cells / t_med / 1e9, 2)
-        out["host_ms_per_batch"] = round(1e3 * t_med, 2)
-        out["host_ms_all"] = [round(1e3 * x, 2) for x in t_host]
-        out["host_spread"] = {"calls": reps, "max_over_median": round(max(t_host) / t_med, 3), "min_over_median": round(min(t_host) / t_med, 3),
-                              "calls_above_1.15_median": int(sum(x > 1.15 * t_med for x in t_host)),
-                              "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None)}
-        link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
-        out["host_link_bytes_per_pair"] = {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}
 
     # ---- the text path: what mz_multiz / mz_roast run every merge through.  N = 1 only.
     if rank == 0 and world == 1 and not args.no_host and not args.no_pre:
@@ -772,10 +851,9 @@ def main():
         out["parity"] = (f"ok: {len(idx)} sampled pairs x {len(workspaces)} workspaces bit-identical (OM + merged columns) "
                          f"to the CPU {cpu['kind']}" + ("; the host path's merged columns too" if host_hash is not None else ""))
         out["vs_cpu"] = {"value_over_measured": round(out["value"] / cpu["value"], 1),
-                         "value_over_socket_linear": round(out["value"] / cpu["socket_linear"], 1)}
-        if "value_host" in out:
-            out["vs_cpu"]["value_host_over_measured"] = round(out["value_host"] / cpu["value"], 1)
-            out["vs_cpu"]["value_host_over_socket_linear"] = round(out["value_host"] / cpu["socket_linear"], 1)
+                         "value_over_socket_linear": round(out["value"] / cpu["socket_linear"], 1),
+                         "value_resident_over_measured": round(out["value_resident"] / cpu["value"], 1),
+                         "value_resident_over_socket_linear": round(out["value_resident"] / cpu["socket_linear"], 1)}
 
     if rank == 0:
         print(json.dumps(out))

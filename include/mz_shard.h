@@ -79,6 +79,34 @@ int mz_shard_totals(mz_comm *comm, const mz_shard *shard, int64_t *cells, int64_
 /* bytes this rank sent and received in its scatters / gathers so far (the root's are the exchange's totals) */
 void mz_shard_traffic(int64_t *sent, int64_t *received);
 
+/* ---------------------------------------------------------------- the same exchange in CHUNKS that overlap (round 6)
+ *
+ * scatter / align / gather above are three phases, each waiting for the one before on every rank.  mz_shard_run() is the whole
+ * exchange as one call on every rank: the root deals the list over ranks x chunks (the same rule: every chunk of every rank the
+ * same mix) and, step by step, packs chunk t+1 and assembles chunk t-3 on its host threads WHILE the transport moves chunk t down
+ * and chunk t-2's result images up (one group each for the headers and the payloads: with RCCL every peer's link at once) WHILE
+ * every rank's GPU aligns chunk t-1 of its share.  C chunks take C + 4 steps of max(host, link, GPU) instead of the three sums.
+ *
+ *   chunks     0: chosen from the list's size (about 4 Ki pairs a chunk and rank, at most 32; MZ_SHARD_CHUNKS overrides); the
+ *              root's value counts, the others learn it from the first header
+ *   align      NULL: the library's GPU path -- mz_link_plan + mz_link_finish where the chunk's image landed (a transport that moves
+ *              host memory: the image goes up and the result comes down inside the step).  Else the caller's: called once per
+ *              non-empty chunk of this rank's share with host copies of the image and its exception block; it hands the chunk's
+ *              result image over with mz_shard_chunk_result(handle, ...) before it returns 0 (the CPU tests put the oracle there)
+ *   times      (may be NULL) where this rank's time went; pairs / cells / failed: what this rank aligned
+ * Root: n, jobs, outs as for mz_shard_gather (outs released with mz_free_outs(), also after -1); the others: 0, NULL, NULL.
+ * Returns the pairs without a result on the root, 0 on the others, -1 on an error of this rank (mz_last_error()).  A chunk that
+ * fails on one rank's GPU travels as failed -- its pairs stay MZ_E_DEVICE on the root -- and the exchange runs to its end. */
+typedef struct mz_shard_times {
+    double pack_s, comm_s, align_s, assemble_s, wall_s;     /* sums over the steps (they overlap: wall_s is less than their sum) */
+    int chunks, steps;
+    int64_t pairs, cells, failed;
+} mz_shard_times;
+typedef int (*mz_shard_align_fn)(void *user, int chunk, const mz_link_desc *desc, const void *image, const void *exc, void *handle);
+int mz_shard_chunk_result(void *handle, const void *result, int64_t bytes);
+int mz_shard_run(mz_comm *comm, int root, int n, const mz_job *jobs, mz_out *outs, int chunks, mz_shard_align_fn align, void *user,
+                 mz_shard_times *times);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MZ_LIB_PATH") or os.path.join(HERE, "libmzamd.so")   
 CSRC = os.path.join(HERE, "csrc")
 
 MZ_STATUS = {0: "ok", 1: "termination", 2: "narrow", 3: "lb_mono", 4: "rb_mono", 5: "traceback", 6: "emit",
-             16: "rows", 17: "shape", 18: "range", 19: "workspace"}
+             16: "rows", 17: "shape", 18: "range", 19: "workspace", 20: "device"}
 
 
 def build(force: bool = False) -> str:
@@ -434,6 +434,55 @@ class Shard:
             f.argtypes = [C.c_void_p, C.c_void_p]
             f(self.comm.ptr, self.ptr)
             self.ptr = None
+
+
+class ShardTimes(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("pack_s", "comm_s", "align_s", "assemble_s", "wall_s")] + \
+               [("chunks", C.c_int), ("steps", C.c_int)] + [(k, C.c_int64) for k in ("pairs", "cells", "failed")]
+
+
+_ALIGN_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(LinkDesc), C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def shard_run(comm: Comm, root: int, jobs: Optional[np.ndarray] = None, chunks: int = 0, align=None):
+    """mz_shard_run(): the whole exchange of a list that exists on `root`, in chunks that overlap -- packed, moved, aligned and assembled
+    side by side (include/mz_shard.h).  Every rank calls; `jobs`: the root's list (JOB_DT records), None elsewhere.  `align`: None = the
+    library's GPU path; else a function (chunk, desc: int64[8], image: uint8[], exc: uint8[]) -> result image (uint8[]) that stands in
+    for it (the CPU tests: the oracle).  Returns (outs, failed, times): outs = OUT_DT records of the whole list in the jobs' order on
+    the root (release with free_outs()), None elsewhere; times = dict of this rank's mz_shard_times."""
+    L = lib()
+    is_root = comm.rank == root
+    jobs = np.ascontiguousarray(jobs) if is_root and jobs is not None else None
+    n = len(jobs) if jobs is not None else 0
+    outs = np.zeros(n, dtype=OUT_DT) if is_root else None
+    err = []
+
+    def c_align(_user, chunk, dptr, image, exc, handle):
+        try:
+            d = dptr.contents
+            desc = np.array([getattr(d, k) for k, _ in LinkDesc._fields_], dtype=np.int64)
+            view = lambda ptr, nb: np.ctypeslib.as_array((C.c_uint8 * nb).from_address(ptr)).copy() if nb else np.zeros(0, np.uint8)  # noqa: E731
+            res = np.ascontiguousarray(align(int(chunk), desc, view(image, int(d.image_bytes)), view(exc, int(d.exc_bytes))), dtype=np.uint8)
+            f = L.mz_shard_chunk_result
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+            return 0 if f(handle, res.ctypes.data, res.size) == 0 else -1
+        except Exception as e:                              # noqa: BLE001  (into the library's error return; re-raised below)
+            err.append(e)
+            return -1
+    cb = _ALIGN_T(c_align) if align is not None else C.cast(None, _ALIGN_T)
+    tm = ShardTimes()
+    f = L.mz_shard_run
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _ALIGN_T, C.c_void_p, C.POINTER(ShardTimes)]
+    rc = f(comm.ptr, root, n, jobs.ctypes.data if n else None, outs.ctypes.data if n else None, int(chunks), cb, None, C.byref(tm))
+    times = {k: getattr(tm, k) for k, _ in ShardTimes._fields_}
+    if rc < 0:
+        if is_root and n:                                    # (chunks assembled before the failure own their blocks)
+            free_outs(outs)
+        if err:
+            raise err[0]
+        _check(rc, "mz_shard_run")
+    return outs, (rc if is_root else 0), times
 
 
 def shard_traffic():

@@ -515,3 +515,411 @@ rdone:
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------ the exchange in chunks (round 6)
+ * mz_shard_scatter / _align / _gather above are three phases one after the other: the root packs EVERY share, then everybody
+ * aligns, then the root assembles everything -- scatter 0.14 s + align 0.08 s + gather 0.16 s for 60 000 pairs on two ranks, nothing
+ * hidden behind anything.  mz_shard_run() deals the list over ranks x chunks (the same snake, so every chunk of every
+ * rank is the same mix) and moves chunk by chunk; in step t, side by side:
+ *
+ *      the root's host threads   pack chunk t+1 of every rank's share (mz_link_pack), assemble chunk t-3's results (mz_link_assemble)
+ *      the transport             group 1: header of chunk t down, header of chunk t-2's result image up
+ *                                group 2: chunk t's image + exception block down, chunk t-2's result image up -- every peer's at once
+ *      every rank's GPU          aligns chunk t-1 of its share (mz_link_plan + mz_link_finish), the root's included
+ *
+ * so a run of C chunks takes C + 4 steps of max(pack + assemble, move, align) each instead of the sum of the three.  A rank's chunk
+ * may be empty (fewer pairs than ranks x chunks): its header says so and nothing else travels.  A rank whose GPU fails a chunk says
+ * so in that chunk's result header (-1 bytes): the root leaves those pairs MZ_E_DEVICE and the exchange runs to its end -- nobody
+ * is left waiting in a receive.  ("overlap chunked scatter with compute anyway"; the independent jobs are the tree
+ * drivers' per-node multiz runs, /root/reference/tba.c:177-255, auto_mz.c:101,113.) */
+#define RUN_SLOTS 4                        /* a chunk's buffers live from step c (received) to step c+3 (assembled) */
+#define RUN_HDR 12                         /* int64: the chunk's mz_link_desc (8), its pairs, chunks of the run, this chunk, a magic */
+#define RUN_MAGIC 0x6d7a5f72756eLL
+
+typedef struct rslot { void *p; size_t cap; } rslot;
+static int rslot_need(mz_comm *c, rslot *s, size_t need)
+{
+    if (s->p && s->cap >= need) return 0;
+    if (s->p) c->release(c, s->p);
+    s->cap = need + need / 4 + 256;                          /* (chunks of one run are about the same size: the first few allocate) */
+    s->p = c->alloc(c, s->cap);
+    if (!s->p) { s->cap = 0; return mzi_set_err("out of memory for a transport buffer of %zu bytes", need); }
+    return 0;
+}
+static void rslot_drop(mz_comm *c, rslot *s) { if (s && s->p) c->release(c, s->p); if (s) { s->p = NULL; s->cap = 0; } }
+
+typedef struct shard_run {
+    mz_comm *c;
+    int root, is_root, W, C;
+    /* this rank's chunk in slot c & 3: descriptor, pairs, image / exceptions / result where the transport can move them */
+    mz_link_desc desc[RUN_SLOTS];
+    int64_t cn[RUN_SLOTS], res_bytes[RUN_SLOTS];            /* res_bytes: -1 = the chunk failed here */
+    rslot img[RUN_SLOTS], exc[RUN_SLOTS], res[RUN_SLOTS], hdr_s, hdr_r;
+    /* the GPU side of a transport that moves host memory (the image goes up, the result comes down) */
+    void *d_img, *d_exc, *d_res; size_t d_img_cap, d_exc_cap, d_res_cap;
+    hipEvent_t ev0, ev1; int ev_ready, aligning;
+    /* the caller's align (CPU tests: the oracle), and what it hands back */
+    mz_shard_align_fn align; void *user;
+    void *cb_result; int64_t cb_bytes; int cb_set;
+    /* the root */
+    const mz_job *jobs; mz_out *outs; int n;
+    int *cnt, *start, *order;              /* bin b = r * C + c: the pairs order[start[b] .. start[b] + cnt[b]) of the list */
+    mz_job *jbuf; mz_out *obuf;
+    rslot *s_img, *s_exc, *s_hdr, *r_hdr;  /* per peer: send buffers [2 * W] (chunk parity), header buffers [W] */
+    rslot *r_res;                          /* per peer and slot [RUN_SLOTS * W]: its result images */
+    mz_link_desc *pdesc;                   /* [RUN_SLOTS * W]: the packed chunks' descriptors */
+    int64_t *rbytes;                       /* [RUN_SLOTS * W]: bytes of the result images (-1: failed there) */
+    int failed;
+    /* the root's host thread of a step */
+    pthread_t th; int th_on, w_step, w_rc; char w_err[500];
+    int64_t my_pairs, my_cells, my_failed;
+    double t_pack, t_comm, t_align, t_asm;
+    int rc; char err[500];                 /* the first error of this rank (the exchange still runs to its end) */
+} shard_run;
+
+static void run_note(shard_run *S) { if (!S->rc) { S->rc = -1; snprintf(S->err, sizeof S->err, "%s", mz_last_error()); } }
+
+int mz_shard_chunk_result(void *handle, const void *result, int64_t bytes)
+{
+    shard_run *S = (shard_run *)handle;
+    if (!S || !result || bytes < 0) return mzi_set_err("mz_shard_chunk_result: bad arguments");
+    free(S->cb_result);
+    S->cb_result = malloc((size_t)bytes + 1);
+    if (!S->cb_result) return mzi_set_err("out of memory");
+    memcpy(S->cb_result, result, (size_t)bytes);
+    S->cb_bytes = bytes; S->cb_set = 1;
+    return 0;
+}
+
+/* ---- the root's host side of step t: assemble chunk t-3, pack chunk t+1 */
+static int run_assemble(shard_run *S, int ch)
+{
+    mz_comm *c = S->c;
+    const int W = S->W, C = S->C, k = ch & (RUN_SLOTS - 1);
+    int r, p;
+    const double t0 = mzi_now_s();
+    for (r = 0; r < W; ++r) {
+        const int b = r * C + ch, cnt = S->cnt[b];
+        const int64_t bytes = r == S->root ? S->res_bytes[k] : S->rbytes[k * W + r];
+        void *host;
+        int f;
+        if (!cnt) continue;
+        if (bytes < 0) { S->failed += cnt; continue; }      /* (that rank's GPU failed the chunk: its pairs stay MZ_E_DEVICE) */
+        host = malloc((size_t)bytes + 1);
+        if (!host) return mzi_set_err("out of memory");
+        if (c->get(c, host, r == S->root ? S->res[k].p : S->r_res[k * W + r].p, (size_t)bytes)) { free(host); return -1; }
+        f = mz_link_assemble(cnt, S->jbuf + S->start[b], host, bytes, S->obuf + S->start[b]);
+        free(host);
+        if (f < 0) { char why[400]; snprintf(why, sizeof why, "%s", mz_last_error()); return mzi_set_err("rank %d's result image of chunk %d: %s", r, ch, why); }
+        S->failed += f;
+        for (p = 0; p < cnt; ++p) S->outs[S->order[S->start[b] + p]] = S->obuf[S->start[b] + p];
+    }
+    S->t_asm += mzi_now_s() - t0;
+    return 0;
+}
+
+static int run_pack(shard_run *S, int ch)
+{
+    mz_comm *c = S->c;
+    const int W = S->W, C = S->C, k = ch & (RUN_SLOTS - 1), par = ch & 1;
+    int r;
+    const double t0 = mzi_now_s();
+    for (r = 0; r < W; ++r) {
+        const int b = r * C + ch;
+        mz_link_desc *d = &S->pdesc[k * W + r];
+        void *img = NULL, *exc = NULL;
+        rslot *si = r == S->root ? &S->img[k] : &S->s_img[par * W + r], *se = r == S->root ? &S->exc[k] : &S->s_exc[par * W + r];
+        int bad;
+        if (mz_link_pack(S->cnt[b], S->jbuf + S->start[b], d, &img, &exc)) return -1;
+        bad = rslot_need(c, si, (size_t)d->image_bytes) || rslot_need(c, se, (size_t)d->exc_bytes) ||
+              (d->image_bytes && c->put(c, si->p, img, (size_t)d->image_bytes)) || (d->exc_bytes && c->put(c, se->p, exc, (size_t)d->exc_bytes));
+        mz_link_free(img); mz_link_free(exc);
+        if (bad) return -1;
+        if (r == S->root) { S->desc[k] = *d; S->cn[k] = S->cnt[b]; }
+    }
+    S->t_pack += mzi_now_s() - t0;
+    return 0;
+}
+
+static void *run_host_thread(void *arg)
+{
+    shard_run *S = (shard_run *)arg;
+    const int t = S->w_step;
+    S->w_rc = 0;
+    if (S->c->device_buffers) hipSetDevice(G.device);       /* (put / get are device copies with such a transport) */
+    if (t - 3 >= 0 && t - 3 < S->C && run_assemble(S, t - 3)) S->w_rc = -1;
+    if (!S->w_rc && t + 1 < S->C && run_pack(S, t + 1)) S->w_rc = -1;
+    if (S->w_rc) snprintf(S->w_err, sizeof S->w_err, "%s", mz_last_error());
+    return NULL;
+}
+
+/* ---- this rank's GPU: chunk ch of its share (slot k), started here, waited for in run_align_wait() */
+static int run_align_start(shard_run *S, int ch)
+{
+    mz_comm *c = S->c;
+    const int k = ch & (RUN_SLOTS - 1);
+    mz_link_desc *d = &S->desc[k];
+    S->aligning = 0; S->res_bytes[k] = 0;
+    if (!S->cn[k]) return 0;
+    S->my_pairs += S->cn[k];
+    if (S->align) {                                          /* the caller's: on host copies, waited for on the spot */
+        void *hi = malloc((size_t)d->image_bytes + 1), *he = malloc((size_t)d->exc_bytes + 1);
+        const double t0 = mzi_now_s();
+        int bad = !hi || !he || c->get(c, hi, S->img[k].p, (size_t)d->image_bytes) || (d->exc_bytes && c->get(c, he, S->exc[k].p, (size_t)d->exc_bytes));
+        if (!hi || !he) mzi_set_err("out of memory");
+        S->cb_set = 0;
+        if (!bad && S->align(S->user, ch, d, hi, he, S)) { bad = 1; mzi_set_err("the caller's align of chunk %d failed", ch); }
+        if (!bad && !S->cb_set) { bad = 1; mzi_set_err("the caller's align of chunk %d handed no result image over (mz_shard_chunk_result)", ch); }
+        if (!bad && S->cb_bytes < mzi_result_image_min((int)S->cn[k])) { bad = 1; mzi_set_err("the caller's align of chunk %d: %lld bytes cannot be the result image of %lld pairs", ch, (long long)S->cb_bytes, (long long)S->cn[k]); }
+        if (!bad) bad = rslot_need(c, &S->res[k], (size_t)S->cb_bytes) || c->put(c, S->res[k].p, S->cb_result, (size_t)S->cb_bytes);
+        free(hi); free(he);
+        S->t_align += mzi_now_s() - t0;
+        if (bad) { S->res_bytes[k] = -1; return -1; }
+        S->res_bytes[k] = S->cb_bytes;
+        return 0;
+    }
+    {
+        const void *di = S->img[k].p, *de = S->exc[k].p;
+        void *dr;
+        if (!S->ev_ready) { if (hipEventCreate(&S->ev0) != hipSuccess || hipEventCreate(&S->ev1) != hipSuccess) { S->res_bytes[k] = -1; return mzi_set_err("no HIP events"); } S->ev_ready = 1; }
+        if (!c->device_buffers) {                            /* the image arrived in host memory: up it goes */
+            if (S->d_img_cap < (size_t)d->image_bytes + 256) { if (S->d_img) hipFree(S->d_img); S->d_img = NULL; S->d_img_cap = (size_t)d->image_bytes * 5 / 4 + 512; if (hipMalloc(&S->d_img, S->d_img_cap) != hipSuccess) { S->d_img_cap = 0; S->res_bytes[k] = -1; return mzi_set_err("out of device memory for a chunk's image"); } }
+            if (S->d_exc_cap < (size_t)d->exc_bytes + 256) { if (S->d_exc) hipFree(S->d_exc); S->d_exc = NULL; S->d_exc_cap = (size_t)d->exc_bytes * 5 / 4 + 512; if (hipMalloc(&S->d_exc, S->d_exc_cap) != hipSuccess) { S->d_exc_cap = 0; S->res_bytes[k] = -1; return mzi_set_err("out of device memory for a chunk's exception block"); } }
+            if (hipMemcpy(S->d_img, di, (size_t)d->image_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                (d->exc_bytes && hipMemcpy(S->d_exc, de, (size_t)d->exc_bytes, hipMemcpyHostToDevice) != hipSuccess)) { S->res_bytes[k] = -1; return mzi_set_err("mz_shard_run: a chunk's image did not reach the GPU"); }
+            di = S->d_img; de = S->d_exc;
+        }
+        if (mz_link_plan(d, di, de, NULL)) { S->res_bytes[k] = -1; return -1; }
+        if (c->device_buffers) { if (rslot_need(c, &S->res[k], (size_t)d->res_bytes)) { S->res_bytes[k] = -1; return -1; } dr = S->res[k].p; }
+        else {
+            if (S->d_res_cap < (size_t)d->res_bytes + 256) { if (S->d_res) hipFree(S->d_res); S->d_res = NULL; S->d_res_cap = (size_t)d->res_bytes * 5 / 4 + 512; if (hipMalloc(&S->d_res, S->d_res_cap) != hipSuccess) { S->d_res_cap = 0; S->res_bytes[k] = -1; return mzi_set_err("out of device memory for a chunk's result image"); } }
+            dr = S->d_res;
+        }
+        hipEventRecord(S->ev0, (hipStream_t)mz_stream());
+        if (mz_link_finish(d, dr, NULL)) { S->res_bytes[k] = -1; return -1; }
+        hipEventRecord(S->ev1, (hipStream_t)mz_stream());
+        S->aligning = 1;
+    }
+    return 0;
+}
+
+static int run_align_wait(shard_run *S, int ch)
+{
+    mz_comm *c = S->c;
+    const int k = ch & (RUN_SLOTS - 1);
+    mz_link_desc *d = &S->desc[k];
+    float ms = 0;
+    if (!S->aligning) return 0;
+    S->aligning = 0;
+    if (hipStreamSynchronize((hipStream_t)mz_stream()) != hipSuccess) { S->res_bytes[k] = -1; return mzi_set_err("mz_shard_run: the GPU did not come back from chunk %d", ch); }
+    if (hipEventElapsedTime(&ms, S->ev0, S->ev1) == hipSuccess) S->t_align += 1e-3 * ms;
+    if (!c->device_buffers) {                                /* ... and the result comes down, to where the transport can move it */
+        void *h = malloc((size_t)d->res_bytes + 1);
+        int bad = !h || hipMemcpy(h, S->d_res, (size_t)d->res_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+                  rslot_need(c, &S->res[k], (size_t)d->res_bytes) || c->put(c, S->res[k].p, h, (size_t)d->res_bytes);
+        free(h);
+        if (bad) { S->res_bytes[k] = -1; return mzi_set_err("mz_shard_run: chunk %d's result image did not come back from the GPU", ch); }
+    }
+    S->res_bytes[k] = d->res_bytes;
+    return 0;
+}
+
+/* cells and failures of this rank's own chunk (from its records, wherever they lie) */
+static void run_count(shard_run *S, int ch)
+{
+    mz_comm *c = S->c;
+    const int k = ch & (RUN_SLOTS - 1);
+    const int64_t n = S->cn[k];
+    mz_res_rec *rec;
+    int64_t p;
+    if (!n) return;
+    if (S->res_bytes[k] < 0) { S->my_failed += n; return; }
+    rec = (mz_res_rec *)malloc(sizeof *rec * (size_t)n);
+    if (!rec) return;
+    if (c->get(c, rec, (const char *)S->res[k].p + 64, sizeof *rec * (size_t)n) == 0)
+        for (p = 0; p < n; ++p) { S->my_cells += rec[p].cells; S->my_failed += rec[p].status != MZ_OK; }
+    free(rec);
+}
+
+/* ---- the transport's two groups of step t */
+static int run_comm(shard_run *S, int t)
+{
+    mz_comm *c = S->c;
+    const int W = S->W, root = S->root;
+    int64_t hdr[RUN_HDR], rh[2];
+    int r;
+    const double t0 = mzi_now_s();
+    if (S->is_root) {
+        const int C = S->C, down = t < C, up = t - 2 >= 0 && t - 2 < C, kd = t & (RUN_SLOTS - 1), ku = (t - 2) & (RUN_SLOTS - 1), par = t & 1;
+        if (W == 1 || (!down && !up)) return 0;
+        for (r = 0; r < W && down; ++r) {                   /* group 1: chunk t's header down, chunk t-2's result header up */
+            if (r == root) continue;
+            memcpy(hdr, &S->pdesc[kd * W + r], 8 * sizeof(int64_t));
+            hdr[8] = S->cnt[r * C + t]; hdr[9] = C; hdr[10] = t; hdr[11] = RUN_MAGIC;
+            if (rslot_need(c, &S->s_hdr[r], sizeof hdr) || c->put(c, S->s_hdr[r].p, hdr, sizeof hdr)) return -1;
+        }
+        for (r = 0; r < W && up; ++r) if (r != root && rslot_need(c, &S->r_hdr[r], sizeof rh)) return -1;
+        if (c->group_start(c)) return -1;
+        for (r = 0; r < W; ++r) {
+            if (r == root) continue;
+            if (down && c->send(c, S->s_hdr[r].p, sizeof hdr, r)) return -1;
+            if (up && c->recv(c, S->r_hdr[r].p, sizeof rh, r)) return -1;
+        }
+        if (c->group_end(c)) return -1;
+        for (r = 0; r < W && up; ++r) {
+            const int64_t cnt = S->cnt[r * C + (t - 2)];
+            if (r == root) continue;
+            if (c->get(c, rh, S->r_hdr[r].p, sizeof rh)) return -1;
+            if (rh[0] != cnt) return mzi_set_err("mz_shard_run: rank %d answers for %lld pairs of chunk %d, it was given %lld", r, (long long)rh[0], t - 2, (long long)cnt);
+            if (rh[1] >= 0 && cnt && rh[1] < mzi_result_image_min((int)cnt)) return mzi_set_err("mz_shard_run: rank %d sends a result image of %lld bytes for the %lld pairs of chunk %d (their records alone take %lld)", r, (long long)rh[1], (long long)cnt, t - 2, (long long)mzi_result_image_min((int)cnt));
+            S->rbytes[ku * W + r] = cnt ? rh[1] : 0;
+            if (rh[1] > 0 && rslot_need(c, &S->r_res[ku * W + r], (size_t)rh[1])) return -1;
+            RECEIVED(sizeof rh);
+        }
+        if (c->group_start(c)) return -1;                    /* group 2: the images down, the result images up -- every peer's at once */
+        for (r = 0; r < W; ++r) {
+            const mz_link_desc *d = &S->pdesc[kd * W + r];
+            if (r == root) continue;
+            if (down) {
+                if (d->image_bytes && c->send(c, S->s_img[par * W + r].p, (size_t)d->image_bytes, r)) return -1;
+                if (d->exc_bytes && c->send(c, S->s_exc[par * W + r].p, (size_t)d->exc_bytes, r)) return -1;
+                SENT((int64_t)sizeof hdr + d->image_bytes + d->exc_bytes);
+            }
+            if (up && S->rbytes[ku * W + r] > 0) { if (c->recv(c, S->r_res[ku * W + r].p, (size_t)S->rbytes[ku * W + r], r)) return -1; RECEIVED(S->rbytes[ku * W + r]); }
+        }
+        if (c->group_end(c)) return -1;
+    } else {
+        const int down = S->C == 0 || t < S->C, up = S->C > 0 && t - 2 >= 0 && t - 2 < S->C, kd = t & (RUN_SLOTS - 1), ku = (t - 2) & (RUN_SLOTS - 1);
+        if (!down && !up) return 0;
+        if ((down && rslot_need(c, &S->hdr_r, sizeof hdr)) || (up && rslot_need(c, &S->hdr_s, sizeof rh))) return -1;
+        if (up) { rh[0] = S->cn[ku]; rh[1] = S->cn[ku] ? S->res_bytes[ku] : 0; if (c->put(c, S->hdr_s.p, rh, sizeof rh)) return -1; }
+        if (c->group_start(c)) return -1;
+        if (down && c->recv(c, S->hdr_r.p, sizeof hdr, root)) return -1;
+        if (up && c->send(c, S->hdr_s.p, sizeof rh, root)) return -1;
+        if (c->group_end(c)) return -1;
+        if (up) SENT(sizeof rh);
+        if (down) {
+            if (c->get(c, hdr, S->hdr_r.p, sizeof hdr)) return -1;
+            memcpy(&S->desc[kd], hdr, 8 * sizeof(int64_t));
+            S->cn[kd] = hdr[8];
+            if (hdr[11] != RUN_MAGIC || hdr[10] != t || hdr[9] < 1 || (S->C && hdr[9] != S->C) || S->cn[kd] < 0 || S->cn[kd] != S->desc[kd].n ||
+                S->desc[kd].image_bytes < 0 || S->desc[kd].exc_bytes < 0)
+                return mzi_set_err("mz_shard_run: rank %d got a header of chunk %d that is none", c->rank, t);
+            S->C = (int)hdr[9];
+            if (rslot_need(c, &S->img[kd], (size_t)S->desc[kd].image_bytes) || rslot_need(c, &S->exc[kd], (size_t)S->desc[kd].exc_bytes)) return -1;
+        }
+        if (c->group_start(c)) return -1;
+        if (down) {
+            if (S->desc[kd].image_bytes && c->recv(c, S->img[kd].p, (size_t)S->desc[kd].image_bytes, root)) return -1;
+            if (S->desc[kd].exc_bytes && c->recv(c, S->exc[kd].p, (size_t)S->desc[kd].exc_bytes, root)) return -1;
+            RECEIVED((int64_t)sizeof hdr + S->desc[kd].image_bytes + S->desc[kd].exc_bytes);
+        }
+        if (up && S->cn[ku] && S->res_bytes[ku] > 0) { if (c->send(c, S->res[ku].p, (size_t)S->res_bytes[ku], root)) return -1; SENT(S->res_bytes[ku]); }
+        if (c->group_end(c)) return -1;
+    }
+    S->t_comm += mzi_now_s() - t0;
+    return 0;
+}
+
+static int run_chunks_for(int share)
+{
+    static int v = -1;
+    int C;
+    if (v < 0) { const char *e = getenv("MZ_SHARD_CHUNKS"); v = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (v) return v > 64 ? 64 : v;
+    C = (share + 2047) / 4096;                               /* chunks of about 4 Ki pairs: a full round of DP waves and more */
+    return C < 1 ? 1 : C > 32 ? 32 : C;
+}
+
+int mz_shard_run(mz_comm *c, int root, int n, const mz_job *jobs, mz_out *outs, int chunks, mz_shard_align_fn align, void *user, mz_shard_times *times)
+{
+    shard_run *S;
+    int t, r, p, rc;
+    const double t_start = mzi_now_s();
+    if (times) memset(times, 0, sizeof *times);
+    if (!c || root < 0 || root >= c->size || chunks < 0 || chunks > 64 || (c->rank == root && (n < 0 || (n && (!jobs || !outs)))))
+        return mzi_set_err("mz_shard_run: bad arguments");
+    S = (shard_run *)calloc(1, sizeof *S);
+    if (!S) return mzi_set_err("out of memory");
+    S->c = c; S->root = root; S->is_root = c->rank == root; S->W = c->size; S->align = align; S->user = user;
+    if (!align && !c->device_buffers) {                      /* (the GPU is this rank's own business: started before the first chunk is waited for) */
+        pthread_mutex_lock(&g_big);
+        if (mzi_ensure_init()) { pthread_mutex_unlock(&g_big); free(S); return -1; }
+        pthread_mutex_unlock(&g_big);
+    }
+    if (S->is_root) {
+        const int W = S->W;
+        int *owner, *where;
+        double *wt;
+        S->C = chunks ? chunks : run_chunks_for((n + W - 1) / W);
+        S->jobs = jobs; S->outs = outs; S->n = n;
+        owner = (int *)malloc(((size_t)n + 1) * sizeof *owner); where = (int *)malloc(((size_t)n + 1) * sizeof *where);
+        wt = (double *)calloc((size_t)n + 1, sizeof *wt);
+        S->cnt = (int *)calloc((size_t)W * S->C, sizeof *S->cnt); S->start = (int *)calloc((size_t)W * S->C, sizeof *S->start);
+        S->order = (int *)malloc(((size_t)n + 1) * sizeof *S->order); S->jbuf = (mz_job *)malloc(((size_t)n + 1) * sizeof *S->jbuf);
+        S->obuf = (mz_out *)malloc(((size_t)n + 1) * sizeof *S->obuf);
+        S->s_img = (rslot *)calloc(2 * (size_t)W, sizeof(rslot)); S->s_exc = (rslot *)calloc(2 * (size_t)W, sizeof(rslot));
+        S->s_hdr = (rslot *)calloc((size_t)W, sizeof(rslot)); S->r_hdr = (rslot *)calloc((size_t)W, sizeof(rslot));
+        S->r_res = (rslot *)calloc(RUN_SLOTS * (size_t)W, sizeof(rslot));
+        S->pdesc = (mz_link_desc *)calloc(RUN_SLOTS * (size_t)W, sizeof *S->pdesc); S->rbytes = (int64_t *)calloc(RUN_SLOTS * (size_t)W, sizeof *S->rbytes);
+        if (!owner || !where || !wt || !S->cnt || !S->start || !S->order || !S->jbuf || !S->obuf || !S->s_img || !S->s_exc || !S->s_hdr || !S->r_hdr || !S->r_res || !S->pdesc || !S->rbytes) {
+            free(owner); free(where); free(wt); mzi_set_err("out of memory"); run_note(S); goto out;
+        }
+        for (p = 0; p < n; ++p) wt[p] = shard_weight(&jobs[p]);
+        /* ranks x chunks bins in the snake's order c * W + r -- the heaviest pairs go round the RANKS first -- kept as b = r * C + c */
+        {
+            int *cnt2 = (int *)calloc((size_t)W * S->C, sizeof *cnt2), *start2 = (int *)calloc((size_t)W * S->C, sizeof *start2);
+            int bad = !cnt2 || !start2 || mzi_deal_snake(n, wt, W * S->C, owner, where, cnt2, start2), b, pos = 0;
+            if (!bad) {
+                for (r = 0; r < W; ++r) for (t = 0; t < S->C; ++t) { b = r * S->C + t; S->cnt[b] = cnt2[t * W + r]; S->start[b] = pos; pos += S->cnt[b]; }
+                for (p = 0; p < n; ++p) {
+                    const int sb = owner[p], rr = sb % W, cc = sb / W, at = S->start[rr * S->C + cc] + (where[p] - start2[sb]);
+                    S->jbuf[at] = jobs[p]; S->order[at] = p;
+                }
+            } else if (!cnt2 || !start2) mzi_set_err("out of memory");
+            free(cnt2); free(start2);
+            if (bad) { free(owner); free(where); free(wt); run_note(S); goto out; }
+        }
+        free(owner); free(where); free(wt);
+        for (p = 0; p < n; ++p) { outs[p].status = MZ_E_DEVICE; outs[p].badrow = -1; outs[p].OM = 0; outs[p].cols = NULL; outs[p].block = NULL; outs[p].score[0] = outs[p].score[1] = outs[p].score[2] = 0; }
+        if (run_pack(S, 0)) { run_note(S); goto out; }       /* (the first chunk: nothing to hide it behind) */
+    }
+    /* the steps.  An error on this rank is noted and the exchange goes on where it can (a failed chunk travels as such); only a
+     * transport that fails ends it -- there is nothing to go on with */
+    for (t = 0; S->C == 0 || t < S->C + 4; ++t) {
+        if (S->is_root) {
+            S->w_step = t; S->th_on = pthread_create(&S->th, NULL, run_host_thread, S) == 0;
+            if (!S->th_on) run_host_thread(S);
+        }
+        if (t - 1 >= 0 && t - 1 < S->C && run_align_start(S, t - 1)) run_note(S);
+        rc = run_comm(S, t);
+        if (S->is_root) {
+            if (S->th_on) pthread_join(S->th, NULL);
+            S->th_on = 0;
+            if (S->w_rc) { mzi_set_err("%s", S->w_err); run_note(S); }
+        }
+        if (rc) { run_note(S); break; }
+        if (t - 1 >= 0 && t - 1 < S->C) { if (run_align_wait(S, t - 1)) run_note(S); run_count(S, t - 1); }
+    }
+out:
+    if (S->aligning) hipStreamSynchronize((hipStream_t)mz_stream());
+    for (t = 0; t < RUN_SLOTS; ++t) { rslot_drop(c, &S->img[t]); rslot_drop(c, &S->exc[t]); rslot_drop(c, &S->res[t]); }
+    rslot_drop(c, &S->hdr_s); rslot_drop(c, &S->hdr_r);
+    for (r = 0; S->s_img && r < 2 * S->W; ++r) { rslot_drop(c, &S->s_img[r]); if (S->s_exc) rslot_drop(c, &S->s_exc[r]); }
+    for (r = 0; S->s_hdr && r < S->W; ++r) { rslot_drop(c, &S->s_hdr[r]); if (S->r_hdr) rslot_drop(c, &S->r_hdr[r]); }
+    for (r = 0; S->r_res && r < RUN_SLOTS * S->W; ++r) rslot_drop(c, &S->r_res[r]);
+    if (S->d_img) hipFree(S->d_img);
+    if (S->d_exc) hipFree(S->d_exc);
+    if (S->d_res) hipFree(S->d_res);
+    if (S->ev_ready) { hipEventDestroy(S->ev0); hipEventDestroy(S->ev1); }
+    if (times) {
+        times->chunks = S->C; times->steps = S->C + 4; times->pack_s = S->t_pack; times->comm_s = S->t_comm; times->align_s = S->t_align; times->assemble_s = S->t_asm;
+        times->wall_s = mzi_now_s() - t_start; times->pairs = S->my_pairs; times->cells = S->my_cells; times->failed = S->my_failed;
+    }
+    rc = S->rc ? -1 : S->is_root ? S->failed : 0;
+    if (S->rc) mzi_set_err("%s", S->err);
+    free(S->cnt); free(S->start); free(S->order); free(S->jbuf); free(S->obuf); free(S->s_img); free(S->s_exc); free(S->s_hdr); free(S->r_hdr);
+    free(S->r_res); free(S->pdesc); free(S->rbytes); free(S->cb_result);
+    free(S);
+    return rc;
+}

@@ -408,6 +408,30 @@ def run_sharded_link(batch: Optional[Dict[str, np.ndarray]], compute: Callable =
     return out, totals
 
 
+def run_sharded_chunks(batch: Optional[Dict[str, np.ndarray]], align: Optional[Callable] = None, src: int = 0, device="cpu", group=None,
+                       chunks: int = 0):
+    """The exchange in chunks that overlap (mz_shard_run, include/mz_shard.h): the root packs chunk t+1 and assembles chunk t-3 while
+    the transport moves chunk t down and chunk t-2's results up and every rank's GPU aligns chunk t-1.  `align`: None = the library's
+    GPU path (mz_link_plan / mz_link_finish; a "gloo" group's host buffers go up and come down inside the step); else a function
+    (chunk, desc, image, exc) -> result image (the CPU tests: the oracle).  Root gets (ShardedOuts, totals, times); others (None, totals,
+    times); totals = (pairs, cells, failed) over all ranks, times = this rank's mz_shard_times as a dict."""
+    import torch.distributed as dist
+    from . import api
+    rank = dist.get_rank(group)
+    comm = comm_for(group, device)
+    s0, r0 = api.shard_traffic()
+    jobs = api.host_jobs(batch)[0] if rank == src else None
+    outs, _failed, times = api.shard_run(comm, src, jobs, chunks=chunks, align=align)
+    s1, r1 = api.shard_traffic()
+    res = None
+    if rank == src:
+        last_exchange.update(pairs=int(len(batch["K"])), up_bytes=int(s1 - s0), down_bytes=int(r1 - r0))
+        res = ShardedOuts(outs, batch["K"].astype(np.int64) + batch["L"].astype(np.int64))
+        res._jobs = jobs                                         # (the merged columns were assembled from these arrays' memory)
+    totals = close_batch(int(times["pairs"]), int(times["cells"]), int(times["failed"]), device, group)
+    return res, totals, times
+
+
 def run_sharded(batch: Optional[Dict[str, np.ndarray]], compute: Callable = device_compute, src: int = 0, device="cpu", group=None):
     """scatter -> compute(shard) -> gather.  compute takes the shard (dict of torch tensors on `device`) and returns
     dict(om, status, off, out: torch tensors; cells, failed: ints).  Root gets (Sharded, totals); others (None, totals)."""

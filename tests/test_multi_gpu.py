@@ -105,6 +105,8 @@ def test_bench_two_ranks_on_one_gpu(extra):
     line = [l for l in p.stdout.decode().split("\n") if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == 6000 and d["value"] > 0
+    # the headline is the transfer-inclusive rate of K = --steps calls of mz_yama_batch() on every rank; the resident pipeline's rate beside it
+    assert d["steps"] == 3 and len(d["host_ms_all"]) == 3 and d["value_resident"] > d["value"] and "mz_yama_batch" in d["value_is"]
     # the self-verifying part of a multi-GPU line: which device every rank held, every rank's own rate, the spread
     assert len(d["devices"]) == 2 and d["distinct_devices"] == 1 and "gloo" in d["backend"]      # (both ranks on GPU 0 here)
     assert len(d["per_rank_gcups"]) == 2 and min(d["per_rank_gcups"]) > 0 and d["rank_max_over_min"] >= 1.0

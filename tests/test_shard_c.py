@@ -188,3 +188,96 @@ def test_more_ranks_than_gpus_fit_a_node():
         sh.free()
     for c in comms:
         c.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------- the exchange in chunks
+# mz_shard_run(): packing, moving, aligning and assembling of different chunks side by side (include/mz_shard.h).  Every rank is a
+# thread here (the steps of different ranks wait for each other's messages); the oracle stands in for the GPU through the align hook.
+
+def _oracle_align(chunk, desc, image, exc):
+    return linkfmt.oracle_result_image(desc, image, exc)[0]
+
+
+def _run_as_threads(world, root, jobs, chunks, align_of=lambda r: _oracle_align):
+    comms = api.Comm.loopback(world)
+    out, errors = {}, {}
+
+    def rank(r):
+        try:
+            out[r] = api.shard_run(comms[r], root, jobs if r == root else None, chunks=chunks, align=align_of(r))
+        except Exception as e:                                    # noqa: BLE001
+            errors[r] = e
+    ts = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    for c in comms:
+        c.free()
+    return out, errors
+
+
+@pytest.mark.parametrize("world,n,chunks,root", [(3, 41, 4, 1), (2, 1, 3, 0), (1, 9, 2, 0), (4, 3, 2, 3), (2, 30, 1, 0), (20, 50, 3, 0), (3, 0, 2, 0)])
+def test_chunked_exchange_ranks_as_threads(world, n, chunks, root):
+    """every (rank, chunk) bin gets the same mix or nothing: with fewer pairs than bins most chunks are EMPTY (a header, no image, no
+    result); 20 ranks: more than one process has GPUs; one chunk: the pipeline's shortest form; no pairs at all"""
+    batch, pairs = _batch(5, n) if n else (None, [])
+    jobs = api.host_jobs(batch)[0] if n else np.zeros(0, dtype=api.JOB_DT)
+    s0, r0 = api.shard_traffic()
+    out, errors = _run_as_threads(world, root, jobs, chunks)
+    assert not errors, errors
+    outs, failed, times = out[root]
+    assert failed == 0 and times["chunks"] == chunks and times["steps"] == chunks + 4
+    assert sum(out[r][2]["pairs"] for r in range(world)) == n                 # every pair was aligned on exactly one rank
+    assert sum(out[r][2]["cells"] for r in range(world)) == sum(mo.band_cells(p[2], p[3]) for p in pairs)
+    if n:
+        assert max(out[r][2]["pairs"] for r in range(world)) <= -(-n // world) + chunks       # the snake's balance, chunk by chunk
+        _check_root(outs, failed, batch, pairs, [np.arange(n)])
+        api.free_outs(outs)
+    s1, r1 = api.shard_traffic()
+    assert world == 1 or n == 0 or (s1 - s0 == r1 - r0 and s1 > s0)              # what was sent arrived, byte for byte
+    assert all(out[r][0] is None for r in range(world) if r != root)
+
+
+def test_chunked_exchange_a_chunk_that_fails_on_one_rank():
+    """a rank whose align fails for one chunk says so in that chunk's result header: the root leaves exactly those pairs without a result
+    (MZ_E_DEVICE), everybody's exchange runs to its end, and the rank that failed reports its error"""
+    world, n, chunks, root = 3, 36, 3, 0
+    batch, pairs = _batch(9, n)
+    jobs, _ = api.host_jobs(batch)
+    seen = []
+
+    def bad_align(chunk, desc, image, exc):
+        seen.append((chunk, int(desc[0])))
+        if chunk == 1:
+            raise ValueError("this GPU is on fire")
+        return _oracle_align(chunk, desc, image, exc)
+    out, errors = _run_as_threads(world, root, jobs, chunks, align_of=lambda r: bad_align if r == 2 else _oracle_align)
+    assert list(errors) == [2] and "on fire" in repr(errors[2])
+    outs, failed, times = out[root]
+    lost = dict(seen)[1]
+    assert failed == lost > 0 and int((outs["status"] != 0).sum()) == lost
+    W = batch["K"].astype(np.int64) + batch["L"]
+    for i, (A, B, LB, RB) in enumerate(pairs):
+        if outs["status"][i] == 0:
+            want = mo.yama(A, B, LB, RB)
+            got = np.ctypeslib.as_array((api.C.c_uint8 * (int(outs["OM"][i]) * int(W[i]))).from_address(int(outs["cols"][i])))
+            assert int(outs["OM"][i]) == want.OM and np.array_equal(got, want.cols.ravel()), i
+        else:
+            assert api.MZ_STATUS[int(outs["status"][i])] == "device" and outs["cols"][i] == 0
+    api.free_outs(outs)
+
+
+def test_chunked_exchange_refuses_a_peers_short_result_image():
+    world, n, chunks = 2, 12, 2
+    batch, pairs = _batch(4, n)
+    jobs, _ = api.host_jobs(batch)
+
+    def short_align(chunk, desc, image, exc):
+        return _oracle_align(chunk, desc, image, exc)[: 64 + 8]
+    out, errors = _run_as_threads(world, 0, jobs, chunks, align_of=lambda r: short_align if r == 1 else _oracle_align)
+    # the peer's own library refuses to take the image from its align (and sends the chunk as failed); nothing short reaches the root
+    assert list(errors) == [1] and "cannot be the result image" in repr(errors[1])
+    outs, failed, _ = out[0]
+    assert failed == int((outs["status"] != 0).sum()) > 0
+    api.free_outs(outs)

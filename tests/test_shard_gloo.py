@@ -99,18 +99,49 @@ def _link_worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
+def _chunk_worker(rank, world, port, n, q):
+    """the exchange in chunks (shard.run_sharded_chunks -> mz_shard_run): a world of processes over gloo, three chunks a rank -- with
+    n < ranks x chunks most of them empty --, the oracle behind the align hook"""
+    import torch.distributed as dist
+    import linkfmt
+    from multiz_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, pairs = _batch(11, n) if rank == 0 else (None, None)
+        sh, totals, times = shard.run_sharded_chunks(batch, lambda ch, desc, image, exc: linkfmt.oracle_result_image(desc, image, exc)[0], chunks=3)
+        ok = times["chunks"] == 3 and times["steps"] == 7
+        if rank == 0:
+            ok &= bool((sh.status == 0).all())
+            for i, (A, B, LB, RB) in enumerate(pairs):
+                want = mo.yama(A, B, LB, RB)
+                ok &= int(sh.om[i]) == want.OM and np.array_equal(sh.cols(i), want.cols.ravel())
+            cells = sum(mo.band_cells(p[2], p[3]) for p in pairs)
+            merged = int(sum(int(sh.om[i]) * (p[0].shape[1] + p[1].shape[1]) for i, p in enumerate(pairs)))
+            ex = dict(shard.last_exchange)
+            ok &= ex["pairs"] == n and ex["down_bytes"] < merged + 200 * n + 1024 * world * 3
+            sh.release()
+            q.put((ok, totals, (n, cells, 0)))
+        else:
+            assert ok
+        shard.drop_comms()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-@pytest.mark.parametrize("world,n,worker", [(2, 23, "pools"), (3, 10, "pools"), (2, 1, "pools"), (2, 23, "link"), (3, 10, "link"), (2, 1, "link")])
+@pytest.mark.parametrize("world,n,worker", [(2, 23, "pools"), (3, 10, "pools"), (2, 1, "pools"), (2, 23, "link"), (3, 10, "link"), (2, 1, "link"),
+                                            (2, 23, "chunks"), (3, 10, "chunks"), (2, 1, "chunks")])
 def test_scatter_compute_gather(world, n, worker):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker if worker == "pools" else _link_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target={"pools": _worker, "link": _link_worker, "chunks": _chunk_worker}[worker], args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue as _q

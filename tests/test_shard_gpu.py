@@ -77,18 +77,53 @@ def _link_worker(rank, world, port, n, cfg, q):
         dist.destroy_process_group()
 
 
+def _chunk_worker(rank, world, port, n, cfg, q):
+    """the exchange in chunks (mz_shard_run) with the PRODUCT's align: every chunk's image goes up to the rank's GPU, mz_link_plan /
+    mz_link_finish run on it while the transport moves the next chunk and the root packs the one after and assembles the one before"""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import multiz_amd as mz
+        from multiz_amd import shard, synth
+        from oracle import mzoracle as mo
+        mz.api.init(0)
+        batch = None
+        if rank == 0:
+            c = synth.CONFIGS[cfg]
+            batch = synth.make_batch(n, c["K"], c["L"], c["mlo"], c["mhi"], c["radius"], first_pair=77, indel=c.get("indel", 0))
+        sh, totals, times = shard.run_sharded_chunks(batch, None, chunks=5)
+        assert times["chunks"] == 5 and times["pairs"] > 0 and times["align_s"] > 0
+        if rank == 0:
+            om, hs, cells, bad = mo.yama_batch(batch, variant=1, threads=8)
+            ok = bad == 0 and bool((sh.status == 0).all())
+            mism = 0
+            for i in range(n):
+                m_ = int(sh.om[i])
+                h = mo.fnv1a_np(sh.cols(i), mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8)))
+                mism += (m_ != om[i]) or (h != int(hs[i]))
+            sh.release()
+            q.put((ok, mism, totals, (n, cells, 0)))
+        torch.cuda.synchronize()
+        shard.drop_comms()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-@pytest.mark.parametrize("cfg,n,worker", [("c4", 600, "pools"), ("c2", 300, "pools"), ("c4", 3000, "link"), ("c2i", 1500, "link")])
+@pytest.mark.parametrize("cfg,n,worker", [("c4", 600, "pools"), ("c2", 300, "pools"), ("c4", 3000, "link"), ("c2i", 1500, "link"),
+                                          ("c4", 3000, "chunks"), ("c2i", 1500, "chunks")])
 def test_scatter_device_compute_gather_two_ranks(cfg, n, worker):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker if worker == "pools" else _link_worker, args=(r, 2, port, n, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target={"pools": _worker, "link": _link_worker, "chunks": _chunk_worker}[worker], args=(r, 2, port, n, cfg, q)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _q
@@ -196,8 +231,16 @@ for i in range(n):
     assert m_ == om[i] and mo.fnv1a_np(got, mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
 api.free_outs(outs)
 sh.free()
+# ... and the same list through the exchange in chunks (mz_shard_run): six chunks, each aligned where the transport's device buffer lies
+outs, bad, times = api.shard_run(comm, 0, jobs, chunks=6)
+assert bad == 0 and times["chunks"] == 6 and times["pairs"] == n and times["cells"] == want_cells and times["failed"] == 0, times
+for i in range(n):
+    m_ = int(outs["OM"][i])
+    got = np.ctypeslib.as_array((api.C.c_uint8 * (m_ * int(W[i]))).from_address(int(outs["cols"][i])))
+    assert m_ == om[i] and mo.fnv1a_np(got, mo.fnv1a_np(np.array([m_], dtype=np.int32).view(np.uint8))) == int(hs[i]), i
+api.free_outs(outs)
 comm.free()
-print("rccl ok", api.shard_traffic())
+print("rccl ok", api.shard_traffic(), times)
 '''
 
 
