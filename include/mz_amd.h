@@ -69,7 +69,13 @@ enum {
                               kernels re-base their scores, and the guard-dropping kernels are only chosen where the
                               plan proves every reachable score stays above -2^29 */
     MZ_E_WORKSPACE = 19,   /* workspace too small for this batch (caller must re-plan) */
-    MZ_E_DEVICE = 20       /* not computed: a device error (or malloc failure) ended the call before this pair's result */
+    MZ_E_DEVICE = 20,      /* not computed: a device error (or malloc failure) ended the call before this pair's result */
+    MZ_E_SENTINEL = 21     /* the traceback left the band of a pair whose scores can fall below the reference's "unreachable" sentinel
+                              MININT = INT_MIN / 2 (mz_yama.c:29) -- K * L * (gap_open + max(gap_extend, max |ss|)) * (M + N + 2) >= 2^30: two
+                              blocks of 100+ rows EACH over ~700 mismatching columns.  Down there sentinel states win comparisons in the
+                              reference too; its walk then steps onto cells outside the band, reads whatever bytes of its one traceback array
+                              lie there (mz_yama.c:98,277) and still arrives.  That is not reproduced: the pair is reported, never mis-aligned.
+                              (The same walk failure on a pair whose scores cannot get there stays MZ_E_TRACEBACK: the reference's own error.) */
 };
 
 /* which DP kernel the plan picked for a pair:
@@ -142,7 +148,7 @@ typedef struct mz_dev_batch {
     int32_t *final3;       /* C,D,I at (M,N), 3 per pair           */
 } mz_dev_batch;
 
-enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2 };
+enum { MZ_WALK_AUTO = 0, MZ_WALK_RUNS = 1, MZ_WALK_CHASE = 2, MZ_WALK_REG = 3 };     /* REG: runs, the window in registers (beside DP kernels, thin blocks) */
 /* the choice the device would make, from the plan's totals (host copy) of an n-pair batch */
 int mz_walk_choice(int n, const int64_t *totals);
 /* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint; bits 8..15: the one with the most), from the plan's

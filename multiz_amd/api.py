@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MZ_LIB_PATH") or os.path.join(HERE, "libmzamd.so")   
 CSRC = os.path.join(HERE, "csrc")
 
 MZ_STATUS = {0: "ok", 1: "termination", 2: "narrow", 3: "lb_mono", 4: "rb_mono", 5: "traceback", 6: "emit",
-             16: "rows", 17: "shape", 18: "range", 19: "workspace", 20: "device"}
+             16: "rows", 17: "shape", 18: "range", 19: "workspace", 20: "device", 21: "sentinel"}
 
 
 def build(force: bool = False) -> str:

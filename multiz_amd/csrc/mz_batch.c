@@ -49,7 +49,7 @@ typedef struct pack_ctx {
 
 typedef struct chunk {
     mz_ctx *X;
-    int set, n, index, lane;               /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk) */
+    int set, n, index, lane, wide;         /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk); wide: a call on four DP slots (its tail is the slot's own) */
     const mz_job *jobs;
     mz_out *outs;
     mz_dev_batch b;
@@ -162,7 +162,7 @@ static int chunk_parts(int n)
 /* the chunk's streams (mz_ctx.h): front (staging block -> device, expansion, plan), DP, tail (walk, script packing, results -> host) */
 static hipStream_t chunk_front(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qf[c->index % c->X->nf]; }
 static hipStream_t chunk_dp(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qd[c->lane]; }
-static hipStream_t chunk_tail(const chunk *c) { return c->lane < 0 ? c->X->stream : c->X->qt[c->index % c->X->nt]; }
+static hipStream_t chunk_tail(const chunk *c) { return c->lane < 0 ? c->X->stream : c->wide ? c->X->qt[c->lane] : c->X->qt[c->index % c->X->nt]; }
 
 /* The calling thread: chunk `index` = the n jobs at `jobs`, laid out in buffer set `set`; its packing as a loop (*pack).
  * One pinned staging block: [K L M N](int32 x n) [offA offB offBand](int64 x n) [bandLen LB0 RB0](int32 x n) offC(int64 x n)
@@ -178,7 +178,8 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
     int p;
 
     c->t_cut0 = mzi_now_s();
-    c->X = X; c->set = set; c->index = index; c->lane = lane; c->n = n; c->jobs = jobs; c->outs = outs;
+    c->X = X; c->set = set; c->index = index; c->lane = lane & 0xff; c->wide = lane >= 0 && (lane >> 8); c->n = n; c->jobs = jobs; c->outs = outs;
+    if (lane < 0) c->lane = -1;
     c->where = NULL; c->ac = NULL; c->cells = 0; c->exc_bytes = 0; c->res_bytes = 0;
     for (p = 0; p < n; ++p) {
         const mz_job *j = &jobs[p];
@@ -499,7 +500,7 @@ static int g_last_hedged;                  /* pieces of the last call's packing 
 
 typedef struct ypipe {
     mz_ctx *X;
-    int n, up, max_pairs, threaded;
+    int n, up, max_pairs, threaded, slots;   /* slots: DP streams of this call (2; 4 for a call of few long pairs) */
     size_t max_bytes;
     const mz_job *jobs;
     mz_out *outs;
@@ -565,12 +566,13 @@ static int y_cut(void *self, int k, int set, mz_ajob *pack)
         ramp_n = 0;
         for (e = e ? e : "2,4"; *e && ramp_n < 8; ) { ramp8[ramp_n++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; }
     }
-    if (P->threaded && k < ramp_n && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) && ramp8[k] >= 1 && ramp8[k] < 8) shift8 = ramp8[k];
+    /* (not for a call on four DP slots: its chunks' DPs take one long pair's time each whatever their size, and all of them run side by side) */
+    if (P->threaded && P->slots <= 2 && k < ramp_n && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) && ramp8[k] >= 1 && ramp8[k] < 8) shift8 = ramp8[k];
     limit = (int)((long long)P->max_pairs * shift8 / 8);
     if (limit < MIN_CHUNK_PAIRS / 2) limit = MIN_CHUNK_PAIRS / 2;
     if (P->up >= P->n) return 0;
     m = next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes / 8 * (size_t)shift8);
-    if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? k % P->X->nq : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
     P->up += m;
     return 1;
 }
@@ -604,7 +606,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
 {
     ypipe *P;
     mz_flow *F;
-    size_t max_bytes = 0;
+    size_t max_bytes = 0, total_bytes = 0;
     int rc, s;
 
     if (hipSetDevice(X->device) != hipSuccess) return mzi_set_err("hipSetDevice(%d) failed", X->device);
@@ -626,6 +628,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     /* chunks by pairs AND by bytes: a call of few long pairs (BASELINE config 5: 1 000 pairs, 1.2 GB) is cut into as many
      * pieces as one of many short ones, at least 8 MB each and at most 1 GB */
     for (s = 0; s < n; ++s) max_bytes += job_bytes(&jobs[s]);
+    total_bytes = max_bytes;
     max_bytes = max_bytes / (size_t)chunk_parts(n) + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
@@ -635,6 +638,14 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     F->X = X; F->self = P; F->nstage = 3; F->threaded = P->threaded;
     F->cut = y_cut; F->stage[0] = y_send; F->stage[1] = y_launch; F->stage[2] = y_collect; F->finish = y_finish;
     if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }
+    P->slots = 2;
+    /* few long pairs (at most 4 096 pairs, cut by bytes into three chunks or more): every chunk's DP takes as long as its longest pair --
+     * milliseconds -- on a fraction of the GPU's SIMDs: four of them side by side (mz_flow.c: mzi_flow_wide; MZ_WIDE=0: two, as before) */
+    {
+        static int wide_on = -1;
+        if (wide_on < 0) { const char *e = getenv("MZ_WIDE"); wide_on = !(e && e[0] == '0'); }
+        if (P->threaded && wide_on && n <= 4096 && total_bytes / (size_t)n >= ((size_t)256 << 10) && mzi_flow_wide(X) == 0) P->slots = MZ_QS;      /* (long: a quarter of a megabyte of input a pair and more) */
+    }
     rc = mzi_flow_run(F);
     if (rc < 0) mzi_flow_sync(X);
     g_last_hedged = F->hedged;

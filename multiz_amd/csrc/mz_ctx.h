@@ -27,8 +27,8 @@ typedef struct gbuf { void *p; size_t cap; } gbuf;
 enum { MZ_PD_IN, MZ_PD_TXT, MZ_PD_COLS, MZ_PD_BAND, MZ_PD_SCR, MZ_PD_META, MZ_PD_OUT1, MZ_PD_OUT2, MZ_PD_A2, MZ_PD_BAND2, MZ_PD_PLAN2, MZ_PD_TB2,
        MZ_PD_SCRIPT2, MZ_PD_PREP2, MZ_PD_RES, MZ_PD_N };
 enum { MZ_PH_IN, MZ_PH_RES, MZ_PH_TOT2, MZ_PH_N };
-#define MZ_QS 2                            /* streams of one kind in the chunk pipelines at most */
-#define MZ_QALL 16                         /* ... and in all, fillers included (mz_flow.c creates them in rounds of four) */
+#define MZ_QS 4                            /* streams of one kind in the chunk pipelines at most (two; four for calls of few long pairs: mzi_flow_wide) */
+#define MZ_QALL 24                         /* ... and in all, fillers included (mz_flow.c creates them in rounds of four) */
 #define MZ_FLOW_STAGES 4                   /* stage threads of a chunk pipeline at most */
 #define MZ_WS_MAX 8                        /* workspaces remembered by mz_dev_run_async() */
 #define MZ_MAX_DEV 16
@@ -93,7 +93,7 @@ typedef struct mz_ctx {
      * WHICH hardware queue a stream gets matters (mz_flow.c: the queues of one pipe of the command processor hold each other up). */
     hipStream_t qf[MZ_QS], qd[MZ_QS], qt[MZ_QS], qc, qall[MZ_QALL];
     mz_dp_lanes qlane[MZ_QS];
-    int nq, nf, nt, nqall, lanes_made;     /* DP slots (chunk k: qd[k % nq]), front streams (qf[k % nf]), tail streams (qt[k % nt]); streams created; the lanes exist */
+    int nq, nf, nt, nqall, lanes_made, nq_wide;     /* DP slots (chunk k: qd[k % nq]), front streams (qf[k % nf]), tail streams (qt[k % nt]); streams created; the lanes exist */
     hipEvent_t bdone[MZ_SETS], bplan[MZ_SETS], bprep[MZ_SETS], bdp[MZ_SETS], bcopy[MZ_SETS];    /* the chunk's last kernel; its plan's totals; its prep records; its DP kernels; its staging block on the device */
     hipEvent_t btime[MZ_SETS][6];          /* MZ_TIMING=2: start, uploaded, planned, DP done, results packed, copied back */
     int btime_ready;
@@ -118,6 +118,7 @@ MZ_INTERNAL int mzi_host_reserve(gbuf *b, size_t need);
 MZ_INTERNAL int mzi_lazy_stream(hipStream_t *s);
 MZ_INTERNAL unsigned mzi_event_flags(void);              /* of the events nobody takes times from: no timing, release to the DEVICE (mz_host.c) */
 MZ_INTERNAL int mzi_flow_streams(mz_ctx *X);              /* mz_flow.c: the chunk streams and their lanes, on first use */
+MZ_INTERNAL int mzi_flow_wide(mz_ctx *X);                 /* ... DP and tail streams 2 and 3, for calls of few long pairs (four chunks' DPs side by side) */
 MZ_INTERNAL int mzi_flow_lanes(mz_ctx *X);                /* ... the DP streams' lanes, when a chunk with several kinds of pairs needs them */
 MZ_INTERNAL void mzi_flow_sync(mz_ctx *X);                /* ... all of them synchronised (after an error) */
 MZ_INTERNAL int mzi_ensure_init(void);

@@ -608,14 +608,27 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     // kernels/walk.inc) and is made on the device from the plan's totals: both kernels are launched and the one not
     // chosen returns at once.  MZ_WALK=wave|direct forces one (tests, measurements).
     static int force = -1;
-    if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : 0; }
+    if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : e[0] == 'r' ? 3 : 0; }
     const int hint = (force || !beside_dp || count <= 16384) ? 0 : b->walk_hint;
     const bool both = !force && beside_dp && count > 16384 && hint == MZ_WALK_AUTO;
-    if (force ? force == 1 : (both || hint != MZ_WALK_CHASE)) {
+    // Beside DP kernels the row-parallel pairs of a launch of at most 4 096 pairs, or of thin blocks (the caller's walk_hint: MZ_WALK_REG),
+    // take the walk whose window lies in registers (k_walk_reg, kernels/walk.inc: no LDS, 30 VGPRs, runs of at most 17-32 steps an
+    // iteration); k_walk_wave takes what is left, when the plan's totals say there is anything.  Measured, one mz_yama_batch() call, reg /
+    // LDS window: C3 4.9 / 5.45 ms, c2i 5.6 / 5.85, C2 8.42 / 8.42 -- and C4, whose paths run straight for 64 steps and more, 22 / 18: hence
+    // the rule.  MZ_WALK=reg: everywhere; MZ_WALK_REG=0: nowhere.
+    static int reg_on = -1;
+    if (reg_on < 0) { const char *e = getenv("MZ_WALK_REG"); reg_on = !(e && e[0] == '0'); }
+    const bool known = (b->dp_hint & MZ_DP_KNOWN) != 0;
+    const bool reg = force == 3 || (!force && reg_on && beside_dp && count <= 16384 && (count <= 4096 || b->walk_hint == MZ_WALK_REG) &&
+                                    (!known || (b->dp_hint & (MZ_DP_ROW | MZ_DP_ROWBIG))));
+    const bool rest = !reg || !known || (b->dp_hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG));
+    if (reg) hipLaunchKernelGGL(k_walk_reg, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
+    if ((force == 3 || !force) && reg ? rest : force ? force == 1 : (both || hint != MZ_WALK_CHASE)) {
+        const int pol = (both ? 1 : 0) | (reg ? 2 : 0);
         if (count <= 4096)      // a launch of few pairs: long ones as likely as not -- the variant that fetches its next window ahead
-            hipLaunchKernelGGL(k_walk_wave_ahead, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+            hipLaunchKernelGGL(k_walk_wave_ahead, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, pol);
         else
-            hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+            hipLaunchKernelGGL(k_walk_wave, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, pol);
     }
     if (force ? force == 2 : (both || hint == MZ_WALK_CHASE)) {
         const int waves = (count + WALK_LANES - 1) / WALK_LANES;
@@ -629,7 +642,8 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
 extern "C" int mz_walk_choice(int n, const int64_t *totals)
 {
     const long long ok = (long long)n - totals[3];
-    return (n > 16384 && MZ_ROWS_SUM(totals[11]) < 8 * (ok > 0 ? ok : 1)) ? MZ_WALK_CHASE : MZ_WALK_RUNS;
+    const bool thin = MZ_ROWS_SUM(totals[11]) < 8 * (ok > 0 ? ok : 1);       // fewer than 8 rows a pair: the paths turn every few steps
+    return (n > 16384 && thin) ? MZ_WALK_CHASE : thin ? MZ_WALK_REG : MZ_WALK_RUNS;
 }
 
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)

@@ -49,14 +49,47 @@ int mzi_flow_streams(mz_ctx *X)
     if (X->nq) return 0;
     { const char *e = getenv("MZ_TAILS"); nt = e && atoi(e) == 1 ? 1 : 2; }
     /* round 0: DP 0, DP 1, fronts, copies; round 1: tail 0, tail 1 (the lanes' rounds: mzi_flow_lanes) */
-    if (flow_new_stream(X, &X->qd[0]) || flow_new_stream(X, &X->qd[1]) || flow_new_stream(X, &X->qf[0]) || flow_new_stream(X, &X->qc) ||
-        flow_new_stream(X, &X->qt[0]) || flow_new_stream(X, nt > 1 ? &X->qt[1] : &filler)) return -1;
+    if (flow_new_stream(X, &X->qd[0]) || flow_new_stream(X, &X->qd[1]) || flow_new_stream(X, &X->qf[0]) || flow_new_stream(X, &X->qc)) return -1;
+    {
+        /* MZ_TAIL_PIPE (measurements): 0 = a tail beside ITS chunk's DP stream (pipes a, b); 1 = beside the OTHER DP stream (chunk k's walk
+         * starts when DP k ends -- and so should DP k+2, on the same queue as DP k: with the tail on that pipe its packets come 60-200 us
+         * late each while the walk runs); 2 = both tails on the copies' pipe d; 3 = both on the fronts' pipe c */
+        static int tp = -1;
+        if (tp < 0) { const char *e = getenv("MZ_TAIL_PIPE"); tp = e ? atoi(e) : 0; if (tp < 0 || tp > 3) tp = 0; }
+        if (tp <= 1) {
+            hipStream_t a, b;
+            if (flow_new_stream(X, &a) || flow_new_stream(X, nt > 1 ? &b : &filler)) return -1;
+            if (nt > 1) { X->qt[0] = tp ? b : a; X->qt[1] = tp ? a : b; } else X->qt[0] = a;
+        } else {
+            for (i = 0; i < nt; ++i) {
+                while (X->nqall % 4 != (tp == 2 ? 3 : 2)) if (flow_new_stream(X, &filler)) return -1;
+                if (flow_new_stream(X, &X->qt[i])) return -1;
+            }
+        }
+    }
     for (i = 0; i < 2; ++i) {
         X->qlane[i].n = 0;
         HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
     }
     X->nf = 1; X->nt = nt; X->nq = 2;
     if (mzi_timing()) fprintf(stderr, "{\"mz_flow_streams\": {\"created\": %d, \"ms\": %.1f}}\n", X->nqall, 1e3 * (mzi_now_s() - t0));
+    return 0;
+}
+
+/* Calls of few LONG pairs (BASELINE config 5: 1 000 pairs of 100 000 columns, four chunks of 250): a chunk's DP is a wave per pair and
+ * takes as long as ONE pair takes -- 25-30 ms -- however few it holds, the four of them fill a quarter of the GPU's SIMDs each, and two
+ * DP streams ran them two after two: 56 ms a call.  Four DP streams (and a tail each) run them side by side.  Which pipe these streams
+ * land on does not matter here: their kernels take milliseconds. */
+int mzi_flow_wide(mz_ctx *X)
+{
+    int i;
+    if (X->nq_wide) return 0;
+    for (i = 2; i < MZ_QS; ++i) {
+        if (flow_new_stream(X, &X->qd[i]) || flow_new_stream(X, &X->qt[i])) return -1;
+        X->qlane[i].n = 0;
+        HIPCK(hipEventCreateWithFlags((hipEvent_t *)&X->qlane[i].fork, mzi_event_flags()));
+    }
+    X->nq_wide = MZ_QS;
     return 0;
 }
 
@@ -101,8 +134,9 @@ void mzi_flow_sync(mz_ctx *X)
     if (X->qc) hipStreamSynchronize(X->qc);
     for (s = 0; s < X->nf; ++s) hipStreamSynchronize(X->qf[s]);
     for (s = 0; s < X->nt; ++s) hipStreamSynchronize(X->qt[s]);
-    for (s = 0; s < X->nq; ++s) {
+    for (s = 0; s < (X->nq_wide ? X->nq_wide : X->nq); ++s) {
         hipStreamSynchronize(X->qd[s]);
+        if (s >= X->nt && X->qt[s]) hipStreamSynchronize(X->qt[s]);
         for (l = 0; l < X->qlane[s].n; ++l) hipStreamSynchronize((hipStream_t)X->qlane[s].stream[l]);
     }
 }

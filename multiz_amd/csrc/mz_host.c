@@ -167,12 +167,12 @@ static void ctx_close(mz_ctx *X)
         hipEventDestroy(X->pplan2[s]);
         if (X->ptime_ready) for (i = 0; i < 8; ++i) hipEventDestroy(X->ptime[s][i]);
     }
-    for (s = 0; s < X->nq; ++s) {                        /* the chunk pipelines' streams (mz_flow.c) */
+    for (s = 0; s < (X->nq_wide ? X->nq_wide : X->nq); ++s) {    /* the chunk pipelines' streams (mz_flow.c) */
         for (i = 0; i < X->qlane[s].n; ++i) hipEventDestroy((hipEvent_t)X->qlane[s].join[i]);
         hipEventDestroy((hipEvent_t)X->qlane[s].fork);
         X->qlane[s].n = 0;
     }
-    X->nqall = X->lanes_made = 0;
+    X->nqall = X->lanes_made = X->nq_wide = 0;
     for (s = 0; s < MZ_QALL; ++s) if (X->qall[s]) { hipStreamSynchronize(X->qall[s]); hipStreamDestroy(X->qall[s]); X->qall[s] = NULL; }
     memset(X->qd, 0, sizeof X->qd); memset(X->qf, 0, sizeof X->qf); memset(X->qt, 0, sizeof X->qt); X->qc = NULL;
     X->nq = X->nf = X->nt = 0;
@@ -684,6 +684,7 @@ __attribute__((noreturn)) void mz_fatal_status(const mz_job *j, const mz_out *o)
     case MZ_E_SHAPE:    mz_fatalf("yama(gfx950): empty block (M=%d, N=%d)", j->M, j->N);
     case MZ_E_RANGE:    mz_fatalf("yama(gfx950): M + N = %lld columns exceed the 2^30 steps of this build", (long long)j->M + j->N);
     case MZ_E_DEVICE:   mz_fatalf("yama(gfx950): not computed (device error or out of memory)");
+    case MZ_E_SENTINEL: mz_fatalf("yama(gfx950): K=%d, L=%d, M=%d, N=%d: scores below the reference's MININT sentinel, where its traceback leaves the band (not reproduced by this build)", j->K, j->L, j->M, j->N);
     default:            mz_fatalf("yama(gfx950): device status %d", o->status);
     }
 }
@@ -708,6 +709,9 @@ void yama(uchar **A, int K, int M, uchar **B, int L, int N, int *LB, int *RB, uc
 
     if (K < 1 || L < 1 || M < 1 || N < 1)
         mz_fatalf("yama(gfx950): empty block (K=%d, L=%d, M=%d, N=%d)", K, L, M, N);
+    /* (a limit of this build -- the reference sizes dashes[MAX(K,L)] at run time, mz_yama.c:73-75 -- said here, before the columns are
+     *  gathered and before the GPU is touched: the plan would refuse the pair from K and L alone) */
+    if (K > 255 || L > 255) mz_fatalf("yama(gfx950): K=%d, L=%d outside the supported 1..255 rows per block", K, L);
     /* the reference only promises 1-based column pointers (mz_yama.h:6-9); gather them */
     ca = (uchar *)malloc((size_t)K * M);
     cb = (uchar *)malloc((size_t)L * N);

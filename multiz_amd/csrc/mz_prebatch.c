@@ -40,7 +40,7 @@ struct pasm;
 
 typedef struct pchunk {
     mz_ctx *X;
-    int set, n, index, any0, lane;         /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk) */
+    int set, n, index, any0, lane, wide;   /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk); wide: four DP slots, the tail is the slot's own */
     const mz_prejob *jobs;
     mz_preout *outs;
     mz_dev_batch b, b2;
@@ -90,7 +90,7 @@ static void pack_text(void *ctx, int lo, int hi)
 /* the chunk's streams (mz_ctx.h): front (staging block -> device, k_pre, plan), DP, tail (walk, emit, k_mid + second plan, k_fin, results -> host) */
 static hipStream_t pchunk_front(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qf[c->index % c->X->nf]; }
 static hipStream_t pchunk_dp(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qd[c->lane]; }
-static hipStream_t pchunk_tail(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->X->qt[c->index % c->X->nt]; }
+static hipStream_t pchunk_tail(const pchunk *c) { return c->lane < 0 ? c->X->stream : c->wide ? c->X->qt[c->lane] : c->X->qt[c->index % c->X->nt]; }
 static int g_ptiming = -1;
 #define PSTAMP(X, set, k, st) do { if (g_ptiming >= 2 && (X)->ptime_ready) HIPCK(hipEventRecord((X)->ptime[set][k], st)); } while (0)
 #define PD(i) (&X->pd[set][i])
@@ -109,7 +109,7 @@ static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n,
     int p, any0 = 0;
 
     c->t_pack0 = mzi_now_s();
-    c->X = X; c->set = set; c->index = index; c->lane = lane; c->n = n; c->jobs = jobs; c->outs = outs; c->cells = 0;
+    c->X = X; c->set = set; c->index = index; c->lane = lane < 0 ? -1 : (lane & 0xff); c->wide = lane >= 0 && (lane >> 8); c->n = n; c->jobs = jobs; c->outs = outs; c->cells = 0;
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
         txt += text_bytes(j);
@@ -466,7 +466,7 @@ static int pchunk_done(pchunk *c)
 
 typedef struct ppipe {
     mz_ctx *X;
-    int n, up, max_pairs, threaded;
+    int n, up, max_pairs, threaded, slots;   /* slots: DP streams of this call (2; 4 for a call of few long merges: mz_batch.c) */
     size_t max_bytes;
     const mz_prejob *jobs;
     mz_preout *outs;
@@ -525,12 +525,12 @@ static int p_cut(void *self, int k, int set, mz_ajob *pack)
 {
     ppipe *P = (ppipe *)self;
     /* the first chunks are a quarter and a half of the size: the GPU starts that much earlier */
-    const int ramp = P->threaded && k < 2 && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) ? 2 - k : 0;
+    const int ramp = P->threaded && P->slots <= 2 && k < 2 && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) ? 2 - k : 0;      /* (four DP slots: equal chunks, all side by side) */
     const int limit = P->max_pairs >> ramp < PRE_MIN_CHUNK / 2 ? PRE_MIN_CHUNK / 2 : P->max_pairs >> ramp;
     int m;
     if (P->up >= P->n) return 0;
     m = next_pchunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp);
-    if (pchunk_cut(P->X, &P->ck[set], k, set, P->threaded ? k % P->X->nq : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    if (pchunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
     P->up += m;
     return 1;
 }
@@ -556,7 +556,7 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
 {
     ppipe *P;
     mz_flow *F;
-    size_t max_bytes = 0;
+    size_t max_bytes = 0, total_bytes = 0;
     int rc, s, max_pairs, two_stage = 0, parts;
     static int env_pairs = -1;
 
@@ -577,6 +577,7 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
         else X->ptime_ready = 0;
     }
     for (s = 0; s < n; ++s) { max_bytes += text_bytes(&jobs[s]); two_stage += jobs[s].v == 0; }
+    total_bytes = max_bytes;
     parts = pre_parts(n, two_stage);
     max_bytes = max_bytes / (size_t)parts + 1;
     if (max_bytes < ((size_t)8 << 20)) max_bytes = (size_t)8 << 20;
@@ -590,6 +591,12 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
     F->X = X; F->self = P; F->nstage = 4; F->threaded = P->threaded;
     F->cut = p_cut; F->stage[0] = p_send; F->stage[1] = p_l1; F->stage[2] = p_l2; F->stage[3] = p_collect; F->finish = p_finish;
     if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }
+    P->slots = 2;
+    {                                                        /* few long merges: four chunks' DPs side by side (mz_batch.c, mz_flow.c: mzi_flow_wide) */
+        static int wide_on = -1;
+        if (wide_on < 0) { const char *e = getenv("MZ_WIDE"); wide_on = !(e && e[0] == '0'); }
+        if (P->threaded && wide_on && n <= 4096 && total_bytes / (size_t)n >= ((size_t)256 << 10) && mzi_flow_wide(X) == 0) P->slots = MZ_QS;      /* (long: a quarter of a megabyte of input a pair and more) */
+    }
     rc = mzi_flow_run(F);
     if (rc < 0) mzi_flow_sync(X);
     for (s = 0; s < MZ_SETS; ++s) { free(P->ck[s].a); free(P->ck[s].where); }

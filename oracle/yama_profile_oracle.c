@@ -21,6 +21,9 @@
 #include "oracle.h"
 
 typedef struct { int32_t C, D, I; } tri;
+#ifdef MZO_SPREAD_STATS              /* tests/tools/spread.c: how far apart the states of one band row lie (HISTORY section 10) */
+#include "spread_hook.h"
+#endif
 static const tri TRI_NEG = { MZO_NEG, MZO_NEG, MZO_NEG };
 
 void *mzo__alloc(mzo_arena *ar, size_t bytes, int zero);
@@ -208,7 +211,13 @@ int mzo__profile(mzo_arena *ar, const uint8_t *A, int K, int M, const uint8_t *B
             dp[c] = now;
             left = now;
             *tp++ = (uint8_t)(fc | (fd << 2) | (fi << 4));
+#ifdef MZO_SPREAD_STATS
+            MZO_SPREAD_CELL(r, c, lo, now);
+#endif
         }
+#ifdef MZO_SPREAD_STATS
+        MZO_SPREAD_ROW(r);
+#endif
     }
 
     if (final3) { final3[0] = left.C; final3[1] = left.D; final3[2] = left.I; }

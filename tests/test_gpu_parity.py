@@ -892,10 +892,11 @@ print("chunked ok")
     assert p.returncode == 0 and b"chunked ok" in p.stdout, p.stderr.decode()[-2000:]
 
 
-@pytest.mark.parametrize("walk", ["wave", "direct"])
+@pytest.mark.parametrize("walk", ["wave", "direct", "reg"])
 def test_every_walk_kernel(walk):
-    # two traceback walks -- the run-following one (default) and the step-by-step chase (MZ_WALK=direct; read once per
-    # process, hence the subprocess): each must produce the reference's merged blocks for every DP layout -- row-parallel ROW / COL
+    # three traceback walks -- the run-following one with its window in LDS, the step-by-step chase (MZ_WALK=direct; read once per
+    # process, hence the subprocess) and the run-following one with its window in registers (MZ_WALK=reg: the row-parallel pairs; the
+    # others by the LDS form) which the walks beside DP kernels take: each must produce the reference's merged blocks for every DP layout -- row-parallel ROW / COL
     # (lift and rotate forms), tagged and untagged wavefronts, the strip kernel -- on short and on long pairs
     import subprocess
     import sys
