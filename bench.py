@@ -17,12 +17,11 @@ value.  `--gpus N` without a torch.distributed environment starts the N ranks it
 One JSON line on stdout (rank 0).  SURVEY.md section 8(d) defines the metric's wall time as "H2D of packed jobs +
 kernels + D2H of packed outputs (report kernel-only as a second column)", so -- since round 6 --
 
-    value / ms_per_step   K calls of mz_yama_batch(): the batch from HOST buffers to malloc()ed merged columns, packing,
-                          PCIe both ways and the host-side assembly included -- what the reference's drivers get;
-                          every call timed on its own between synchronisations (max over ranks), 50 ms apart (the GPU
-                          boxes give a job 16 CPUs' worth of time per 100 ms and a call spends 0.15 s of CPU: calls
-                          issued back to back run into that quota, `back_to_back` has that rate), value = cells x K /
-                          the sum of the K times.  (`value_host`: the same number under its old name.)
+    value / ms_per_step   K calls of mz_yama_batch(), one after the other in ONE timed region (barrier + synchronize on
+                          both sides, max over ranks): the batch from HOST buffers to malloc()ed merged columns --
+                          packing, PCIe both ways and the host-side assembly included; what the reference's drivers get.
+                          (`value_host`: the same number.  `host_calls_apart`: the same calls one by one, 50 ms apart --
+                          GPU and host threads idle in between --, their median and spread: what rounds 3-5 printed.)
     value_resident        the second column: the batch already in HBM, the pipelined device-resident form
                           (mz_dev_run_async), `resident_steps` steps -- what rounds 1-5 printed as `value`.
     single_batch_gcups    one resident batch, its phases one after the other from HIP events; `roofline` is the DP launch
@@ -685,10 +684,27 @@ def main():
         # (the container's CPU quota is per 100 ms period: let the period the harness's own threads -- generator, checker --
         #  have drawn on run out before the library's host threads are timed)
         time.sleep(0.3)
-        t_host = []
         os.environ["MZ_TIMING"] = "0"
+        # the K timed steps: K calls one after the other, ONE timed region bracketed by barrier + synchronize (max over ranks)
         thr0 = cpu_throttle()
+        sync_all()
+        t = time.perf_counter()
         for _ in range(args.steps):
+            api.yama_batch_records(jobs, outs)
+            api.free_outs(outs)
+        sync_all()
+        t_steps = time.perf_counter() - t
+        thr1 = cpu_throttle()
+        if world > 1:
+            tt = torch.tensor([t_steps], dtype=torch.float64, device=red)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_steps = float(tt.item())
+        # ... and the calls one by one, `host_gap_ms` apart (what a driver that prepares its next batch between calls sees: the GPU and the
+        # host threads idle in between; the spread of single calls)
+        time.sleep(0.3)
+        t_host = []
+        ncalls = max(3, min(args.steps, 25))
+        for _ in range(ncalls):
             sync_all()
             t = time.perf_counter()
             api.yama_batch_records(jobs, outs)
@@ -697,22 +713,12 @@ def main():
             api.free_outs(outs)
             if args.host_gap_ms > 0:
                 time.sleep(args.host_gap_ms * 1e-3)
-        thr1 = cpu_throttle()
+        thr2 = cpu_throttle()
         t_host = np.array(t_host, dtype=np.float64)
-        if world > 1:                                            # a step ends when the slowest rank's call has
+        if world > 1:                                            # a call ends when the slowest rank's has
             tt = torch.from_numpy(t_host.copy()).to(red)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_host = tt.cpu().numpy()
-        # the same calls back to back (no pause): what a caller that streams batches gets under this box's CPU quota
-        sync_all()
-        nb2b = min(args.steps, 12)
-        t = time.perf_counter()
-        for _ in range(nb2b):
-            api.yama_batch_records(jobs, outs)
-            api.free_outs(outs)
-        sync_all()
-        t_b2b = (time.perf_counter() - t) / nb2b
-        thr2 = cpu_throttle()
         if cpu is not None:                                      # the host path's BYTES, hashed like the CPU leg's (checker code; untimed call)
             from oracle import mzoracle as mo
             api.yama_batch_records(jobs, outs)
@@ -720,16 +726,15 @@ def main():
             host_hash = mo.hash_cols(outs["cols"], outs["OM"], batch["K"] + batch["L"])
             api.free_outs(outs)
         assert np.array_equal(host_om, res["om"]), "host path and device-resident path disagree"
-        t_med, t_sum = float(np.median(t_host)), float(t_host.sum())
+        t_med = float(np.median(t_host))
         link = api.link_bytes(jobs)                              # what one call moves over PCIe, from the library's own accounting
-        host = {"gcups": all_cells * args.steps / t_sum / 1e9, "ms": 1e3 * t_sum / args.steps,
-                "median_gcups": round(all_cells / t_med / 1e9, 2), "median_ms": round(1e3 * t_med, 2),
-                "ms_all": [round(1e3 * x, 2) for x in t_host],
-                "spread": {"calls": int(args.steps), "max_over_median": round(float(t_host.max()) / t_med, 3), "min_over_median": round(float(t_host.min()) / t_med, 3),
-                           "calls_above_1.15_median": int((t_host > 1.15 * t_med).sum()),
-                           "cgroup_throttled_during_the_calls": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None)},
-                "back_to_back": {"calls": nb2b, "ms_per_call": round(1e3 * t_b2b, 2), "gcups": round(all_cells / t_b2b / 1e9, 2),
-                                 "cgroup_throttled_during_the_calls": ({"periods": thr2[0] - thr1[0], "usec": thr2[1] - thr1[1]} if thr1 and thr2 else None)},
+        host = {"gcups": all_cells * args.steps / t_steps / 1e9, "ms": 1e3 * t_steps / args.steps,
+                "cgroup_throttled_during_the_steps": ({"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]} if thr0 and thr1 else None),
+                "apart": {"calls": int(ncalls), "gap_ms": args.host_gap_ms, "median_gcups": round(all_cells / t_med / 1e9, 2), "median_ms": round(1e3 * t_med, 2),
+                          "ms_all": [round(1e3 * x, 2) for x in t_host],
+                          "max_over_median": round(float(t_host.max()) / t_med, 3), "min_over_median": round(float(t_host.min()) / t_med, 3),
+                          "calls_above_1.15_median": int((t_host > 1.15 * t_med).sum()),
+                          "cgroup_throttled_during_the_calls": ({"periods": thr2[0] - thr1[0], "usec": thr2[1] - thr1[1]} if thr1 and thr2 else None)},
                 "link_bytes_per_pair": {"up": round(link[0] / len(jobs), 1), "down": round(link[1] / len(jobs), 1)}}
 
     out = {
@@ -789,12 +794,12 @@ def main():
         out["roofline"]["valu"] = v
         out["roofline"]["pmc"] = {"source": pmc["source"], "stale": pmc["stale"], "kernel_avg_ms_in_stats_run": round(pmc.get("avg_ns", 0) / 1e6, 3)}
     if host:
-        out["value_host"] = round(host["gcups"], 2)              # (the headline under its old name; rounds 3-5 printed the median of the calls)
+        out["value_host"] = round(host["gcups"], 2)              # (the headline under its old name)
         out["host_ms_per_batch"] = round(host["ms"], 2)
-        out["host_median"] = {"gcups": host["median_gcups"], "ms": host["median_ms"]}
-        out["host_ms_all"] = host["ms_all"]
-        out["host_spread"] = host["spread"]
-        out["back_to_back"] = host["back_to_back"]
+        out["cgroup_throttled_during_the_steps"] = host["cgroup_throttled_during_the_steps"]
+        out["host_calls_apart"] = host["apart"]                  # (rounds 3-5 printed this median as value_host)
+        out["host_ms_all"] = host["apart"]["ms_all"]
+        out["host_spread"] = {k: host["apart"][k] for k in ("calls", "max_over_median", "min_over_median", "calls_above_1.15_median", "cgroup_throttled_during_the_calls")}
         out["host_link_bytes_per_pair"] = host["link_bytes_per_pair"]
     if exchange:
         out["exchange"] = exchange

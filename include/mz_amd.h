@@ -154,7 +154,12 @@ int mz_walk_choice(int n, const int64_t *totals);
 /* which DP kernels have pairs in this batch (mz_dev_batch.dp_hint; bits 8..15: the one with the most), from the plan's
  * totals (host copy) */
 enum { MZ_DP_ROW = 1, MZ_DP_WAVEFRONT = 2, MZ_DP_WIDE = 4, MZ_DP_LAG = 8, MZ_DP_KNOWN = 16, MZ_DP_ROWBIG = 32,
-       MZ_DP_HELPERS_FIRST = 0x10000 };   /* not a hint, a request (kept whatever hint_gen says): the batch's plan / prep / walk / emit kernels raise their waves'
+       MZ_DP_STAMP = 0x20000,           /* a request too (measurements: tests/tools/c5_where.py): k_dp_row_lat leaves per pair p, in scanAux[3p .. 3p+2] (batches of
+                                           at most MZ_PLAN_FOLD_MAX pairs), where its wave ran -- HW_ID | XCC_ID << 32 -- and when: s_memrealtime at its start and end */
+       MZ_DP_SOLO = 0x40000,            /* a request: this batch is one of several whose row-parallel pairs TOGETHER leave the GPU's SIMDs at most a wave each (the chunks
+                                           of a call of few long pairs): their DP takes the build whose waves cannot share a SIMD (kernels/row.inc: k_dp_row_solo) */
+       MZ_DP_HELPERS_FIRST = 0x10000,
+       MZ_DP_REQUESTS = 0x10000 | 0x20000 | 0x40000 };   /* the bits of dp_hint that are requests, not hints: kept whatever hint_gen says */   /* not a hint, a request (kept whatever hint_gen says): the batch's plan / prep / walk / emit kernels raise their waves'
                                              issue priority.  For batches whose small kernels must get through beside OTHER batches' DP waves at once (the chunk
                                              pipelines of mz_yama_batch / mz_preyama_batch: a late plan is an idle DP stream); a loss of 1.5-3 % for device-resident
                                              batches, whose helpers only have to be done a whole DP later */

@@ -178,7 +178,7 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
     int p;
 
     c->t_cut0 = mzi_now_s();
-    c->X = X; c->set = set; c->index = index; c->lane = lane & 0xff; c->wide = lane >= 0 && (lane >> 8); c->n = n; c->jobs = jobs; c->outs = outs;
+    c->X = X; c->set = set; c->index = index; c->lane = lane & 0xff; c->wide = lane >= 0 && ((lane >> 8) & 1); c->n = n; c->jobs = jobs; c->outs = outs;
     if (lane < 0) c->lane = -1;
     c->where = NULL; c->ac = NULL; c->cells = 0; c->exc_bytes = 0; c->res_bytes = 0;
     for (p = 0; p < n; ++p) {
@@ -201,7 +201,7 @@ static int chunk_cut(mz_ctx *X, chunk *c, int index, int set, int lane, int n, c
 
     memset(&b, 0, sizeof b);
     b.n = n;
-    b.dp_hint = lane >= 0 ? MZ_DP_HELPERS_FIRST : 0;      /* (beside other chunks' DPs: include/mz_amd.h) */
+    b.dp_hint = lane >= 0 ? MZ_DP_HELPERS_FIRST | ((lane >> 9) & 1 ? MZ_DP_SOLO : 0) : 0;      /* (beside other chunks' DPs: include/mz_amd.h; lane bit 9: a call of at most 1 024 long pairs on four slots) */
 #define SLICE(hptr, type, field, bytes) do { hptr = (type *)h; b.field = (const type *)d; \
         h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
 #define SLICE2(hptr, dptr, type, bytes) do { hptr = (type *)h; dptr = (const type *)d; \
@@ -317,16 +317,22 @@ static int chunk_launch(chunk *c)
         return -1;
     b.tbw = (uint32_t *)X->d_tb[set].p; b.script = (uint8_t *)X->d_script[set].p; b.out = NULL;     /* (no merged columns on the device) */
     b.walk_hint = mz_walk_choice(n, totals);             /* (the plan's totals are here: no need for both launches) */
-    b.dp_hint = mz_dp_hint(n, totals) | (b.dp_hint & MZ_DP_HELPERS_FIRST);      /* (nor for DP kernels that have no pairs) */
+    b.dp_hint = mz_dp_hint(n, totals) | (b.dp_hint & MZ_DP_REQUESTS);      /* (nor for DP kernels that have no pairs) */
     b.dp_grid = mz_dp_grid(n, totals); b.dp_rows = mz_dp_rows(n, totals); b.hint_gen = g_hint_gen;
     b.capTb = (int64_t)(X->d_tb[set].cap / 4); b.capScript = (int64_t)X->d_script[set].cap; b.capOut = INT64_MAX;
     if (c->lane >= 0 && !X->lanes_made && mz_dp_kinds(b.dp_hint) > 1 && mzi_flow_lanes(X)) return -1;     /* several kinds of pairs: the DP streams' lanes */
 
     dres = (char *)X->d_res[set].p;
-    if (sd != chunk_front(c)) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));      /* (the prep records: behind the plan on the front stream) */
-    if (mzk_dp_range_on(&b, 0, n, sd, c->lane < 0 ? NULL : &X->qlane[c->lane])) return mzi_set_err("%s", mzk_last_error());
-    TSTAMP(X, set, 3, sd);
-    if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
+    /* (the prep records: made behind the plan on the front stream -- a few microseconds after the totals this thread has just waited for.
+     *  Waited for HERE, not by the DP stream: a wait packet in front of the DP is one more packet that starts 60-200 us late while the
+     *  stream's pipe-mate, the tail of the chunk before, has a kernel running; the DP's "done" event rides on its own packet likewise) */
+    if (sd != chunk_front(c)) HIPCK(hipEventSynchronize(X->bprep[set]));
+    {
+        int rides = 0;
+        if (mzk_dp_range_ev(&b, 0, n, sd, c->lane < 0 ? NULL : &X->qlane[c->lane], st != sd && g_timing < 2 ? (void *)X->bdp[set] : NULL, &rides)) return mzi_set_err("%s", mzk_last_error());
+        TSTAMP(X, set, 3, sd);
+        if (st != sd) { if (!rides) HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
+    }
     if (mzk_walk(&b, st, 1) || mzk_script_pack(&b, dres, dres + 64, dres + 64 + mzi_al256(sizeof(mz_res_rec) * (size_t)n), st))
         return mzi_set_err("%s", mzk_last_error());
     TSTAMP(X, set, 4, st);
@@ -544,11 +550,11 @@ static size_t job_bytes(const mz_job *j)
  * the waves of a launch out from its first CUs on: several small launches in flight pile onto the same CUs).  C5,
  * 1 000 pairs of 100 000 rows: 12 chunks of 84 pairs 125 ms, 4 of 256 pairs 83 ms, one chunk 60 ms. */
 #define MIN_CHUNK_PAIRS 1024
-static int next_chunk(const mz_job *jobs, int n, int first, int limit, size_t max_bytes)
+static int next_chunk(const mz_job *jobs, int n, int first, int limit, size_t max_bytes, int min_pairs)
 {
     size_t bytes = 0;
     int m = 0;
-    while (first + m < n && m < limit && (bytes < max_bytes || (m < MIN_CHUNK_PAIRS && bytes < ((size_t)1 << 30)))) {
+    while (first + m < n && m < limit && (bytes < max_bytes || (m < min_pairs && bytes < ((size_t)1 << 30)))) {
         bytes += job_bytes(&jobs[first + m]);
         ++m;
     }
@@ -559,20 +565,22 @@ static int y_cut(void *self, int k, int set, mz_ajob *pack)
 {
     ypipe *P = (ypipe *)self;
     /* the first chunks are smaller: the GPU starts that much earlier (MZ_RAMP: their sizes in eighths of a chunk, e.g. "2,4") */
-    static int ramp_n = -1, ramp8[8];
+    static int ramp_n = -1, ramp8[16];
     int limit = P->max_pairs, m, shift8 = 8;
     if (ramp_n < 0) {
         const char *e = getenv("MZ_RAMP");
         ramp_n = 0;
-        for (e = e ? e : "2,4"; *e && ramp_n < 8; ) { ramp8[ramp_n++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; }
+        for (e = e ? e : "2,4"; *e && ramp_n < 16; ) { ramp8[ramp_n++] = atoi(e); while (*e && *e != ',') ++e; if (*e) ++e; }
     }
     /* (not for a call on four DP slots: its chunks' DPs take one long pair's time each whatever their size, and all of them run side by side) */
-    if (P->threaded && P->slots <= 2 && k < ramp_n && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) && ramp8[k] >= 1 && ramp8[k] < 8) shift8 = ramp8[k];
+    if (P->threaded && P->slots <= 2 && k < ramp_n && (P->max_pairs >= 2048 || P->max_bytes >= ((size_t)32 << 20)) && ramp8[k] >= 1 && ramp8[k] <= 32) shift8 = ramp8[k];
     limit = (int)((long long)P->max_pairs * shift8 / 8);
     if (limit < MIN_CHUNK_PAIRS / 2) limit = MIN_CHUNK_PAIRS / 2;
     if (P->up >= P->n) return 0;
-    m = next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes / 8 * (size_t)shift8);
-    if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    /* (four DP slots: the call in four chunks of as many pairs each, however few -- all of them run side by side, each as long as one pair takes) */
+    m = P->slots > 2 ? next_chunk(P->jobs, P->n, P->up, (P->n + P->slots - 1) / P->slots, (size_t)1 << 30, 0)
+                     : next_chunk(P->jobs, P->n, P->up, limit, P->max_bytes / 8 * (size_t)shift8, MIN_CHUNK_PAIRS);
+    if (chunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 | (P->n <= 1024 ? 0x200 : 0) : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
     P->up += m;
     return 1;
 }
@@ -634,7 +642,7 @@ static int batch_on_ctx(mz_ctx *X, int n, const mz_job *jobs, mz_out *outs, int 
     if (max_bytes > ((size_t)1 << 30)) max_bytes = (size_t)1 << 30;
     P->max_bytes = max_bytes;
     /* one chunk: the steps inline (no thread is woken for a single yama() call); also when no thread can be had */
-    P->threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes) < n;
+    P->threaded = next_chunk(jobs, n, 0, max_pairs, max_bytes, MIN_CHUNK_PAIRS) < n;
     F->X = X; F->self = P; F->nstage = 3; F->threaded = P->threaded;
     F->cut = y_cut; F->stage[0] = y_send; F->stage[1] = y_launch; F->stage[2] = y_collect; F->finish = y_finish;
     if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }

@@ -28,6 +28,9 @@ int mzk_dp_range(const mz_dev_batch *b, int first, int count, void *stream);
 typedef struct mz_dp_lanes { int n; void *stream[4]; void *fork; void *join[4]; } mz_dp_lanes;
 int mz_dp_kinds(int dp_hint);          /* DP kernels a batch with this mz_dp_hint() launches */
 int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes);
+/* ... and an event (hipEvent_t as void *) for "these DP kernels are through": *done_set = 1 when it rode on the one kernel's own dispatch
+ * packet (a batch of one row-parallel kind), 0 when the caller has to record it on `stream` */
+int mzk_dp_range_ev(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes, void *done, int *done_set);
 int mzk_walk_range(const mz_dev_batch *b, int first, int count, void *stream, int beside_dp);
 /* bytes (a multiple of 16, both addresses 16-byte aligned) from src to dst by a kernel on `stream`: either may be pinned host memory */
 int mzk_link_copy(void *dst, const void *src, size_t bytes, void *stream);

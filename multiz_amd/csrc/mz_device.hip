@@ -23,6 +23,7 @@
 // No MFMA anywhere: this is an integer max-plus recurrence, not a contraction.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <mutex>
 #include <stdint.h>
@@ -31,6 +32,7 @@
 #include "mz_device.h"
 
 #define WAVE   64
+#define SIMDS_TOTAL 1024        // 256 CUs x 4 SIMDs
 #define ROLL_VMAX 64            // kernels/roll.inc: the longest wait (in steps) of a row the rolling form with late starts admits (its rings hold 2 V + 128: static_assert there)
 #define MZ_ROWS_SUM(t11)     ((t11) & ((1LL << 44) - 1))      // totals[11]: rows (K+L) of all valid pairs ...
 #define MZ_TSTRIP_PAIRS(t11) ((t11) >> 44)                    // ... and the number of MZ_MODE_TSTRIP pairs (kernels/plan.inc, scan_load)
@@ -477,6 +479,27 @@ static int grid_of(int count, int most, int field)       // waves for a counter 
     if (field > 0 && 8 * field < g) g = 8 * field;
     return g < 1 ? 1 : g;
 }
+// `done` (may be null): an event to stand for "these DP kernels are through".  Where the batch takes ONE row-parallel kernel the event
+// rides on that kernel's own dispatch packet (hipExtLaunchKernel's stop event) and *done_set = 1; otherwise the caller records it.  Why
+// it matters: on a queue whose pipe-mate has a kernel running every PACKET starts 60-200 us late (mz_flow.c) -- a DP stream's next DP
+// behind an event-record packet and a wait packet started three such delays after the DP before it ended (the chunk pipelines' DP
+// kernels: 70-340 us apart on their stream, profiles/r6_timeline_host_c2.txt before / after).
+static thread_local hipEvent_t t_dp_done = nullptr;
+static thread_local int t_dp_done_set = 0;
+extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes);
+extern "C" int mzk_dp_range_ev(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes, void *done, int *done_set)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("MZ_DP_EVENT_RIDES"); on = !(e && e[0] == '0'); }
+    t_dp_done = on ? (hipEvent_t)done : nullptr; t_dp_done_set = 0;
+    const int rc = mzk_dp_range_on(b, first, count, stream, lanes);
+    if (done_set) *done_set = t_dp_done_set;
+    t_dp_done = nullptr;
+    return rc;
+}
+#define ROW_LAUNCH(kernel, ...) do { \
+        if (t_dp_done && nk == 1) { hipExtLaunchKernelGGL(kernel, dim3(row_blocks), dim3(WAVE), dyn_lds, s, nullptr, t_dp_done, 0, __VA_ARGS__); t_dp_done_set = 1; } \
+        else hipLaunchKernelGGL(kernel, dim3(row_blocks), dim3(WAVE), dyn_lds, s, __VA_ARGS__); } while (0)
 extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void *stream, const mz_dp_lanes *lanes)
 {
     if (count <= 0) return 0;
@@ -486,6 +509,8 @@ extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void
     if (dyn_lds_lag < 0) { const char *e = getenv("MZ_DYN_LDS_LAG"); dyn_lds_lag = e ? atoi(e) : 0; }
     static int lat_max = -1;                      // MZ_LAT_MAX=<waves>: launches that leave the GPU at most that many row-parallel waves take k_dp_row_lat (0: never)
     if (lat_max < 0) { const char *e = getenv("MZ_LAT_MAX"); lat_max = e ? atoi(e) : 2048; }
+    static int solo_on = -1;                      // MZ_SOLO=0: never the one-wave-a-SIMD build (measurements)
+    if (solo_on < 0) { const char *e = getenv("MZ_SOLO"); solo_on = !(e && e[0] == '0'); }
     static int serial = -1;                       // MZ_DP_SERIAL=1: never side by side (measurements)
     if (serial < 0) { const char *e = getenv("MZ_DP_SERIAL"); serial = e && e[0] == '1'; }
     hipStream_t main_s = (hipStream_t)stream;
@@ -536,13 +561,17 @@ extern "C" int mzk_dp_range_on(const mz_dev_batch *b, int first, int count, void
         const int row_items = rows_listed ? b->dp_rows : count, row_blocks = row_items;
         if (kinds[i] == MZ_DP_ROW) {
             // few pairs -- a wave or two per SIMD, nothing to hide a latency behind: the latency-tolerant build (kernels/row.inc)
-            if ((long long)row_blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
-                hipLaunchKernelGGL(k_dp_row_lat, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
+            // (a wave per SIMD at most, counting what the caller runs beside this launch -- MZ_DP_SOLO: the chunks of a call of at most 1 024
+            //  long pairs; mz_dev_run_async's batches abreast: g_abreast --: the build whose waves cannot share a SIMD, kernels/row.inc)
+            if (solo_on && ((b->dp_hint & MZ_DP_SOLO) || (!(b->dp_hint & MZ_DP_HELPERS_FIRST) && (long long)row_blocks * g_abreast <= SIMDS_TOTAL)) && (long long)row_blocks * g_abreast <= lat_max)
+                ROW_LAUNCH(k_dp_row_solo, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
+            else if ((long long)row_blocks * g_abreast <= lat_max)   // (the DPs of g_abreast consecutive batches run side by side: mz_dev_run_async)
+                ROW_LAUNCH(k_dp_row_lat, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
             else
-                hipLaunchKernelGGL(k_dp_row, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
+                ROW_LAUNCH(k_dp_row, *b, first, row_items, rows_listed ? 3 : known ? 0 : 1);
         }
         else if (kinds[i] == MZ_DP_ROWBIG)
-            hipLaunchKernelGGL(k_dp_row_big, dim3(row_blocks), dim3(WAVE), dyn_lds, s, *b, first, row_items, rows_listed ? 3 : known ? 0 : 2);
+            ROW_LAUNCH(k_dp_row_big, *b, first, row_items, rows_listed ? 3 : known ? 0 : 2);
         // (the counter kernels: no more waves than pairs -- a wave that finds the counter exhausted still had to wait for
         //  its 9-13 KB of LDS beside the other kernels' waves, and the launch is over only when the last one has)
         else if (kinds[i] == MZ_DP_WAVEFRONT)
@@ -611,15 +640,16 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
     if (force < 0) { const char *e = getenv("MZ_WALK"); force = !e ? 0 : e[0] == 'w' ? 1 : e[0] == 'd' ? 2 : e[0] == 'r' ? 3 : 0; }
     const int hint = (force || !beside_dp || count <= 16384) ? 0 : b->walk_hint;
     const bool both = !force && beside_dp && count > 16384 && hint == MZ_WALK_AUTO;
-    // Beside DP kernels the row-parallel pairs of a launch of at most 4 096 pairs, or of thin blocks (the caller's walk_hint: MZ_WALK_REG),
-    // take the walk whose window lies in registers (k_walk_reg, kernels/walk.inc: no LDS, 30 VGPRs, runs of at most 17-32 steps an
-    // iteration); k_walk_wave takes what is left, when the plan's totals say there is anything.  Measured, one mz_yama_batch() call, reg /
-    // LDS window: C3 4.9 / 5.45 ms, c2i 5.6 / 5.85, C2 8.42 / 8.42 -- and C4, whose paths run straight for 64 steps and more, 22 / 18: hence
-    // the rule.  MZ_WALK=reg: everywhere; MZ_WALK_REG=0: nowhere.
+    // Beside DP kernels the row-parallel pairs of a batch whose caller says so (walk_hint MZ_WALK_REG, from mz_walk_choice(): a launch of at
+    // most 4 096 pairs, or thin blocks -- and no long pairs) take the walk whose window lies in registers (k_walk_reg, kernels/walk.inc: no
+    // LDS, 30 VGPRs, runs of at most 17-32 steps an iteration); k_walk_wave takes what is left, when the plan's totals say there is
+    // anything.  Measured, one mz_yama_batch() call, reg / LDS window: C3 4.9 / 5.45 ms, c2i 5.6 / 5.85, C2 8.42 / 8.42 -- and C4, whose paths
+    // run straight for 64 steps and more, 22 / 18; C5's 100 000-row pairs 11.9 / 7 ms a walk (a lone wave per pair: the LDS form's window
+    // fetched a whole window ahead is what counts there): hence the rule.  MZ_WALK=reg: everywhere; MZ_WALK_REG=0: nowhere.
     static int reg_on = -1;
     if (reg_on < 0) { const char *e = getenv("MZ_WALK_REG"); reg_on = !(e && e[0] == '0'); }
     const bool known = (b->dp_hint & MZ_DP_KNOWN) != 0;
-    const bool reg = force == 3 || (!force && reg_on && beside_dp && count <= 16384 && (count <= 4096 || b->walk_hint == MZ_WALK_REG) &&
+    const bool reg = force == 3 || (!force && reg_on && beside_dp && count <= 16384 && b->walk_hint == MZ_WALK_REG &&
                                     (!known || (b->dp_hint & (MZ_DP_ROW | MZ_DP_ROWBIG))));
     const bool rest = !reg || !known || (b->dp_hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE | MZ_DP_LAG));
     if (reg) hipLaunchKernelGGL(k_walk_reg, dim3(count), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count);
@@ -643,7 +673,8 @@ extern "C" int mz_walk_choice(int n, const int64_t *totals)
 {
     const long long ok = (long long)n - totals[3];
     const bool thin = MZ_ROWS_SUM(totals[11]) < 8 * (ok > 0 ? ok : 1);       // fewer than 8 rows a pair: the paths turn every few steps
-    return (n > 16384 && thin) ? MZ_WALK_CHASE : thin ? MZ_WALK_REG : MZ_WALK_RUNS;
+    const bool lng = totals[0] > (long long)(ok > 0 ? ok : 1) * (1 << 18);      // a quarter of a million traceback dwords a pair: ~20 000 rows and more
+    return (n > 16384 && thin) ? MZ_WALK_CHASE : ((thin || n <= 4096) && !lng) ? MZ_WALK_REG : MZ_WALK_RUNS;
 }
 
 extern "C" int mzk_emit_range(const mz_dev_batch *b, int first, int count, void *stream)

@@ -391,9 +391,9 @@ int mz_hint_generation(void) { return g_hint_gen; }
  * scores in force now -- a stale dp_hint would skip the kernels of modes the re-plan assigns */
 static const mz_dev_batch *checked_hints(const mz_dev_batch *b, mz_dev_batch *tmp)
 {
-    if (!((b->dp_hint & ~MZ_DP_HELPERS_FIRST) | b->dp_grid | b->dp_rows | b->walk_hint) || b->hint_gen == g_hint_gen) return b;
+    if (!((b->dp_hint & ~MZ_DP_REQUESTS) | b->dp_grid | b->dp_rows | b->walk_hint) || b->hint_gen == g_hint_gen) return b;
     *tmp = *b;
-    tmp->dp_hint = b->dp_hint & MZ_DP_HELPERS_FIRST;         /* (a request, not a hint) */
+    tmp->dp_hint = b->dp_hint & MZ_DP_REQUESTS;         /* (a request, not a hint) */
     tmp->dp_grid = tmp->dp_rows = tmp->walk_hint = 0;
     return tmp;
 }

@@ -40,7 +40,7 @@ struct pasm;
 
 typedef struct pchunk {
     mz_ctx *X;
-    int set, n, index, any0, lane, wide;   /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk); wide: four DP slots, the tail is the slot's own */
+    int set, n, index, any0, lane, wide, solo;   /* lane: which stream slot (X->qf / qd / qt[lane]); -1: the context's own stream (a call of one chunk); wide: four DP slots, the tail is the slot's own */
     const mz_prejob *jobs;
     mz_preout *outs;
     mz_dev_batch b, b2;
@@ -109,7 +109,7 @@ static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n,
     int p, any0 = 0;
 
     c->t_pack0 = mzi_now_s();
-    c->X = X; c->set = set; c->index = index; c->lane = lane < 0 ? -1 : (lane & 0xff); c->wide = lane >= 0 && (lane >> 8); c->n = n; c->jobs = jobs; c->outs = outs; c->cells = 0;
+    c->X = X; c->set = set; c->index = index; c->lane = lane < 0 ? -1 : (lane & 0xff); c->wide = lane >= 0 && ((lane >> 8) & 1); c->solo = lane >= 0 && ((lane >> 9) & 1); c->n = n; c->jobs = jobs; c->outs = outs; c->cells = 0;
     for (p = 0; p < n; ++p) {
         const mz_prejob *j = &jobs[p];
         txt += text_bytes(j);
@@ -152,7 +152,7 @@ static int pchunk_cut(mz_ctx *X, pchunk *c, int index, int set, int lane, int n,
         c->q.lds16 = keep16; c->q.lds_bytes = keepb;
     }
     c->b.n = c->b2.n = c->q.n = n;
-    c->b.dp_hint = c->b2.dp_hint = c->lane >= 0 ? MZ_DP_HELPERS_FIRST : 0;      /* (beside other chunks' DPs: include/mz_amd.h) */
+    c->b.dp_hint = c->b2.dp_hint = c->lane >= 0 ? MZ_DP_HELPERS_FIRST | (c->solo ? MZ_DP_SOLO : 0) : 0;      /* (beside other chunks' DPs: include/mz_amd.h) */
 #define SL(hptr, type, dptr, bytes) do { hptr = (type *)h; dptr = (const type *)d; h += mzi_al256(bytes); d += mzi_al256(bytes); } while (0)
     SL(hK, int32_t, c->q.K, 4 * (size_t)n); SL(hL, int32_t, c->q.L, 4 * (size_t)n); SL(hMa, int32_t, c->q.Ma, 4 * (size_t)n);
     SL(hNa, int32_t, c->q.Na, 4 * (size_t)n); SL(hRad, int32_t, c->q.rad, 4 * (size_t)n); SL(hV, int32_t, c->q.v, 4 * (size_t)n);
@@ -260,22 +260,24 @@ static int run_stage(mz_ctx *X, int set, int stamp, hipStream_t sd, hipStream_t 
     b->tbw = (uint32_t *)tb->p; b->script = (uint8_t *)script->p; b->out = (uint8_t *)out->p;
     b->capTb = (int64_t)(tb->cap / 4); b->capScript = (int64_t)script->cap; b->capOut = (int64_t)out->cap;
     b->walk_hint = mz_walk_choice(n, totals);
-    b->dp_hint = mz_dp_hint(n, totals) | (b->dp_hint & MZ_DP_HELPERS_FIRST); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
+    b->dp_hint = mz_dp_hint(n, totals) | (b->dp_hint & MZ_DP_REQUESTS); b->dp_grid = mz_dp_grid(n, totals); b->dp_rows = mz_dp_rows(n, totals); b->hint_gen = g_hint_gen;
     if (lanes && !X->lanes_made && mz_dp_kinds(b->dp_hint) > 1 && mzi_flow_lanes(X)) return -1;      /* several kinds of pairs: the DP streams' lanes */
     /* the DP on the slot's DP stream (whatever else it reads is through: the host has seen this plan's totals), the rest behind its event */
-    if (wait_prep) HIPCK(hipStreamWaitEvent(sd, X->bprep[set], 0));
+    /* (the prep records are waited for HERE and the DP's "done" event rides on its own dispatch packet where it can: every packet on the DP
+     *  stream starts 60-200 us late while its pipe-mate, the tail of the chunk before, has a kernel running -- mz_batch.c, chunk_launch) */
+    if (wait_prep) HIPCK(hipEventSynchronize(X->bprep[set]));
     {
         /* (the two launch stages run on threads of their own and chunks k and k + 2 share a DP stream's lanes: the fork / launch / join
          *  sequence of one at a time -- what a wait refers to is fixed when it is enqueued) */
         static pthread_mutex_t launch_mu = PTHREAD_MUTEX_INITIALIZER;
-        int rc;
+        int rc, rides = 0;
         pthread_mutex_lock(&launch_mu);
-        rc = mzk_dp_range_on(b, 0, n, sd, lanes);
+        rc = mzk_dp_range_ev(b, 0, n, sd, lanes, st != sd ? (void *)X->bdp[set] : NULL, &rides);
         pthread_mutex_unlock(&launch_mu);
         if (rc) return mzi_set_err("%s", mzk_last_error());
+        if (stamp >= 0) PSTAMP(X, set, stamp, sd);
+        if (st != sd) { if (!rides) HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
     }
-    if (stamp >= 0) PSTAMP(X, set, stamp, sd);
-    if (st != sd) { HIPCK(hipEventRecord(X->bdp[set], sd)); HIPCK(hipStreamWaitEvent(st, X->bdp[set], 0)); }
     if (mzk_walk(b, st, 1) || mzk_emit(b, st)) return mzi_set_err("%s", mzk_last_error());
     if (stamp >= 0) PSTAMP(X, set, stamp + 1, st);
     return 0;
@@ -510,11 +512,11 @@ static int pre_parts(int n, int two_stage)
 }
 
 #define PRE_MIN_CHUNK 1024
-static int next_pchunk(const mz_prejob *jobs, int n, int first, int limit, size_t max_bytes)
+static int next_pchunk(const mz_prejob *jobs, int n, int first, int limit, size_t max_bytes, int min_pairs)
 {
     size_t bytes = 0;
     int m = 0;
-    while (first + m < n && m < limit && (bytes < max_bytes || (m < PRE_MIN_CHUNK && bytes < ((size_t)1 << 30)))) {
+    while (first + m < n && m < limit && (bytes < max_bytes || (m < min_pairs && bytes < ((size_t)1 << 30)))) {
         bytes += text_bytes(&jobs[first + m]);
         ++m;
     }
@@ -529,8 +531,9 @@ static int p_cut(void *self, int k, int set, mz_ajob *pack)
     const int limit = P->max_pairs >> ramp < PRE_MIN_CHUNK / 2 ? PRE_MIN_CHUNK / 2 : P->max_pairs >> ramp;
     int m;
     if (P->up >= P->n) return 0;
-    m = next_pchunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp);
-    if (pchunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
+    m = P->slots > 2 ? next_pchunk(P->jobs, P->n, P->up, (P->n + P->slots - 1) / P->slots, (size_t)1 << 30, 0)       /* (four DP slots: four chunks, side by side) */
+                     : next_pchunk(P->jobs, P->n, P->up, limit, P->max_bytes >> ramp, PRE_MIN_CHUNK);
+    if (pchunk_cut(P->X, &P->ck[set], k, set, P->threaded ? (k % P->slots) | (P->slots > 2 ? 0x100 | (P->n <= 1024 ? 0x200 : 0) : 0) : -1, m, P->jobs + P->up, P->outs + P->up, pack) < 0) return -1;
     P->up += m;
     return 1;
 }
@@ -587,7 +590,7 @@ int mzi_pre_on_ctx(mz_ctx *X, int n, const mz_prejob *jobs, mz_preout *outs, int
         max_pairs = env_pairs ? env_pairs : per < PRE_MIN_CHUNK ? PRE_MIN_CHUNK : per > 16384 ? 16384 : per;
     }
     P->max_pairs = max_pairs; P->max_bytes = max_bytes;
-    P->threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes) < n;
+    P->threaded = next_pchunk(jobs, n, 0, max_pairs, max_bytes, PRE_MIN_CHUNK) < n;
     F->X = X; F->self = P; F->nstage = 4; F->threaded = P->threaded;
     F->cut = p_cut; F->stage[0] = p_send; F->stage[1] = p_l1; F->stage[2] = p_l2; F->stage[3] = p_collect; F->finish = p_finish;
     if (P->threaded && mzi_flow_streams(X)) { P->threaded = F->threaded = 0; }

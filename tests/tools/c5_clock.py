@@ -1,5 +1,5 @@
 """Which shader clock did every launch of a DP kernel run at?  (HISTORY 9.12: the serial C5 DP takes 25.4 or 30.2 ms with the same binary.)
-    python tests/tools/c5_clock.py <dir> [config] [kernel prefix]          (on the GPU box)
+    python tests/tools/c5_clock.py <dir> [config] [kernel prefix] [host]   (on the GPU box)
 One rocprofv3 pass with --kernel-trace --pmc GRBM_GUI_ACTIVE over `bench.py --config c5 --steps 12 --no-cpu --no-host`: per dispatch the
 counter is the cycles the GPU was active during it, summed over the 8 XCDs; cycles / 8 / the dispatch's own duration = its clock."""
 import csv, glob, os, subprocess, sys
@@ -7,8 +7,9 @@ out = sys.argv[1]
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c5"
 pref = sys.argv[3] if len(sys.argv) > 3 else "k_dp_row"
 py = os.path.realpath(sys.executable)
-subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", out, "--",
-                py, "bench.py", "--config", cfg, "--steps", "12", "--warmup", "2", "--no-cpu", "--no-host"],
+host = len(sys.argv) > 4 and sys.argv[4] == "host"          # ... or of the chunk pipeline's launches: tests/tools/hostpath.py (HOSTPATH_SLEEP as set)
+cmd = [py, "tests/tools/hostpath.py", "0", cfg] if host else [py, "bench.py", "--config", cfg, "--steps", "12", "--warmup", "2", "--no-cpu", "--no-host"]
+subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", out, "--"] + cmd,
                env=dict(os.environ, TMPDIR="/tmp", MZ_DP_STREAMS="1"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 dur = {}
 for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
