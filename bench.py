@@ -665,8 +665,9 @@ def main():
     # rows or more), the lagged one, or the wavefront fallbacks
     big = bool((np.maximum(batch["K"], batch["L"]) >= 4).any())
     nrow = int(modes[5:9].sum())
-    # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat: C5 as one batch)
-    row_kernel = "k_dp_row_big" if big else "k_dp_row_lat" if 0 < nrow <= 2048 else "k_dp_row"
+    # (a launch that leaves the GPU at most 2 048 row-parallel waves takes the latency-tolerant build, k_dp_row_lat; at most a wave per SIMD:
+    #  the build whose waves cannot share one, k_dp_row_solo: C5 as one batch)
+    row_kernel = "k_dp_row_big" if big else "k_dp_row_solo" if 0 < nrow <= 1024 else "k_dp_row_lat" if nrow <= 2048 else "k_dp_row"
     dominant_kernel = max((nrow, row_kernel), (int(modes[11]), "k_dp_lag"),
                           (int(modes[:4].sum()), "k_dp"), (int(modes[4]), "k_dp_tstrip"), (int(modes[13]), "k_dp_duo"), (int(modes[9:11].sum() + modes[12]), "k_dp_wide"))[1]
 
