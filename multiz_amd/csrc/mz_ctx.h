@@ -144,6 +144,7 @@ typedef struct mz_ajob {
     int next, pending, active, hedged, npiece; struct mz_ajob *link, *olink;
     unsigned char state[MZ_HEDGE_PIECES]; double t_start[MZ_HEDGE_PIECES];
     double t_sum; int n_done;              /* first runs that came back: their durations, their number (what "late" is measured against) */
+    double skip_until;                     /* no piece of this loop can be late before then: the search for late pieces passes it by (mz_pool.c) */
 } mz_ajob;
 MZ_INTERNAL void mzi_post(mz_ajob *job);
 MZ_INTERNAL int mzi_job_quiet(mz_ajob *job);                            /* wait until no thread is in a piece of a (complete) posted loop; pieces run twice */

@@ -664,6 +664,9 @@ extern "C" int mzk_walk_range(const mz_dev_batch *b, int first, int count, void 
         const int waves = (count + WALK_LANES - 1) / WALK_LANES;
         CK(hipMemsetAsync(&b->totals[10], 0, sizeof(int64_t), (hipStream_t)stream), "walk counter");      // the chase's pair counter
         hipLaunchKernelGGL(k_walk, dim3(waves < WALK_GRID ? waves : WALK_GRID), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
+        // (the exact kernels' pairs, if the batch has any: the plan's totals know -- wavefront and 128+-row lists)
+        if (!(b->dp_hint & MZ_DP_KNOWN) || (b->dp_hint & (MZ_DP_WAVEFRONT | MZ_DP_WIDE)))
+            hipLaunchKernelGGL(k_walk_exact, dim3(waves), dim3(WAVE), 0, (hipStream_t)stream, *b, first, count, both ? 1 : 0);
     }
     CK(hipGetLastError(), "walk launch");
     return 0;

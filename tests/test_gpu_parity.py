@@ -976,3 +976,48 @@ def test_host_path_sweep(mz):
             continue
         w = mo.yama(A, B, LB, RB, variant="profile")
         assert r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols), (i, A.shape, B.shape)
+
+
+def test_below_the_sentinel_is_reported_as_such(mz):
+    """Two blocks of 100+ rows EACH over hundreds of mismatching columns: scores fall below the reference's MININT sentinel (mz_yama.c:29),
+    "unreachable" states win its comparisons, and its walk steps outside the band, reads neighbouring rows' traceback bytes and still
+    arrives (tests/golden/below_sentinel.npz: the compiled reference's OM and column hash, which the oracle reproduces).  The product
+    does not follow it there: such a pair comes back MZ_E_SENTINEL -- not MZ_E_TRACEBACK, the reference's own error, and never another
+    alignment -- on every kernel set, through the device-resident API and through yama_batch()."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "below_sentinel.npz"))
+    A, B, LB, RB = z["A"], z["B"], z["LB"], z["RB"]
+    K, L, M, N = A.shape[1], B.shape[1], A.shape[0], B.shape[0]
+    assert K * L * 525 * (M + N + 2) >= 1 << 30                  # scores CAN get below -2^30 here
+    w = mo.yama(A, B, LB, RB, variant="profile")                 # (the oracle follows the reference: a result, the fixture's)
+    assert w.rc == 0 and w.OM == int(z["OM"]) and mo.fnv1a_np(w.cols, mo.fnv1a_np(np.array([w.OM], dtype=np.int32).view(np.uint8))) == int(z["hash"])
+    ok = inputs.make_pair(np.random.default_rng(5), 2, 2, 120, 130, 30, "diag", mo.smooth)
+    for fast, row in ((1, 1), (1, 0), (0, 0)):
+        mz.lib().mz_enable_fast(fast); mz.lib().mz_enable_row(row)
+        res = mz.yama_batch([ok, (A, B, LB, RB), ok])
+        assert [r.status for r in res] == [0, 21, 0] and res[1].cols is None, [r.status for r in res]
+        assert mz.api.MZ_STATUS[res[1].status] == "sentinel"
+    mz.lib().mz_enable_fast(1); mz.lib().mz_enable_row(1)
+
+
+def test_rebased_kernels_report_a_frontier_below_the_sentinel(mz):
+    """The row-parallel kernels re-base their scores and would find the TRUE optimum however low the scores go; the reference does not (its
+    sentinel states start winning below -2^30).  Two blocks of 30 rows over thousands of UNRELATED columns: at 3 000 columns the scores stay
+    above the sentinel and the result is the reference's; at 14 000 the frontier falls below -2^29 on the way, the kernels mark the pair
+    (kernels/row.inc: ROW_SENTINEL_EDGE) and it comes back MZ_E_SENTINEL -- or, where the plan took an exact kernel, as the oracle has it."""
+    rng = np.random.default_rng(77)
+    pairs = []
+    for n in (3000, 14000):
+        A = inputs.random_block(rng, n, 30, dash=0.05, odd=0.0)
+        B = inputs.random_block(rng, n, 30, dash=0.05, odd=0.0)
+        LB, RB = inputs.diag_band(n, n)
+        LB, RB = mo.smooth(LB, RB, n, n, 30)
+        pairs.append((A, B, LB.astype(np.int32), RB.astype(np.int32)))
+    for row in (1, 0):
+        mz.lib().mz_enable_fast(1); mz.lib().mz_enable_row(row)
+        res = mz.yama_batch(pairs)
+        for i, (p, r) in enumerate(zip(pairs, res)):
+            w = mo.yama(*p, variant="profile")
+            same = r.status == 0 and r.OM == w.OM and np.array_equal(r.cols, w.cols)
+            assert same or (i == 1 and r.status == 21), (row, i, r.status)
+        assert res[0].status == 0
+    mz.lib().mz_enable_fast(1); mz.lib().mz_enable_row(1)

@@ -43,7 +43,7 @@ for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json
     try:
         d = json.load(open(f))
         r = d["roofline"]
-        print(os.path.basename(f), "value (host)", d["value"], d["ms_per_step"], "resident", d.get("value_resident"), "apart", (d.get("host_calls_apart") or {}).get("median_gcups"), (d.get("host_spread") or {}).get("calls_above_1.15_median"),
+        print(os.path.basename(f), "value (host)", d["value"], d["ms_per_step"], "resident", d.get("value_resident"), "median", (d.get("host_median") or {}).get("gcups"), "slow calls", (d.get("host_spread") or {}).get("calls_above_1.15_median"), "b2b", (d.get("back_to_back") or {}).get("gcups"),
               "pre", d.get("value_pre"), d.get("value_pre_v0"), "serial", d["single_batch_gcups"], d["kernel_ms"],
               "roof", r["frac"], "valu", (r.get("valu") or {}).get("frac"), "traffic", r.get("traffic"), "cpu", d.get("cpu_baseline", {}).get("value"), d.get("cpu_baseline", {}).get("socket_linear"), d.get("vs_cpu"))
     except Exception as e:
