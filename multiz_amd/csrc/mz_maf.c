@@ -85,34 +85,72 @@ static void printable_src(const char *src, char *out, size_t cap)
         snprintf(out + n, cap - n, ".%s", rest);
 }
 
-/* one block in MAF text, column-aligned the way the reference writer does it (maf.c:251-294) */
+/* one block in MAF text, column-aligned the way the reference writer does it (maf.c:251-294): the block is put together in one
+ * buffer -- the fields laid down by hand, what "s %-*s %*d %*d %c %*d %s\n" prints -- and written with one call (a guide-tree run
+ * prints thirteen million rows at its destination alone; a formatted print per row was most of that time) */
+static char *put_right(char *p, int width, int v)          /* %*d of a non-negative number */
+{
+    char tmp[12];
+    int n = 0, k;
+    unsigned u = (unsigned)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    for (k = n; k < width; ++k) *p++ = ' ';
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
 void mafWrite(FILE *f, struct mafAli *a)
 {
     struct mafComp *c;
-    int wsrc = 0, wstart = 0, wsize = 0, wsrcsize = 0, row = 0;
-    char name[512];
+    int wsrc = 0, wstart = 0, wsize = 0, wsrcsize = 0, row = 0, rows = 0;
+    size_t need = 512, text = 0;
+    char name[512], stack[16384], *buf, *p;
 
-    fputs("a", f);
-    if (a->score != MIN_INT) fprintf(f, " score=%3.1f", a->score);
-    for (c = a->components; c; c = c->next, ++row) {
-        if (c->paralog == 'a') fprintf(f, " amplifier=%d", row);
-        else if (c->paralog == 'c') fprintf(f, " copy=%d", row);
-        else if (c->paralog != 's') mz_fatalf("Wrong character: \'%c\'", c->paralog);
-    }
-    fputc('\n', f);
     for (c = a->components; c; c = c->next) {
         int n = (int)strlen(c->src);
         if (n > wsrc) wsrc = n;
+        text += strlen(c->text);
+        ++rows;
+    }
+    /* (the widths of the numbers are taken below, behind the header line: digits10() ends the program on a negative one, and the
+     * stock writer has printed the header by then) */
+    need += (size_t)rows * ((size_t)wsrc + 64) + text;
+    buf = need <= sizeof stack ? stack : (char *)xmalloc(need);
+    p = buf;
+    *p++ = 'a';
+    if (a->score != MIN_INT) p += sprintf(p, " score=%3.1f", a->score);
+    for (c = a->components; c; c = c->next, ++row) {
+        if (c->paralog == 'a') p += sprintf(p, " amplifier=%d", row);
+        else if (c->paralog == 'c') p += sprintf(p, " copy=%d", row);
+        else if (c->paralog != 's') { fwrite(buf, 1, (size_t)(p - buf), f); mz_fatalf("Wrong character: '%c'", c->paralog); }
+    }
+    *p++ = '\n';
+    for (c = a->components; c; c = c->next) {
+        int n;
+        if (c->start < 0 || c->size < 0 || c->srcSize < 0) fwrite(buf, 1, (size_t)(p - buf), f);      /* (digits10() is about to end the program) */
         if ((n = digits10(c->start)) > wstart) wstart = n;
         if ((n = digits10(c->size)) > wsize) wsize = n;
         if ((n = digits10(c->srcSize)) > wsrcsize) wsrcsize = n;
     }
     for (c = a->components; c; c = c->next) {
+        size_t n;
         printable_src(c->src, name, sizeof name);
-        fprintf(f, "s %-*s %*d %*d %c %*d %s\n", wsrc, name, wstart, c->start, wsize, c->size,
-                c->strand, wsrcsize, c->srcSize, c->text);
+        n = strlen(name);
+        *p++ = 's'; *p++ = ' ';
+        memcpy(p, name, n); p += n;
+        for (; n < (size_t)wsrc; ++n) *p++ = ' ';
+        *p++ = ' ';
+        p = put_right(p, wstart, c->start); *p++ = ' ';
+        p = put_right(p, wsize, c->size); *p++ = ' ';
+        *p++ = c->strand; *p++ = ' ';
+        p = put_right(p, wsrcsize, c->srcSize); *p++ = ' ';
+        n = strlen(c->text);
+        memcpy(p, c->text, n); p += n;
+        *p++ = '\n';
     }
-    fputc('\n', f);
+    *p++ = '\n';
+    fwrite(buf, 1, (size_t)(p - buf), f);
+    if (buf != stack) free(buf);
 }
 
 /* column (0-based) of sequence position pos in row c (reference multi_util.c:633-645) */

@@ -265,41 +265,40 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
  * per-node loop this region is a nested one and runs on the calling thread), and the records are joined in order.  A list that is
  * not sorted by start is walked in one piece, as ever. */
 #define WALK_PIECE_MIN 2048                                 /* blocks (both lists) below which a contig is not worth cutting */
-static void walk_contig(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int radius, int minw)
+static int walk_piece_min(void)
 {
-#define BEG(a) ((a)->components->start)
-#define END(a) ((a)->components->start + (a)->components->size - 1)
-    struct mafAli *a, **arr1, **arr2;
-    int n1 = 0, n2 = 0, i1, i2, npieces = 0, want, k, sorted = 1;
-    int *cut1, *cut2;
+    const char *pm = getenv("MZ_WALK_PIECE_MIN");           /* (tests: pieces of a few blocks; read per contig -- the tree driver walks several nodes' lists at once) */
+    return pm && atoi(pm) > 1 ? atoi(pm) : WALK_PIECE_MIN;
+}
+
+/* the blocks of the two lists in arr1[0..n1) / arr2[0..n2) (still linked), the first and last reference position of each in b / e.
+ * Returns 0 with the lists as they were when the contig is not cut (lists out of order, too few blocks or no place to cut) */
+static int walk_pieces(record *R, struct mafAli **arr1, const int *b1, const int *e1, int n1, struct mafAli **arr2, const int *b2, const int *e2, int n2,
+                       int piece_min, int v, int radius, int minw)
+{
+    int i1, i2, npieces = 0, want, k, sorted = 1;
+    int *cut1, *cut2, *ev0, *mg0;
     long long reach;
     record *piece;
-    const char *pm = getenv("MZ_WALK_PIECE_MIN");           /* (tests: pieces of a few blocks; read per contig -- the tree driver walks several nodes' lists at once) */
-    const int piece_min = pm && atoi(pm) > 1 ? atoi(pm) : WALK_PIECE_MIN;
-    for (a = *wk1; a; a = a->next) ++n1;
-    for (a = *wk2; a; a = a->next) ++n2;
-    if (n1 + n2 < piece_min) { walk(R, wk1, wk2, v, radius, minw); return; }
-    arr1 = (struct mafAli **)mz_xmalloc(((size_t)n1 + 1) * sizeof *arr1);
-    arr2 = (struct mafAli **)mz_xmalloc(((size_t)n2 + 1) * sizeof *arr2);
-    for (a = *wk1, n1 = 0; a; a = a->next) { if (n1 && BEG(a) < BEG(arr1[n1 - 1])) sorted = 0; arr1[n1++] = a; }
-    for (a = *wk2, n2 = 0; a; a = a->next) { if (n2 && BEG(a) < BEG(arr2[n2 - 1])) sorted = 0; arr2[n2++] = a; }
+    for (k = 1; k < n1 && sorted; ++k) if (b1[k] < b1[k - 1]) sorted = 0;
+    for (k = 1; k < n2 && sorted; ++k) if (b2[k] < b2[k - 1]) sorted = 0;
     want = (n1 + n2) / (piece_min / 2 > 0 ? piece_min / 2 : 1);
     if (want > 4 * MZ_STAGE_THREADS) want = 4 * MZ_STAGE_THREADS;
-    if (!sorted || want < 2) { free(arr1); free(arr2); walk(R, wk1, wk2, v, radius, minw); return; }
+    if (!sorted || want < 2) return 0;
     cut1 = (int *)mz_xmalloc(((size_t)want + 2) * sizeof(int)); cut2 = (int *)mz_xmalloc(((size_t)want + 2) * sizeof(int));
     /* the two lists in merged order; a piece may end in front of a block that starts behind `reach` */
     cut1[0] = cut2[0] = 0; npieces = 1;
     reach = -1;
     for (i1 = i2 = 0; i1 < n1 || i2 < n2; ) {
-        const int take1 = i2 >= n2 || (i1 < n1 && BEG(arr1[i1]) <= BEG(arr2[i2]));
-        struct mafAli *b = take1 ? arr1[i1] : arr2[i2];
-        if ((i1 || i2) && (long long)BEG(b) > reach && npieces < want &&
+        const int take1 = i2 >= n2 || (i1 < n1 && b1[i1] <= b2[i2]);
+        const int bb = take1 ? b1[i1] : b2[i2], be = take1 ? e1[i1] : e2[i2];
+        if ((i1 || i2) && (long long)bb > reach && npieces < want &&
             (long long)(i1 + i2) * want >= (long long)npieces * (n1 + n2)) { cut1[npieces] = i1; cut2[npieces] = i2; ++npieces; }
-        if ((long long)END(b) > reach) reach = END(b);
+        if ((long long)be > reach) reach = be;
         if (take1) ++i1; else ++i2;
     }
     cut1[npieces] = n1; cut2[npieces] = n2;
-    if (npieces < 2) { free(arr1); free(arr2); free(cut1); free(cut2); walk(R, wk1, wk2, v, radius, minw); return; }
+    if (npieces < 2) { free(cut1); free(cut2); return 0; }
     for (k = 1; k < npieces; ++k) {                         /* the lists, severed at the cuts */
         if (cut1[k] > 0) arr1[cut1[k] - 1]->next = NULL;
         if (cut2[k] > 0) arr2[cut2[k] - 1]->next = NULL;
@@ -312,24 +311,94 @@ static void walk_contig(record *R, struct mafAli **wk1, struct mafAli **wk2, int
         piece[k].has1 = R->has1; piece[k].has2 = R->has2; piece[k].keep_blocks = R->keep_blocks;
         walk(&piece[k], &l1, &l2, v, radius, minw);
     }
-    *wk1 = *wk2 = NULL;                                     /* (a walk takes every block of its lists) */
-    for (k = 0; k < npieces; ++k) {                         /* joined in order: event and merge numbers shift */
+    /* joined in order: event and merge numbers shift (the pieces' records copied side by side) */
+    ev0 = (int *)mz_xmalloc(((size_t)npieces + 1) * sizeof(int)); mg0 = (int *)mz_xmalloc(((size_t)npieces + 1) * sizeof(int));
+    ev0[0] = R->nev; mg0[0] = R->nmg;
+    for (k = 0; k < npieces; ++k) { ev0[k + 1] = ev0[k] + piece[k].nev; mg0[k + 1] = mg0[k] + piece[k].nmg; }
+    if (ev0[npieces] > R->capev) { R->capev = 2 * ev0[npieces] + 256; R->ev = (event *)realloc(R->ev, (size_t)R->capev * sizeof(event)); if (!R->ev) mz_fatalf("out of memory"); }
+    if (mg0[npieces] > R->capmg) { R->capmg = 2 * mg0[npieces] + 256; R->mg = (merge *)realloc(R->mg, (size_t)R->capmg * sizeof(merge)); if (!R->mg) mz_fatalf("out of memory"); }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS)
+    for (k = 0; k < npieces; ++k) {
         record *P = &piece[k];
-        const int ev0 = R->nev, mg0 = R->nmg;
         int i;
-        if (R->nev + P->nev > R->capev) { R->capev = 2 * (R->nev + P->nev) + 256; R->ev = (event *)realloc(R->ev, (size_t)R->capev * sizeof(event)); if (!R->ev) mz_fatalf("out of memory"); }
-        if (R->nmg + P->nmg > R->capmg) { R->capmg = 2 * (R->nmg + P->nmg) + 256; R->mg = (merge *)realloc(R->mg, (size_t)R->capmg * sizeof(merge)); if (!R->mg) mz_fatalf("out of memory"); }
-        if (P->nev) memcpy(R->ev + ev0, P->ev, (size_t)P->nev * sizeof(event));
-        if (P->nmg) memcpy(R->mg + mg0, P->mg, (size_t)P->nmg * sizeof(merge));
-        for (i = 0; i < P->nev; ++i) if (R->ev[ev0 + i].job >= 0) R->ev[ev0 + i].job += mg0;
-        for (i = 0; i < P->nmg; ++i) R->mg[mg0 + i].side_ev += ev0;
-        R->nev += P->nev; R->nmg += P->nmg;
-        if (P->arena) { arena_chunk *t = P->arena; while (t->next) t = t->next; t->next = R->arena; R->arena = P->arena; }
+        if (P->nev) memcpy(R->ev + ev0[k], P->ev, (size_t)P->nev * sizeof(event));
+        if (P->nmg) memcpy(R->mg + mg0[k], P->mg, (size_t)P->nmg * sizeof(merge));
+        for (i = 0; i < P->nev; ++i) if (R->ev[ev0[k] + i].job >= 0) R->ev[ev0[k] + i].job += mg0[k];
+        for (i = 0; i < P->nmg; ++i) R->mg[mg0[k] + i].side_ev += ev0[k];
         free(P->ev); free(P->mg);
     }
-    free(piece); free(arr1); free(arr2); free(cut1); free(cut2);
-#undef BEG
-#undef END
+    R->nev = ev0[npieces]; R->nmg = mg0[npieces];
+    for (k = 0; k < npieces; ++k) {
+        record *P = &piece[k];
+        if (P->arena) { arena_chunk *t = P->arena; while (t->next) t = t->next; t->next = R->arena; R->arena = P->arena; }
+    }
+    free(piece); free(cut1); free(cut2); free(ev0); free(mg0);
+    return 1;
+}
+
+static void walk_contig(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int radius, int minw)
+{
+    struct mafAli *a, **arr1, **arr2;
+    int n1 = 0, n2 = 0, *key, cut;
+    const int piece_min = walk_piece_min();
+    for (a = *wk1; a; a = a->next) ++n1;
+    for (a = *wk2; a; a = a->next) ++n2;
+    if (n1 + n2 < piece_min) { walk(R, wk1, wk2, v, radius, minw); return; }
+    arr1 = (struct mafAli **)mz_xmalloc(((size_t)n1 + 1) * sizeof *arr1);
+    arr2 = (struct mafAli **)mz_xmalloc(((size_t)n2 + 1) * sizeof *arr2);
+    key = (int *)mz_xmalloc(2 * ((size_t)n1 + (size_t)n2 + 1) * sizeof(int));
+    for (a = *wk1, n1 = 0; a; a = a->next, ++n1) { arr1[n1] = a; key[n1] = a->components->start; }
+    for (a = *wk2, n2 = 0; a; a = a->next, ++n2) { arr2[n2] = a; key[n1 + n2] = a->components->start; }
+    for (cut = 0; cut < n1; ++cut) key[n1 + n2 + cut] = key[cut] + arr1[cut]->components->size - 1;
+    for (cut = 0; cut < n2; ++cut) key[2 * n1 + n2 + cut] = key[n1 + cut] + arr2[cut]->components->size - 1;
+    cut = walk_pieces(R, arr1, key, key + n1 + n2, n1, arr2, key + n1, key + 2 * n1 + n2, n2, piece_min, v, radius, minw);
+    free(arr1); free(arr2); free(key);
+    if (cut) *wk1 = *wk2 = NULL;                            /* (a walk takes every block of its lists) */
+    else walk(R, wk1, wk2, v, radius, minw);
+}
+
+/* Two long lists on ONE reference contig (a level of a guide tree run chromosome by chromosome): each list walked once into an array,
+ * the keys and the contig check taken from the blocks on all threads, then the walk in pieces.  Returns 0 with the lists untouched
+ * when that is not the case. */
+typedef struct { struct mafAli **arr; int n; } blist;
+static blist list_array(struct mafAli *l)
+{
+    blist b = { NULL, 0 };
+    int cap = 4096;
+    b.arr = (struct mafAli **)mz_xmalloc((size_t)cap * sizeof *b.arr);
+    for (; l; l = l->next) {
+        if (b.n == cap) { cap *= 2; b.arr = (struct mafAli **)realloc(b.arr, (size_t)cap * sizeof *b.arr); if (!b.arr) mz_fatalf("out of memory"); }
+        b.arr[b.n++] = l;
+    }
+    return b;
+}
+static int prepare_one_contig(record *R, struct mafAli **list1, struct mafAli **list2, mz_blocks *idx1, mz_blocks *idx2, int v, int radius, int minw)
+{
+    const int piece_min = walk_piece_min();
+    const char *chr = (*list1)->components->src;
+    blist L[2];
+    int *key, n1, n2, i, other = 0, done = 0;
+#pragma omp parallel for schedule(static, 1) num_threads(2)
+    for (i = 0; i < 2; ++i) {
+        mz_blocks *idx = i ? idx2 : idx1;
+        if (idx && idx->p) { L[i].arr = idx->p; L[i].n = idx->n; idx->p = NULL; idx->n = idx->cap = 0; }      /* (the blocks are known: nothing to walk) */
+        else L[i] = list_array(i ? *list2 : *list1);
+    }
+    n1 = L[0].n; n2 = L[1].n;
+    if (n1 + n2 >= piece_min) {
+        key = (int *)mz_xmalloc(2 * ((size_t)n1 + (size_t)n2 + 1) * sizeof(int));
+#pragma omp parallel for schedule(static, 1024) num_threads(MZ_STAGE_THREADS) reduction(| : other)
+        for (i = 0; i < n1 + n2; ++i) {
+            const struct mafComp *c = (i < n1 ? L[0].arr[i] : L[1].arr[i - n1])->components;
+            key[i] = c->start; key[n1 + n2 + i] = c->start + c->size - 1;
+            if (c->src != chr && strcmp(c->src, chr) != 0) other |= 1;
+        }
+        if (!other) done = walk_pieces(R, L[0].arr, key, key + n1 + n2, n1, L[1].arr, key + n1, key + 2 * n1 + n2, n2, piece_min, v, radius, minw);
+        free(key);
+    }
+    free(L[0].arr); free(L[1].arr);
+    if (done) *list1 = *list2 = NULL;
+    return done;
 }
 
 /* Stage 1 of every merge, then the pending yama() calls of all of them wave after wave.  The merges are
@@ -392,14 +461,25 @@ static int run_merges_device(mref *all, int nmg, int minw, int timing)
     double t0 = mz_now_s(), t1;
     who = (int *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof(int));
     first = (size_t *)mz_xmalloc((size_t)(nmg ? nmg : 1) * sizeof *first);
-    for (i = 0; i < nmg; ++i) {                             /* the merges of this path, and where each one's row pointers start */
+    /* the merges of this path, and where each one's row pointers start (the rows counted on all threads: a guide-tree level is half a
+     * million merges of up to thirty rows, each row a step down a list) */
+#pragma omp parallel for schedule(static, 512) num_threads(MZ_STAGE_THREADS) if (nmg > 4096)
+    for (i = 0; i < nmg; ++i) {
         merge *g = &all[i].R->mg[all[i].i];
         struct mafComp *c;
-        if (!on_device(g)) continue;
+        int rows = 0;
+        if (on_device(g)) {
+            for (c = g->a1->components; c; c = c->next) ++rows;
+            for (c = g->a2->components; c; c = c->next) ++rows;
+        } else rows = -1;
+        who[i] = rows;
+    }
+    for (i = 0; i < nmg; ++i) {
+        const int rows = who[i];
+        if (rows < 0) continue;
         first[n] = nptr;
-        who[n++] = i;
-        for (c = g->a1->components; c; c = c->next) ++nptr;
-        for (c = g->a2->components; c; c = c->next) ++nptr;
+        who[n++] = i;                                       /* (n <= i: the entry is not needed again) */
+        nptr += (size_t)rows;
     }
     if (n == 0) { free(who); free(first); return 1; }
     jobs = (mz_prejob *)mz_xmalloc((size_t)n * sizeof *jobs);
@@ -575,29 +655,37 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
 /* the same replay into three LISTS (record.keep_blocks): every block as the next program of the stock chain would read it from the text
  * this replay does not write (mz_ali_as_reread).  The one piece of text a kept-blocks run still holds -- pre_yama()'s side write to out2
  * when nothing of the first block is left to align (mz_preyama.c:193-196: host stage 1) -- is read back here. */
-typedef struct { struct mafAli *head, *tail; } alist;
+typedef struct { struct mafAli *head, *tail; mz_blocks idx; } alist;
 static void alist_add(alist *l, struct mafAli *a)          /* (a: one block, or a chain; already as their reader would hold them) */
 {
     if (!a) return;
     if (l->tail) l->tail->next = a; else l->head = a;
-    while (a->next) a = a->next;
+    for (;;) { mz_blocks_push(&l->idx, a); if (!a->next) break; a = a->next; }
     l->tail = a;
 }
-static void replay_lists(record *R, struct mafAli **out, struct mafAli **f1, struct mafAli **f2)
+static void alist_add_one(alist *l, struct mafAli *a)      /* (a: ONE block -- nothing of it is read here) */
 {
-    alist L[3] = { { NULL, NULL }, { NULL, NULL }, { NULL, NULL } };
+    a->next = NULL;
+    if (l->tail) l->tail->next = a; else l->head = a;
+    mz_blocks_push(&l->idx, a);
+    l->tail = a;
+}
+static void replay_lists(record *R, struct mafAli **out, struct mafAli **f1, struct mafAli **f2, struct mafAli **tails, mz_blocks *idx)
+{
+    alist L[3];
     int i;
+    memset(L, 0, sizeof L);
     for (i = 0; i < R->nev; ++i) {
         event *e = &R->ev[i];
         if (e->job >= 0) {
             merge *g = &R->mg[e->job];
             if (g->state == MERGE_FAILED) mz_fatal_status(&g->bad_job, &g->bad_out);
-            if (g->result) { alist_add(&L[SINK_OUT], g->result); g->result = NULL; }
+            if (g->result) { alist_add_one(&L[SINK_OUT], g->result); g->result = NULL; }
             free(g->text);
             g->a1 = g->a2 = NULL;                           /* (arena) */
         } else if (e->blk) {
             if ((e->sink == SINK_1 && !R->has1) || (e->sink == SINK_2 && !R->has2)) mafAliFree(&e->blk);
-            else alist_add(&L[e->sink], e->blk);
+            else alist_add_one(&L[e->sink], e->blk);
             e->blk = NULL;
         } else if (e->text) {
             if (e->len && !((e->sink == SINK_1 && !R->has1) || (e->sink == SINK_2 && !R->has2))) {
@@ -614,6 +702,11 @@ static void replay_lists(record *R, struct mafAli **out, struct mafAli **f1, str
     arena_release(&R->arena);
     memset(R, 0, sizeof *R);
     *out = L[SINK_OUT].head;
+    if (tails) { tails[0] = L[SINK_OUT].tail; tails[1] = f1 ? L[SINK_1].tail : NULL; tails[2] = f2 ? L[SINK_2].tail : NULL; }
+    for (i = 0; i < 3; ++i) {
+        if (idx && (i == 0 || (i == 1 ? f1 != NULL : f2 != NULL))) idx[i] = L[i].idx;
+        else { if (idx) memset(&idx[i], 0, sizeof idx[i]); mz_blocks_drop(&L[i].idx); }
+    }
     if (f1) *f1 = L[SINK_1].head; else { struct mafAli *a = L[SINK_1].head; while (a) { struct mafAli *n = a->next; a->next = NULL; mafAliFree(&a); a = n; } }
     if (f2) *f2 = L[SINK_2].head; else { struct mafAli *a = L[SINK_2].head; while (a) { struct mafAli *n = a->next; a->next = NULL; mafAliFree(&a); a = n; } }
 }
@@ -628,10 +721,18 @@ struct mz_mzrun { record R; int minw; };
 struct mz_mzrun *mz_multiz_prepare(struct mafAli **list1, struct mafAli **list2, int v, int radius, int min_output_wid,
                                    int has_out1, int has_out2)
 {
+    return mzi_multiz_prepare_blocks(list1, list2, NULL, NULL, v, radius, min_output_wid, has_out1, has_out2);
+}
+/* the same with the lists' indexes, where they are known (consumed either way) */
+struct mz_mzrun *mzi_multiz_prepare_blocks(struct mafAli **list1, struct mafAli **list2, mz_blocks *idx1, mz_blocks *idx2, int v, int radius,
+                                           int min_output_wid, int has_out1, int has_out2)
+{
     struct mz_mzrun *run = (struct mz_mzrun *)mz_xmalloc(sizeof *run);
     memset(run, 0, sizeof *run);
     run->minw = min_output_wid;
     run->R.has1 = has_out1; run->R.has2 = has_out2;
+    if (*list1 && *list2 && prepare_one_contig(&run->R, list1, list2, idx1, idx2, v, radius, min_output_wid)) return run;
+    mz_blocks_drop(idx1); mz_blocks_drop(idx2);
     while (*list1 && *list2) {                              /* one reference contig at a time, in file-1 order */
         struct mafAli *wk1 = NULL, *wk2 = NULL;
         char *chr = mz_xstrdup((*list1)->components->src);
@@ -663,8 +764,14 @@ void mz_multiz_finish(struct mz_mzrun *run, FILE *out, FILE *out1, FILE *out2)
 void mz_multiz_keep_blocks(struct mz_mzrun *run) { run->R.keep_blocks = 1; }
 void mz_multiz_finish_lists(struct mz_mzrun *run, struct mafAli **out, struct mafAli **out1, struct mafAli **out2)
 {
+    mzi_multiz_finish_tails(run, out, out1, out2, NULL, NULL);
+}
+/* the same, and the last block of each list in tails[0..2] (NULL for an empty one): the tree driver goes on appending to them */
+/* ... and the blocks of each list in idx[0..2] */
+void mzi_multiz_finish_tails(struct mz_mzrun *run, struct mafAli **out, struct mafAli **out1, struct mafAli **out2, struct mafAli **tails, mz_blocks *idx)
+{
     if (!run->R.keep_blocks) mz_fatalf("mz_multiz_finish_lists: the run was aligned for text");
-    replay_lists(&run->R, out, out1, out2);
+    replay_lists(&run->R, out, out1, out2, tails, idx);
     free(run);
 }
 

@@ -210,7 +210,7 @@ static void fuse_neighbours_long(struct mafAli *list)
 /* Project `all` (blocks in file order; consumed) onto `target` (a species name or a full source name).  Returns
  * the projected blocks in output order; blocks without a row of the target go to *others in file order (freed
  * when others == NULL). */
-struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others)
+static struct mafAli *project_plain(struct mafAli *all, const char *target, struct mafAli **others)
 {
     struct mafAli *A = NULL, *out = NULL, *out_tail = NULL, *oth_tail = NULL, *a, *next;
     if (others) *others = NULL;
@@ -264,4 +264,177 @@ struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct m
         A = B;
     }
     return out;
+}
+
+/* ------------------------------------------------------------------------------------------------ long lists
+ * The same projection for a list of tens or hundreds of thousands of blocks (a level of a guide tree), where the plain form's time
+ * goes into walking the list again and again -- every pass a chain of cache misses, a dozen passes: here the list is walked ONCE
+ * into an array, the per-block work (finding the target's row, moving it to the top, the reverse complement) runs on all threads,
+ * contigs are told apart by number, and the fusion passes and the final linking work on the array.  The ORDER of everything the plain
+ * form does is kept: the blocks reach the library's qsort in the order the stock tool's back-to-front collection and contig-by-contig
+ * partition give them (so ties fall as they do there), and fusions are made left to right with the same questions asked. */
+typedef struct { struct mafAli *a; const char *src; unsigned hash; int start, contig; } pitem;
+
+static unsigned str_hash(const char *s)
+{
+    unsigned h = 2166136261u;
+    for (; *s; ++s) h = (h ^ (unsigned char)*s) * 16777619u;
+    return h;
+}
+
+/* one fusion pass (fuse_neighbours_long) over the blocks of arr[0..n); returns how many are left, in arr[0..) */
+static int fuse_array(struct mafAli **arr, int n)
+{
+    unsigned char *yes;
+    struct mafAli *a;
+    int i, out = 0, grown = 0;
+    if (n < 2) return n;
+    yes = (unsigned char *)mz_xmalloc((size_t)n);
+#pragma omp parallel for schedule(static, 512) num_threads(MZ_STAGE_THREADS)
+    for (i = 0; i < n - 1; ++i) yes[i] = (unsigned char)continues(arr[i], arr[i + 1]);
+    a = arr[0];
+    for (i = 1; i < n; ++i) {                               /* a: arr[i - 1] as it was asked about, or a block that has grown by fusions */
+        struct mafAli *b = arr[i];
+        if (grown ? continues(a, b) : yes[i - 1]) {
+            append_block(a, b);
+            mafAliFree(&b);
+            grown = 1;
+        } else { arr[out++] = a; a = b; grown = 0; }
+    }
+    arr[out++] = a;
+    free(yes);
+    return out;
+}
+
+static struct mafAli *project_long(pitem *it, int n, const char *target, struct mafAli **others, mz_blocks *res)
+{
+    struct mafAli *out = NULL, *out_tail = NULL, *oth_tail = NULL;
+    int *S, *S2, ns = 0, i, ncontig = 0, clash = 0;
+    struct { unsigned hash; int rep; } *tab;
+    int tabcap = 1024;
+    if (others) *others = NULL;
+    pthread_once(&g_compl_once, compl_fill);
+#pragma omp parallel for schedule(static, 256) num_threads(MZ_STAGE_THREADS)
+    for (i = 0; i < n; ++i) {
+        struct mafAli *a = it[i].a;
+        struct mafComp *c, *b;
+        a->next = NULL;
+        for (c = a->components; c; c = c->next)
+            if (strcmp(c->name, target) == 0 || strcmp(c->src, target) == 0) break;
+        it[i].src = NULL;
+        if (!c) continue;
+        if (c != a->components) {                        /* the target's row to the top */
+            for (b = a->components; b && b->next != c; b = b->next)
+                ;
+            if (!b) mz_fatalf("maf_project: cannot happen");
+            b->next = c->next;
+            c->next = a->components;
+            a->components = c;
+        }
+        if (c->strand == '-') block_revcomp(a);
+        it[i].src = c->src; it[i].hash = str_hash(c->src); it[i].start = c->start;
+    }
+    /* the blocks without a row of the target, in file order; the others numbered back to front, as the stock tool collects them */
+    S = (int *)mz_xmalloc(((size_t)n + 1) * sizeof(int)); S2 = (int *)mz_xmalloc(((size_t)n + 1) * sizeof(int));
+    if (others) {
+        for (i = 0; i < n; ++i)
+            if (!it[i].src) { if (oth_tail) oth_tail->next = it[i].a; else *others = it[i].a; oth_tail = it[i].a; }
+    } else {                                                /* (a quarter of a guide-tree level's blocks: the unused parts of blocks that lost their reference row) */
+#pragma omp parallel for schedule(dynamic, 256) num_threads(MZ_STAGE_THREADS)
+        for (i = 0; i < n; ++i) if (!it[i].src) mafAliFree(&it[i].a);
+    }
+    for (i = n - 1; i >= 0; --i) if (it[i].src) S[ns++] = i;
+    /* contigs by number: equal hashes are taken for equal names, then every block's name is compared with its contig's first -- on all
+     * threads; a clash (two names, one hash) is settled by comparing names in the table itself */
+    tab = mz_xmalloc((size_t)tabcap * sizeof *tab);
+    for (i = 0; i < ns; ++i) {
+        pitem *p = &it[S[i]];
+        int k;
+        for (k = 0; k < ncontig && tab[k].hash != p->hash; ++k)
+            ;
+        if (k == ncontig) {
+            if (ncontig == tabcap) { tabcap *= 2; tab = realloc(tab, (size_t)tabcap * sizeof *tab); if (!tab) mz_fatalf("out of memory"); }
+            tab[k].hash = p->hash; tab[k].rep = S[i]; ++ncontig;
+        }
+        p->contig = k;
+    }
+#pragma omp parallel for schedule(static, 1024) num_threads(MZ_STAGE_THREADS) reduction(| : clash)
+    for (i = 0; i < ns; ++i) {
+        const pitem *p = &it[S[i]];
+        if (p->src != it[tab[p->contig].rep].src && strcmp(p->src, it[tab[p->contig].rep].src) != 0) clash |= 1;
+    }
+    if (clash) {
+        ncontig = 0;
+        for (i = 0; i < ns; ++i) {
+            pitem *p = &it[S[i]];
+            int k;
+            for (k = 0; k < ncontig && !(tab[k].hash == p->hash && strcmp(it[tab[k].rep].src, p->src) == 0); ++k)
+                ;
+            if (k == ncontig) {
+                if (ncontig == tabcap) { tabcap *= 2; tab = realloc(tab, (size_t)tabcap * sizeof *tab); if (!tab) mz_fatalf("out of memory"); }
+                tab[k].hash = p->hash; tab[k].rep = S[i]; ++ncontig;
+            }
+            p->contig = k;
+        }
+    }
+    free(tab);
+    init_scores70();
+    while (ns > 0) {                                        /* one reference contig at a time: the head's; the rest goes on in reverse */
+        const int chr = it[S[0]].contig;
+        struct mafAli **blocks;
+        keyed *arr;
+        int m = 0, rest = 0;
+        for (i = 0; i < ns; ++i) if (it[S[i]].contig == chr) ++m;
+        arr = (keyed *)mz_xmalloc((size_t)m * sizeof *arr);
+        for (i = 0, m = 0, rest = ns; i < ns; ++i) {
+            if (it[S[i]].contig == chr) { arr[m].start = it[S[i]].start; arr[m].a = it[S[i]].a; ++m; }
+            else S2[--rest] = S[i];
+        }
+        qsort(arr, (size_t)m, sizeof *arr, by_top_start);        /* the same library sort on the same order: ties fall alike */
+        blocks = (struct mafAli **)mz_xmalloc((size_t)m * sizeof *blocks);
+        for (i = 0; i < m; ++i) blocks[i] = arr[i].a;
+        free(arr);
+        m = fuse_array(blocks, m);
+        m = fuse_array(blocks, m);                          /* (the stock tool's second pass, maf_project.c:690-695) */
+#pragma omp parallel for schedule(static, 1024) num_threads(MZ_STAGE_THREADS) if (m > 4096)
+        for (i = 0; i < m; ++i) blocks[i]->next = i + 1 < m ? blocks[i + 1] : NULL;
+        if (out_tail) out_tail->next = blocks[0]; else out = blocks[0];
+        out_tail = blocks[m - 1];
+        if (res && !res->p) { res->p = blocks; res->n = res->cap = m; }        /* the result's index: the first contig's array, the others' behind it */
+        else { if (res) for (i = 0; i < m; ++i) mz_blocks_push(res, blocks[i]); free(blocks); }
+        { const int left = ns - rest; int k; for (k = 0; k < left; ++k) S[k] = S2[rest + k]; ns = left; }
+    }
+    free(S); free(S2);
+    return out;
+}
+
+struct mafAli *mz_project_lists(struct mafAli *all, const char *target, struct mafAli **others)
+{
+    return mzi_project_blocks(all, NULL, target, others);
+}
+
+struct mafAli *mzi_project_blocks(struct mafAli *all, mz_blocks *idx, const char *target, struct mafAli **others)
+{
+    const char *e = getenv("MZ_FUSE_PARALLEL_MIN");         /* (tests: the long form on short lists) */
+    const int long_min = e && atoi(e) > 1 ? atoi(e) : FUSE_PARALLEL_MIN;
+    struct mafAli *a, *res;
+    pitem *it;
+    int n = 0, cap = long_min, i;
+    if (idx && idx->p) n = idx->n;
+    else for (a = all; a && n < long_min; a = a->next) ++n;
+    if (n < long_min) { mz_blocks_drop(idx); return project_plain(all, target, others); }
+    if (idx && idx->p) {                                    /* the blocks are known: nothing to walk */
+        it = (pitem *)mz_xmalloc((size_t)n * sizeof *it);
+        for (i = 0; i < n; ++i) it[i].a = idx->p[i];
+        mz_blocks_drop(idx);
+    } else {
+        it = (pitem *)mz_xmalloc((size_t)cap * sizeof *it);
+        for (a = all, n = 0; a; a = a->next) {
+            if (n == cap) { cap *= 2; it = (pitem *)realloc(it, (size_t)cap * sizeof *it); if (!it) mz_fatalf("out of memory"); }
+            it[n++].a = a;
+        }
+    }
+    res = project_long(it, n, target, others, idx);
+    free(it);
+    return res;
 }

@@ -28,6 +28,9 @@
  */
 #include "mz_drivers.h"
 #include <ctype.h>
+#include <omp.h>
+#include <unistd.h>
+#include <sys/resource.h>
 
 #define ROAST_VERSION 3
 #define MAX_NODES 2000
@@ -40,10 +43,12 @@ typedef struct rnode {
     char **names; int nnames;    /* leaf species below this node, in the stock driver's order */
     buf mz;                      /* the node's result: the file <prefix>MZ<id> of the stock driver -- as text ... */
     struct mafAli *mzl;          /* ... or (mz_list) as the list of its blocks */
+    mz_blocks mzi;               /* ... and, where known, the blocks of that list (mz_drivers.h) */
     int mz_list;
     int taint;                   /* a leaf file below has a line the stock chain's line filters would remove: text all the way up */
     int as_lists;                /* this node's multiz run ends in lists */
     struct mafAli *left_l, *right_l;       /* inputs that came as lists (left_is_l / right_is_l) */
+    mz_blocks left_i, right_i, i1, i2;     /* the blocks of left_l / right_l, of l1 / l2 (where known) */
     int left_is_l, right_is_l;
     int done;
     /* a multiz step in flight */
@@ -96,6 +101,24 @@ static void append_lines_without(buf *dst, const buf *src, const char *word)
     }
 }
 
+/* grep -v <word> of a text, straight into a file (the destination of a guide-tree run is hundreds of megabytes: searched for the
+ * word as a whole, written in the stretches between the lines that hold it, copied nowhere) */
+static void write_lines_without(FILE *f, const char *p, size_t n, const char *word)
+{
+    const size_t wl = strlen(word);
+    const char *end = p + n;
+    while (p < end) {
+        const char *hit = (const char *)memmem(p, (size_t)(end - p), word, wl), *ls, *le;
+        if (!hit) { fwrite(p, 1, (size_t)(end - p), f); return; }
+        ls = (const char *)memrchr(p, '\n', (size_t)(hit - p));
+        ls = ls ? ls + 1 : p;
+        le = (const char *)memchr(hit, '\n', (size_t)(end - hit));
+        le = le ? le + 1 : end;
+        if (ls > p) fwrite(p, 1, (size_t)(ls - p), f);
+        p = le;
+    }
+}
+
 static buf read_file(const char *path)
 {
     buf b = { NULL, 0, 0 };
@@ -110,12 +133,26 @@ static buf read_file(const char *path)
     return b;
 }
 
-static buf leaf_file(const char *species)
+/* The leaf files are read ahead, side by side, while the GPU starts up (leaves_ahead(): a file that cannot be opened is left for
+ * leaf_file() to fail on, at its place in the stock driver's order); each with the answer of leaf_taints(). */
+static struct { const char *species; buf b; int taint; } g_ahead[MAX_NODES];
+static int g_nahead;
+static int leaf_taints(const buf *b, const char *species);
+
+static buf leaf_file(const char *species, int *taint)
 {
     char path[1200];
+    int k;
     snprintf(path, sizeof path, "%s.%s%s", T.ref, species, T.suffix);
     if (T.verbose) printf("read %s\n", path);
-    { buf b; TIMED(0, b = read_file(path)); return b; }
+    for (k = 0; k < g_nahead; ++k)
+        if (g_ahead[k].b.p && strcmp(g_ahead[k].species, species) == 0) {
+            buf b = g_ahead[k].b;
+            memset(&g_ahead[k].b, 0, sizeof g_ahead[k].b);
+            *taint = g_ahead[k].taint;
+            return b;
+        }
+    { buf b; TIMED(0, b = read_file(path)); *taint = leaf_taints(&b, species); return b; }
 }
 
 static void free_list(struct mafAli *l) { while (l) { struct mafAli *a = mz_pop_first(&l); mafAliFree(&a); } }
@@ -143,10 +180,37 @@ static int leaf_taints(const buf *b, const char *species)
     return 0;
 }
 
-static void list_append(struct mafAli **head, struct mafAli *more)
+/* `more` (whose last block is more_tail) behind the list whose last block is *tail (NULL: the list is empty) */
+static void leaves_ahead(void)
 {
-    while (*head) head = &(*head)->next;
-    *head = more;
+    int i, k;
+    for (i = 0, g_nahead = 0; i < T.nn; ++i)
+        if (T.nd[i].id < 0 && strcmp(T.nd[i].names[0], T.ref) != 0) { g_ahead[g_nahead].species = T.nd[i].names[0]; memset(&g_ahead[g_nahead].b, 0, sizeof(buf)); ++g_nahead; }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (g_nahead > 1)
+    for (k = 0; k < g_nahead; ++k) {
+        char path[1200];
+        FILE *f;
+        long n;
+        buf b = { NULL, 0, 0 };
+        snprintf(path, sizeof path, "%s.%s%s", T.ref, g_ahead[k].species, T.suffix);
+        f = fopen(path, "r");
+        if (!f) continue;
+        if (fseek(f, 0, SEEK_END) == 0 && (n = ftell(f)) >= 0 && fseek(f, 0, SEEK_SET) == 0 && (b.p = (char *)malloc((size_t)n + 1)) != NULL) {
+            if (fread(b.p, 1, (size_t)n, f) == (size_t)n) {
+                b.p[n] = 0; b.n = (size_t)n; b.cap = (size_t)n + 1;
+                g_ahead[k].taint = leaf_taints(&b, g_ahead[k].species);
+                g_ahead[k].b = b;
+            } else free(b.p);
+        }
+        fclose(f);
+    }
+}
+
+static void list_append(struct mafAli **head, struct mafAli **tail, struct mafAli *more, struct mafAli *more_tail)
+{
+    if (!more) return;
+    if (*tail) (*tail)->next = more; else *head = more;
+    *tail = more_tail;
 }
 
 /* a list as the text of the file it stands for (a node that runs on text above one that ran on lists) */
@@ -164,33 +228,71 @@ static buf list_to_text(struct mafAli *list)
 }
 
 /* maf_project <file> REF <others> > out : header, projected blocks, trailer (reference maf_project.c:592-598,777) */
-static buf project_list_text(struct mafAli *list, const char *what, int last)
+/* (dst != NULL: the run's last projection -- `grep -v eof` of the text goes to dst, and nothing is returned) */
+static buf project_list_text(struct mafAli *list, mz_blocks *known, const char *what, FILE *dst)
 {
+    const int last = dst != NULL;
+    mz_blocks idx = { NULL, 0, 0 };
     buf out = { NULL, 0, 0 };
     struct mafAli *a, **blocks;
     char head[1400];
     int n = 0, i, pieces, k;
     buf *part;
-    { const double t_ = mz_now_s(); list = mz_project_lists(list, T.ref, NULL); g_t[1] += mz_now_s() - t_; }
+    if (known) { idx = *known; memset(known, 0, sizeof *known); }
+    { const double t_ = mz_now_s(); list = mzi_project_blocks(list, &idx, T.ref, NULL); g_t[1] += mz_now_s() - t_; }
     { const double t_ = mz_now_s();
     /* the blocks rendered in pieces side by side (the destination of a guide-tree run is hundreds of thousands of blocks) */
-    for (a = list; a; a = a->next) ++n;
-    blocks = (struct mafAli **)mz_xmalloc(((size_t)n + 1) * sizeof *blocks);
-    for (a = list, n = 0; a; a = a->next) blocks[n++] = a;
-    pieces = n < 4096 ? 1 : MZ_STAGE_THREADS;
-    part = (buf *)mz_xmalloc((size_t)pieces * sizeof *part);
-#pragma omp parallel for schedule(static, 1) num_threads(MZ_STAGE_THREADS) if (pieces > 1)
-    for (k = 0; k < pieces; ++k) {
-        const int lo = (int)((long long)n * k / pieces), hi = (int)((long long)n * (k + 1) / pieces);
-        FILE *m = open_memstream(&part[k].p, &part[k].n);
-        int j;
-        for (j = lo; j < hi; ++j) mafWrite(m, blocks[j]);
-        fclose(m);
+    if (idx.p) { blocks = idx.p; n = idx.n; }
+    else {
+        for (a = list; a; a = a->next) ++n;
+        blocks = (struct mafAli **)mz_xmalloc(((size_t)n + 1) * sizeof *blocks);
+        for (a = list, n = 0; a; a = a->next) blocks[n++] = a;
     }
+    pieces = n < 4096 ? 1 : dst ? 8 * MZ_STAGE_THREADS : MZ_STAGE_THREADS;
+    part = (buf *)mz_xmalloc((size_t)pieces * sizeof *part);
     snprintf(head, sizeof head, "##maf version=1 scoring=maf_project.v12\n# maf_project.v12 %s %s (in process)\n", what, T.ref);
-    buf_puts(&out, head);
-    for (k = 0; k < pieces; ++k) { buf_append(&out, part[k].p, part[k].n); free(part[k].p); }
-    buf_puts(&out, "##eof maf\n");
+    if (dst) {
+        /* the destination: many pieces, each written -- in order -- as soon as it is rendered, by the first thread of the team, while the
+         * others render the pieces behind it (a team of one renders everything first) */
+        int next = 0, written = 0, *ready = (int *)mz_xmalloc((size_t)pieces * sizeof(int));
+        memset(ready, 0, (size_t)pieces * sizeof(int));
+        write_lines_without(dst, head, strlen(head), "eof");
+#pragma omp parallel num_threads(MZ_STAGE_THREADS) if (pieces > 1)
+        {
+            if (omp_get_thread_num() == 0 && omp_get_num_threads() > 1) {
+                for (; written < pieces; ++written) {
+                    while (!__atomic_load_n(&ready[written], __ATOMIC_ACQUIRE)) usleep(50);
+                    write_lines_without(dst, part[written].p, part[written].n, "eof");
+                    free(part[written].p);
+                }
+            } else
+                for (;;) {
+                    const int kk = __atomic_fetch_add(&next, 1, __ATOMIC_RELAXED);
+                    int lo, hi, j;
+                    FILE *m;
+                    if (kk >= pieces) break;
+                    lo = (int)((long long)n * kk / pieces); hi = (int)((long long)n * (kk + 1) / pieces);
+                    m = open_memstream(&part[kk].p, &part[kk].n);
+                    for (j = lo; j < hi; ++j) mafWrite(m, blocks[j]);
+                    fclose(m);
+                    __atomic_store_n(&ready[kk], 1, __ATOMIC_RELEASE);
+                }
+        }
+        for (; written < pieces; ++written) { write_lines_without(dst, part[written].p, part[written].n, "eof"); free(part[written].p); }
+        free(ready);
+    } else {
+#pragma omp parallel for schedule(static, 1) num_threads(MZ_STAGE_THREADS) if (pieces > 1)
+        for (k = 0; k < pieces; ++k) {
+            const int lo = (int)((long long)n * k / pieces), hi = (int)((long long)n * (k + 1) / pieces);
+            FILE *m = open_memstream(&part[k].p, &part[k].n);
+            int j;
+            for (j = lo; j < hi; ++j) mafWrite(m, blocks[j]);
+            fclose(m);
+        }
+        buf_puts(&out, head);
+        for (k = 0; k < pieces; ++k) { buf_append(&out, part[k].p, part[k].n); free(part[k].p); }
+        buf_puts(&out, "##eof maf\n");
+    }
     free(part); free(blocks);
     if (!last) free_list(list);                          /* (the destination's blocks: the process ends with them -- 13 M frees of a guide-tree run) */
     g_t[5] += mz_now_s() - t_; }
@@ -202,7 +304,7 @@ static buf project_text(const buf *in, const char *what)
     struct mafAli *list;
     if (!in->p) mz_fatalf("Cannot open %s.", what);
     TIMED(2, list = mz_maf_read_mem(in->p, in->n, what));
-    return project_list_text(list, what, 0);
+    return project_list_text(list, NULL, what, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------------ the tree */
@@ -282,13 +384,15 @@ static void node_inputs(rnode *nd)
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
     buf left = { NULL, 0, 0 }, right = { NULL, 0, 0 };
     struct mafAli *left_l = NULL, *right_l = NULL;
+    mz_blocks left_i = { NULL, 0, 0 }, right_i = { NULL, 0, 0 };
     int left_is_l = 0, right_is_l = 0;
 
     /* mv MZ<i> left.maf<id>: the child's result, text or list */
-    if (x->id >= 0) { left = x->mz; left_l = x->mzl; left_is_l = x->mz_list; memset(&x->mz, 0, sizeof x->mz); x->mzl = NULL; x->mz_list = 0; }
-    if (y->id >= 0) { right = y->mz; right_l = y->mzl; right_is_l = y->mz_list; memset(&y->mz, 0, sizeof y->mz); y->mzl = NULL; y->mz_list = 0; }
+    if (x->id >= 0) { left = x->mz; left_l = x->mzl; left_i = x->mzi; left_is_l = x->mz_list; memset(&x->mz, 0, sizeof x->mz); memset(&x->mzi, 0, sizeof x->mzi); x->mzl = NULL; x->mz_list = 0; }
+    if (y->id >= 0) { right = y->mz; right_l = y->mzl; right_i = y->mzi; right_is_l = y->mz_list; memset(&y->mz, 0, sizeof y->mz); memset(&y->mzi, 0, sizeof y->mzi); y->mzl = NULL; y->mz_list = 0; }
     buf_free(&nd->mz);
-    nd->mzl = NULL; nd->mz_list = 0;
+    nd->mzl = NULL; nd->mz_list = 0; mz_blocks_drop(&nd->mzi);
+    memset(&nd->left_i, 0, sizeof nd->left_i); memset(&nd->right_i, 0, sizeof nd->right_i); memset(&nd->i1, 0, sizeof nd->i1); memset(&nd->i2, 0, sizeof nd->i2);
     nd->run = NULL; nd->l1 = nd->l2 = NULL; nd->both_leaves = 0; nd->as_lists = 0;
     nd->left_l = nd->right_l = NULL; nd->left_is_l = nd->right_is_l = 0;
     memset(&nd->left_in, 0, sizeof nd->left_in); memset(&nd->right_in, 0, sizeof nd->right_in);
@@ -300,14 +404,14 @@ static void node_inputs(rnode *nd)
         rnode *other = ref_left ? y : x;
         buf *ob = ref_left ? &right : &left;
         if (other->nnames == 1) {
-            buf f = leaf_file(other->names[0]);
+            buf f = leaf_file(other->names[0], &nd->taint);
             char head[64];
-            nd->taint = leaf_taints(&f, other->names[0]);
             snprintf(head, sizeof head, "##maf version=1 scoring=multiz.%d\n", ROAST_VERSION); buf_puts(&nd->mz, head);
             append_lines_without(&nd->mz, &f, "eof"); buf_free(&f);
         } else if (ref_left ? right_is_l : left_is_l) {
             nd->mzl = ref_left ? right_l : left_l; nd->mz_list = 1;       /* (grep -v eof finds the trailer only) */
-            if (ref_left) right_l = NULL; else left_l = NULL;
+            nd->mzi = ref_left ? right_i : left_i;
+            if (ref_left) { right_l = NULL; memset(&right_i, 0, sizeof right_i); } else { left_l = NULL; memset(&left_i, 0, sizeof left_i); }
             nd->taint = other->taint;
         } else {
             char head[64];
@@ -317,11 +421,12 @@ static void node_inputs(rnode *nd)
         }
         buf_free(&left); buf_free(&right);               /* rm -f: the closing greps of the parser find nothing */
         free_list(left_l); free_list(right_l);
+        mz_blocks_drop(&left_i); mz_blocks_drop(&right_i);
         nd->done = 1;
         return;
     }
-    if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0]); x->taint = leaf_taints(&left, x->names[0]); }
-    if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0]); y->taint = leaf_taints(&right, y->names[0]); }
+    if (x->nnames == 1) { buf_free(&left); left = leaf_file(x->names[0], &x->taint); }
+    if (y->nnames == 1) { buf_free(&right); right = leaf_file(y->names[0], &y->taint); }
     if (!left.p && !left_is_l) mz_fatalf("Cannot open %s.", "left.maf");
     if (!right.p && !right_is_l) mz_fatalf("Cannot open %s.", "right.maf");
     nd->taint = x->taint || y->taint;
@@ -329,9 +434,11 @@ static void node_inputs(rnode *nd)
     if (!nd->as_lists) {                                 /* a node on text takes text */
         if (left_is_l) { left = list_to_text(left_l); left_l = NULL; left_is_l = 0; }
         if (right_is_l) { right = list_to_text(right_l); right_l = NULL; right_is_l = 0; }
+        mz_blocks_drop(&left_i); mz_blocks_drop(&right_i);
     }
     nd->left_in = left; nd->right_in = right;
     nd->left_l = left_l; nd->right_l = right_l; nd->left_is_l = left_is_l; nd->right_is_l = right_is_l;
+    nd->left_i = left_i; nd->right_i = right_i;
 }
 
 /* maf_project left REF > U1; mv U1 left (and the same on the right), then the aligner reads both: the projected
@@ -341,11 +448,14 @@ static void node_parse(rnode *nd, int side)
 {
     buf *in = side ? &nd->right_in : &nd->left_in;
     struct mafAli *l;
+    mz_blocks idx = { NULL, 0, 0 };
     if (side ? nd->right_is_l : nd->left_is_l) {
-        l = mz_project_lists(side ? nd->right_l : nd->left_l, T.ref, NULL);
+        idx = side ? nd->right_i : nd->left_i;
+        memset(side ? &nd->right_i : &nd->left_i, 0, sizeof idx);
+        l = mzi_project_blocks(side ? nd->right_l : nd->left_l, &idx, T.ref, NULL);
         if (side) nd->right_l = NULL; else nd->left_l = NULL;
-    } else l = mz_project_lists(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), T.ref, NULL);
-    if (side) nd->l2 = l; else nd->l1 = l;
+    } else l = mzi_project_blocks(mz_maf_read_mem(in->p, in->n, side ? "right.maf" : "left.maf"), &idx, T.ref, NULL);
+    if (side) { nd->l2 = l; nd->i2 = idx; } else { nd->l1 = l; nd->i1 = idx; }
     buf_free(in);
 }
 
@@ -354,20 +464,21 @@ static void node_prepare(rnode *nd)
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
     const int l = has_ref(x), r = has_ref(y);
     if (!l && !r) nd->both_leaves = x->nnames == 1 && y->nnames == 1;
-    else if (r) { struct mafAli *t = nd->l1; nd->l1 = nd->l2; nd->l2 = t; }
+    else if (r) { struct mafAli *t = nd->l1; const mz_blocks ti = nd->i1; nd->l1 = nd->l2; nd->l2 = t; nd->i1 = nd->i2; nd->i2 = ti; }
     if (!T.use_multic) {
-        nd->run = mz_multiz_prepare(&nd->l1, &nd->l2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
+        nd->run = mzi_multiz_prepare_blocks(&nd->l1, &nd->l2, &nd->i1, &nd->i2, (l || r) ? 1 : 0, T.radius, T.minw, 1, 1);
         if (nd->as_lists) mz_multiz_keep_blocks(nd->run);
-    }
+    } else { mz_blocks_drop(&nd->i1); mz_blocks_drop(&nd->i2); }
 }
 
 /* the blocks of a list the stock driver would print (contigs only one side has), as their reader would hold them; the rest freed */
-static struct mafAli *printed_blocks(struct mafAli *l)
+static struct mafAli *printed_blocks(struct mafAli *l, struct mafAli **last, mz_blocks *idx)
 {
     struct mafAli *keep = NULL, **tail = &keep;
+    *last = NULL;
     while (l) {
         struct mafAli *a = mz_pop_first(&l);
-        if (row2 == 0 || a->components->next) { mz_ali_as_reread(a); *tail = a; tail = &a->next; }
+        if (row2 == 0 || a->components->next) { mz_ali_as_reread(a); *tail = a; tail = &a->next; *last = a; mz_blocks_push(idx, a); }
         else mafAliFree(&a);
     }
     return keep;
@@ -376,16 +487,22 @@ static struct mafAli *printed_blocks(struct mafAli *l)
 static void end_node_lists(rnode *nd)
 {
     rnode *x = &T.nd[nd->left], *y = &T.nd[nd->right];
-    struct mafAli *out = NULL, *u1 = NULL, *u2 = NULL;
-    mz_multiz_finish_lists(nd->run, &out, &u1, &u2);     /* stdout, U1, U2 of `multiz M=.. left right v U1 U2` */
+    struct mafAli *out = NULL, *u1 = NULL, *u2 = NULL, *tails[3], *p, *pt;
+    mz_blocks idx[3];
+    int k;
+    mzi_multiz_finish_tails(nd->run, &out, &u1, &u2, tails, idx);   /* stdout, U1, U2 of `multiz M=.. left right v U1 U2` */
     nd->run = NULL;
-    list_append(&u1, printed_blocks(nd->l1));            /* contigs only one side has */
-    list_append(&u2, printed_blocks(nd->l2));
+    p = printed_blocks(nd->l1, &pt, &idx[1]); list_append(&u1, &tails[1], p, pt);      /* contigs only one side has */
+    p = printed_blocks(nd->l2, &pt, &idx[2]); list_append(&u2, &tails[2], p, pt);
     nd->l1 = nd->l2 = NULL;
     if (nd->both_leaves || x->id >= 0 || y->id >= 0) {   /* >> MZ<id>: the unused parts follow (the line filters find nothing in them) */
-        list_append(&out, u1);
-        list_append(&out, u2);
+        list_append(&out, &tails[0], u1, tails[1]);
+        list_append(&out, &tails[0], u2, tails[2]);
+        for (k = 0; k < idx[1].n; ++k) mz_blocks_push(&idx[0], idx[1].p[k]);
+        for (k = 0; k < idx[2].n; ++k) mz_blocks_push(&idx[0], idx[2].p[k]);
     } else { free_list(u1); free_list(u2); }
+    mz_blocks_drop(&idx[1]); mz_blocks_drop(&idx[2]);
+    nd->mzi = idx[0];
     nd->mzl = out; nd->mz_list = 1;
     nd->done = 1;
 }
@@ -411,6 +528,7 @@ static void end_node(rnode *nd)
     for (a = nd->l1; a; a = a->next) if (row2 == 0 || a->components->next) mafWrite(m1, a);   /* contigs only one side has */
     for (a = nd->l2; a; a = a->next) if (row2 == 0 || a->components->next) mafWrite(m2, a);
     free_list(nd->l1); free_list(nd->l2); nd->l1 = nd->l2 = NULL;
+    mz_blocks_drop(&nd->i1); mz_blocks_drop(&nd->i2);
     fprintf(mo, "##eof maf\n");
     fclose(mo); fclose(m1); fclose(m2);
 
@@ -447,7 +565,7 @@ int mz_roast_main(int argc, char **argv)
     char *cmdline;
     size_t na = 64;
     int i, root, rounds = 0, batches = 0;
-    double t0 = mz_now_s();
+    double t0 = mz_now_s(), r_t[8];
     FILE *dst;
 
     snprintf(cmd, sizeof cmd, "roast.v%d", ROAST_VERSION);
@@ -507,6 +625,7 @@ int mz_roast_main(int argc, char **argv)
         return 0;
     }
 
+    TIMED(0, leaves_ahead());
     /* rounds: every node whose children are finished is begun; the multiz runs of the round share their GPU
      * batches; then the nodes are finished in the stock driver's order */
     for (;;) {
@@ -517,15 +636,19 @@ int mz_roast_main(int argc, char **argv)
             if (nd->id >= 0 && !nd->done && T.nd[nd->left].done && T.nd[nd->right].done) ready[nready++] = i;
         }
         if (nready == 0) break;
+        memcpy(r_t, g_t, sizeof r_t);
         {
             int todo[MAX_NODES], ntodo = 0, k;
-            for (i = 0; i < nready; ++i) {
-                node_inputs(&T.nd[ready[i]]);
-                if (!T.nd[ready[i]].done) todo[ntodo++] = ready[i];
-            }
+            { const double t_ = mz_now_s();
+              for (i = 0; i < nready; ++i) {
+                  node_inputs(&T.nd[ready[i]]);
+                  if (!T.nd[ready[i]].done) todo[ntodo++] = ready[i];
+              }
+              g_t[7] += mz_now_s() - t_; }
             /* the round's inputs parsed and projected, a task per node and side; then the list walks, a task per node */
             { const double t_ = mz_now_s();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 0)
+              /* (a round of few nodes: one list after the other -- a long list's projection runs on all threads by itself, mz_project.c) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(MZ_STAGE_THREADS) if (ntodo > 4)
               for (k = 0; k < 2 * ntodo; ++k) node_parse(&T.nd[todo[k >> 1]], k & 1);
               g_t[2] += mz_now_s() - t_; }
             { const double t_ = mz_now_s();
@@ -550,6 +673,9 @@ int mz_roast_main(int argc, char **argv)
               for (i = 0; i < nready; ++i) end_node(&T.nd[ready[i]]);
           }
           g_t[5] += mz_now_s() - t_; }
+        if (mzi_timing())
+            fprintf(stderr, "mz_roast: round %d, %d nodes: inputs taken over %.3f s (leaves read %.3f), parsed + projected %.3f, list walks %.3f, alignment batch %.3f, replay + rendering %.3f\n",
+                    rounds + 1, nready, g_t[7] - r_t[7], g_t[0] - r_t[0], g_t[2] - r_t[2], g_t[3] - r_t[3], g_t[4] - r_t[4], g_t[5] - r_t[5]);
         ++rounds;
     }
     if (T.nd[root].id < 0) mz_fatalf("tree specification is improper");
@@ -557,14 +683,20 @@ int mz_roast_main(int argc, char **argv)
     dst = fopen(destination, "w");
     if (!dst) mz_fatalf("Cannot open %s.", destination);
     fprintf(dst, "##maf version=1 scoring=%s.%d\n%s\n", cmd, ROAST_VERSION, cmdline);
-    {
-        buf fin = T.nd[root].mz_list ? project_list_text(T.nd[root].mzl, "MZ", 1) : project_text(&T.nd[root].mz, "MZ"), body = { NULL, 0, 0 };
-        append_lines_without(&body, &fin, "eof");
-        if (body.n) fwrite(body.p, 1, body.n, dst);
-        buf_free(&fin); buf_free(&body);
+    if (T.nd[root].mz_list) project_list_text(T.nd[root].mzl, &T.nd[root].mzi, "MZ", dst);
+    else {
+        buf fin = project_text(&T.nd[root].mz, "MZ");
+        write_lines_without(dst, fin.p, fin.n, "eof");
+        buf_free(&fin);
     }
     fprintf(dst, "##eof maf\n");
     fclose(dst);
+    if (mzi_timing()) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "mz_roast: CPU time %.2f s in the program + %.2f s in the kernel (%ld page faults), %ld MB at most\n",
+                ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec, ru.ru_minflt, ru.ru_maxrss >> 10);
+    }
     if (mzi_timing())
         fprintf(stderr, "mz_roast: %d internal nodes in %d rounds, %d shared alignment batches, %.3f s (reading leaves %.3f, final projection %.3f, parsing + projecting the inputs %.3f, "
                 "list walks %.3f, waiting for the GPU's start-up %.3f, alignment batches with their host stages %.3f, replay + rendering + line filters %.3f)\n",
