@@ -6,6 +6,8 @@
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 int main(int argc, char **argv)
 {
@@ -14,7 +16,17 @@ int main(int argc, char **argv)
     void (*warm_wait)(void);
     int rc;
     setenv("OMP_WAIT_POLICY", "passive", 0);
-    lib = dlopen("libmzamd.so", RTLD_NOW | RTLD_GLOBAL);   /* (found beside the program: its run path is $ORIGIN) */
+    {   /* the library beside the program (by its path: a dlopen() that an interposed one makes -- a sanitizer's -- does not see the run path) */
+        char path[4096 + 16];
+        ssize_t n = readlink("/proc/self/exe", path, 4096);
+        lib = NULL;
+        if (n > 0) {
+            while (n > 0 && path[n - 1] != '/') --n;
+            strcpy(path + n, "libmzamd.so");
+            lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!lib) lib = dlopen("libmzamd.so", RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!lib) { fprintf(stderr, "mz_roast: %s\n", dlerror()); return 1; }
     *(void **)&run = dlsym(lib, "mz_roast_main");
     *(void **)&warm_wait = dlsym(lib, "mz_warm_wait");
