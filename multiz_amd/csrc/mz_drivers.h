@@ -29,6 +29,9 @@ extern char *argv0;
 __attribute__((visibility("hidden"))) int mzi_timing(void);
 static inline double mz_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
+/* mz_maf.c: rows in one allocation */
+__attribute__((visibility("hidden"))) struct mafComp *mzi_row_new(const struct mafComp *t, long text_len);
+__attribute__((visibility("hidden"))) void mzi_row_free_field(struct mafComp *c, void *p);
 /* mz_mafio.c */
 struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE *echo);
 struct mafAli *mz_maf_read_mem(const char *text, size_t len, const char *name);

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
 #include "../../include/maf.h"
 #include "../../include/mz_scores.h"
 
@@ -44,11 +45,50 @@ struct mafComp *mafCpyComp(struct mafComp *t)
     return c;
 }
 
+/* ROWS IN ONE ALLOCATION.  The drivers of this library (mz_multiz.c, mz_roast.c ...) make and drop rows by the ten million, and a row
+ * of the reference's making is five allocations: the struct, src, name, contig and the text.  Rows the drivers make for themselves
+ * (mzi_row_new) are ONE: the struct with the three names and, where its length is known, the text behind it -- marked by mafPosMap
+ * pointing at the row itself (no position map can live there).  mafCompFree() knows the mark; code that replaces a field of a row
+ * asks mzi_row_free_field() to free the old value, which does nothing for a value that lives inside the row's allocation.  Rows that
+ * leave the library through the drop-in boundary (pre_yama()'s result: mz_preyama.c) are made the reference's way, by mafCpyComp():
+ * the caller frees them with its own mafAliFree(). */
+static int row_inside(const struct mafComp *c, const void *p)
+{
+    return c->mafPosMap == (const int *)c && (const char *)p >= (const char *)(c + 1) &&
+           (const char *)p < (const char *)c + malloc_usable_size((void *)c);
+}
+__attribute__((visibility("hidden"))) void mzi_row_free_field(struct mafComp *c, void *p)
+{
+    if (p && !row_inside(c, p)) free(p);
+}
+/* a fresh row with the bookkeeping fields and names of t; text_len >= 0: room for that much text (and its 0) behind the names,
+ * text pointing at it; < 0: no text yet (the caller sets one of its own, freed with the row) */
+__attribute__((visibility("hidden"))) struct mafComp *mzi_row_new(const struct mafComp *t, long text_len)
+{
+    const size_t ns = t->src ? strlen(t->src) + 1 : 0, nn = t->name ? strlen(t->name) + 1 : 0, nc = t->contig ? strlen(t->contig) + 1 : 0;
+    struct mafComp *c = (struct mafComp *)xmalloc(sizeof *c + ns + nn + nc + (text_len >= 0 ? (size_t)text_len + 1 : 0));
+    char *p = (char *)(c + 1);
+    memset(c, 0, sizeof *c);
+    if (t->src) { c->src = (char *)memcpy(p, t->src, ns); p += ns; }
+    if (t->name) { c->name = (char *)memcpy(p, t->name, nn); p += nn; }
+    if (t->contig) { c->contig = (char *)memcpy(p, t->contig, nc); p += nc; }
+    if (text_len >= 0) { c->text = p; p[text_len] = 0; }
+    c->srcSize = t->srcSize;
+    c->start = t->start;
+    c->size = t->size;
+    c->strand = t->strand;
+    c->paralog = t->paralog;
+    c->mafPosMap = (int *)c;
+    return c;
+}
+
 void mafCompFree(struct mafComp **pc)
 {
     struct mafComp *c = *pc;
     if (!c) return;
-    free(c->src); free(c->text); free(c->contig); free(c->name); free(c->mafPosMap);
+    if (c->mafPosMap == (int *)c) {
+        mzi_row_free_field(c, c->src); mzi_row_free_field(c, c->text); mzi_row_free_field(c, c->contig); mzi_row_free_field(c, c->name);
+    } else { free(c->src); free(c->text); free(c->contig); free(c->name); free(c->mafPosMap); }
     free(c);
     *pc = NULL;
 }

@@ -22,7 +22,7 @@ void mz_tune_malloc(void)
 
 /* ------------------------------------------------------------------------------------------------ MAF reader */
 
-typedef struct { FILE *fp; const char *name; int line_nbr, verbose; char *line; size_t cap; FILE *echo; } maf_in;
+typedef struct { FILE *fp; const char *name; int line_nbr, verbose; char *line; size_t cap; FILE *echo; char *tmp; size_t tmpcap; } maf_in;
 
 /* one line, newline kept; -1 at end of file */
 static long in_line(maf_in *in)
@@ -100,17 +100,27 @@ static struct mafAli *maf_next(maf_in *in)
     a = (struct mafAli *)mz_xmalloc(sizeof *a);
     memset(a, 0, sizeof *a);
     while ((len = in_maf_line(in)) != -1 && in->line[0] != '\n' && in->line[0] != ' ' && in->line[0] != '#') {
-        char *src, *text;
+        char *src, *text, *name;
+        const char *dot;
+        struct mafComp t;
+        size_t ns;
         if (in->line[0] != 's') continue;                  /* i / e / q lines are ignored */
-        c = (struct mafComp *)mz_xmalloc(sizeof *c);
-        memset(c, 0, sizeof *c);
-        src = (char *)mz_xmalloc((size_t)len + 1);
-        text = (char *)mz_xmalloc((size_t)len + 1);
-        if (sscanf(in->line, "s %s %d %d %c %d %s", src, &c->start, &c->size, &c->strand, &c->srcSize, text) != 6)
+        if (in->tmpcap < 3 * ((size_t)len + 1)) {           /* the fields of a line, parsed into the reader's own room: the row is ONE allocation (mz_maf.c) */
+            in->tmpcap = 3 * ((size_t)len + 1) + 256;
+            free(in->tmp);
+            in->tmp = (char *)mz_xmalloc(in->tmpcap);
+        }
+        src = in->tmp; text = src + len + 1; name = text + len + 1;
+        memset(&t, 0, sizeof t);
+        if (sscanf(in->line, "s %s %d %d %c %d %s", src, &t.start, &t.size, &t.strand, &t.srcSize, text) != 6)
             mz_fatalf("bad component in file %s, line %d:\n%s", in->name, in->line_nbr, src);
-        c->src = mz_xstrdup(src); free(src);
-        c->text = text;
-        split_src(c);
+        dot = strchr(src, '.');                             /* species and contig parts of "species.contig" (split_src) */
+        ns = dot ? (size_t)(dot - src) : strlen(src);
+        memcpy(name, src, ns); name[ns] = 0;
+        t.src = src; t.name = name; t.contig = (char *)((dot && dot[1]) ? dot + 1 : src);
+        t.paralog = 's';
+        c = mzi_row_new(&t, (long)strlen(text));
+        strcpy(c->text, text);
         c->paralog = 's';
         if (!a->components) { a->textSize = (int)strlen(c->text); a->components = c; }
         else {
@@ -153,7 +163,7 @@ struct mafAli *mz_maf_read_stream(FILE *fp, const char *name, int verbose, FILE 
         if (last) last->next = a; else first = a;
         last = a;
     }
-    free(in.line);
+    free(in.line); free(in.tmp);
     return first;
 }
 
@@ -203,10 +213,10 @@ void mz_ali_as_reread(struct mafAli *a)
         }
         if (changed || !c->name || !c->contig) {                                 /* (otherwise name and contig are this src's already: they are
                                                                                   * copied with it from rows the reader split) */
-            free(c->name); free(c->contig);
+            mzi_row_free_field(c, c->name); mzi_row_free_field(c, c->contig);
             split_src(c);
         }
-        if (c->mafPosMap) { free(c->mafPosMap); c->mafPosMap = NULL; }
+        if (c->mafPosMap && c->mafPosMap != (int *)c) { free(c->mafPosMap); c->mafPosMap = NULL; }
         c->nameID = 0;
     }
 }
@@ -219,9 +229,8 @@ struct mafAli *mz_ali_copy(const struct mafAli *a)
     memset(d, 0, sizeof *d);
     d->score = a->score; d->textSize = a->textSize;
     for (c = a->components; c; c = c->next) {
-        struct mafComp *nc = mafCpyComp(c);
-        nc->text = (char *)mz_xmalloc((size_t)a->textSize + 1);
-        memcpy(nc->text, c->text, (size_t)a->textSize); nc->text[a->textSize] = 0;
+        struct mafComp *nc = mzi_row_new(c, a->textSize);
+        memcpy(nc->text, c->text, (size_t)a->textSize);
         if (tail) tail->next = nc; else d->components = nc;
         tail = nc;
     }

@@ -16,10 +16,16 @@
  * (multiz.c:180-294).  The MAF reader and the list helpers are in mz_mafio.c, the multic driver in mz_multic.c.
  */
 #include "mz_drivers.h"
+#include <pthread.h>
 
-/* The walk goes on cutting the blocks it holds, so every pending merge keeps private copies of its two blocks
- * until the replay.  They are never resized or freed one by one: they come from a bump arena that is released as
- * a whole (thirty malloc/free pairs per merge otherwise -- a sixth of a 20 000-block run). */
+/* The walk goes on cutting the blocks it holds, so every pending merge and every recorded piece of output keeps the two blocks AS
+ * THEY STAND at that moment -- the rows they have, each row's start, size and text.  Nothing is copied for that but the bookkeeping:
+ * cutting a block (keep_from) only moves its rows' text pointers forward, a row that runs out of bases is unlinked, not freed, and a
+ * block the walk is through with is retired into the record (record.dead / dead_rows) instead of freed -- so the snapshots, which
+ * come from a bump arena and share names and text with the originals, stay good until the merges are through (run_merges() frees
+ * the retired blocks of all its records on all threads; a record that never gets there frees them when it goes).  (A level of a
+ * guide tree is half a million merges of up to thirty rows: copying every row's names and text per snapshot, allocating every cut
+ * row anew and freeing both inside the walk was most of the walk.) */
 typedef struct arena_chunk { struct arena_chunk *next; size_t used, cap; } arena_chunk;
 /* one arena per record (a run's list walk): the tree driver walks the lists of sibling nodes on several threads */
 static void *arena_alloc(arena_chunk **arena, size_t n)
@@ -36,17 +42,12 @@ static void *arena_alloc(arena_chunk **arena, size_t n)
     (*arena)->used += n;
     return p;
 }
-static char *arena_strdup(arena_chunk **arena, const char *s)
-{
-    const size_t n = strlen(s) + 1;
-    return (char *)memcpy(arena_alloc(arena, n), s, n);
-}
 static void arena_release(arena_chunk **arena)
 {
     while (*arena) { arena_chunk *c = *arena; *arena = c->next; free(c); }
 }
 
-static struct mafAli *clone_ali(arena_chunk **arena, const struct mafAli *a)      /* arena-owned: never passed to mafAliFree() */
+static struct mafAli *clone_ali(arena_chunk **arena, const struct mafAli *a)      /* arena-owned: never passed to mafAliFree(); names and text are the original's */
 {
     struct mafAli *b = (struct mafAli *)arena_alloc(arena, sizeof *b);
     struct mafComp *c, *tail = NULL;
@@ -56,42 +57,11 @@ static struct mafAli *clone_ali(arena_chunk **arena, const struct mafAli *a)    
         struct mafComp *d = (struct mafComp *)arena_alloc(arena, sizeof *d);
         *d = *c;
         d->next = NULL; d->mafPosMap = NULL;
-        d->src = arena_strdup(arena, c->src); d->name = arena_strdup(arena, c->name); d->contig = arena_strdup(arena, c->contig);
-        d->text = arena_strdup(arena, c->text);
         if (tail) tail->next = d; else b->components = d;
         tail = d;
     }
     return b;
 }
-
-/* cut the block down to what starts at reference position beg; rows left with no base go
- * (reference multi_util.c:468-509) */
-static struct mafAli *keep_from(struct mafAli *a, int beg)
-{
-    const int len = (int)strlen(a->components->text);
-    struct mafComp **pp, *c;
-    int col, i, n;
-
-    col = mafPos2Col(a->components, beg, a->textSize);
-    while (col > 0 && a->components->text[col - 1] == '-') --col;
-    for (pp = &a->components; (c = *pp) != NULL; ) {
-        char *s;
-        for (n = i = 0; i < col; ++i) n += c->text[i] != '-';
-        if (c->size - n < 1) { *pp = c->next; mafCompFree(&c); continue; }
-        c->start += n;
-        c->size -= n;
-        s = (char *)mz_xmalloc((size_t)(len - col) + 2);
-        memcpy(s, c->text + col, (size_t)(len - col));
-        s[len - col] = 0;
-        free(c->text);
-        c->text = s;
-        pp = &c->next;
-    }
-    a->textSize = len - col;
-    a->score = mafScoreRange(a, 0, len - col);
-    return a;
-}
-
 
 /* ------------------------------------------------------------------------------------------------ the record */
 
@@ -119,8 +89,127 @@ typedef struct {
     merge *mg; int nmg, capmg;
     int has1, has2;           /* out1 / out2 sinks exist */
     int keep_blocks;          /* the run ends in mz_multiz_finish_lists(): blocks are kept as blocks, nothing is rendered */
-    arena_chunk *arena;       /* the private block copies of this run's events and merges */
+    arena_chunk *arena;       /* the snapshots of this run's events and merges */
+    mz_blocks dead;           /* blocks the walk is through with (their rows' text pointers back at the start of their allocations) */
+    struct mafComp *dead_rows;/* rows cut off such blocks */
 } record;
+
+/* cut the block down to what starts at reference position beg; rows left with no base go
+ * (reference multi_util.c:468-509).  *off: the columns cut off this block so far (every row's text pointer stands that far into
+ * its allocation) */
+static struct mafAli *keep_from(record *R, struct mafAli *a, int beg, int *off)
+{
+    const int len = (int)strlen(a->components->text);
+    struct mafComp **pp, *c;
+    int col, i, n;
+
+    col = mafPos2Col(a->components, beg, a->textSize);
+    while (col > 0 && a->components->text[col - 1] == '-') --col;
+    for (pp = &a->components; (c = *pp) != NULL; ) {
+        for (n = i = 0; i < col; ++i) n += c->text[i] != '-';
+        if (c->size - n < 1) { *pp = c->next; c->text -= *off; c->next = R->dead_rows; R->dead_rows = c; continue; }
+        c->start += n;
+        c->size -= n;
+        c->text += col;
+        pp = &c->next;
+    }
+    *off += col;
+    a->textSize = len - col;
+    a->score = mafScoreRange(a, 0, len - col);
+    return a;
+}
+static void retire(record *R, struct mafAli *a, int off)
+{
+    struct mafComp *c;
+    if (off) for (c = a->components; c; c = c->next) c->text -= off;
+    mz_blocks_push(&R->dead, a);
+}
+/* The retired blocks go in the BACKGROUND: one thread frees them, a record's lot after the other, while the run goes on (the next
+ * round's parsing, the replay, the destination's rendering).  Freed on all threads at once they cost more than they did inside the walk
+ * -- neighbours in a list come from the same thread's heap, and threads that free into one heap at the same time queue for its lock
+ * (8 s of kernel time in a 2.5 s run); freed by the caller they are a second of one thread that everybody waits for.  Nobody waits for
+ * the reaper to get through: when the program ends (atexit) it is told to stop after the block in hand and the exit goes on once it
+ * has -- whatever is left goes with the process.  MZ_REAPER=0: freed on the spot, by the caller. */
+typedef struct reap { struct reap *next; struct mafAli **blocks; int n; struct mafComp *rows; } reap;
+static pthread_mutex_t g_reap_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_reap_cv = PTHREAD_COND_INITIALIZER;
+static pthread_cond_t g_reap_parked_cv = PTHREAD_COND_INITIALIZER;
+static reap *g_reap_head, *g_reap_tail;
+static int g_reap_started, g_reap_quit, g_reap_parked;
+
+static void reap_now(struct mafAli **blocks, int n, struct mafComp *rows)
+{
+    int i;
+    for (i = 0; i < n; ++i) mafAliFree(&blocks[i]);
+    free(blocks);
+    while (rows) { struct mafComp *c = rows; rows = c->next; mafCompFree(&c); }
+}
+static void reaper_park(void)                               /* (the mutex held) for good: the program is ending */
+{
+    g_reap_parked = 1;
+    pthread_cond_broadcast(&g_reap_parked_cv);
+    for (;;) pthread_cond_wait(&g_reap_cv, &g_reap_mu);
+}
+static void *reaper(void *arg)
+{
+    (void)arg;
+    for (;;) {
+        reap *j;
+        int i;
+        pthread_mutex_lock(&g_reap_mu);
+        while (!g_reap_head && !g_reap_quit) pthread_cond_wait(&g_reap_cv, &g_reap_mu);
+        if (g_reap_quit) reaper_park();
+        j = g_reap_head; g_reap_head = j->next;
+        if (!g_reap_head) g_reap_tail = NULL;
+        pthread_mutex_unlock(&g_reap_mu);
+        for (i = 0; i < j->n; ++i) {
+            if (__atomic_load_n(&g_reap_quit, __ATOMIC_RELAXED)) { pthread_mutex_lock(&g_reap_mu); reaper_park(); }
+            mafAliFree(&j->blocks[i]);
+        }
+        reap_now(NULL, 0, j->rows);
+        free(j->blocks);
+        free(j);
+    }
+    return NULL;
+}
+static void reaper_stop(void)                               /* atexit: nothing of this library runs beside the exit handlers that follow */
+{
+    pthread_mutex_lock(&g_reap_mu);
+    __atomic_store_n(&g_reap_quit, 1, __ATOMIC_RELAXED);
+    pthread_cond_broadcast(&g_reap_cv);
+    while (!g_reap_parked) pthread_cond_wait(&g_reap_parked_cv, &g_reap_mu);
+    pthread_mutex_unlock(&g_reap_mu);
+}
+static void free_retired(record *R)
+{
+    const char *e = getenv("MZ_REAPER");
+    reap *j;
+    if (!R->dead.n && !R->dead_rows) { mz_blocks_drop(&R->dead); return; }
+    if (e && atoi(e) == 0) { reap_now(R->dead.p, R->dead.n, R->dead_rows); memset(&R->dead, 0, sizeof R->dead); R->dead_rows = NULL; return; }
+    j = (reap *)mz_xmalloc(sizeof *j);
+    j->next = NULL; j->blocks = R->dead.p; j->n = R->dead.n; j->rows = R->dead_rows;
+    memset(&R->dead, 0, sizeof R->dead); R->dead_rows = NULL;
+    pthread_mutex_lock(&g_reap_mu);
+    if (!g_reap_started) {
+        pthread_t t;
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&t, &at, reaper, NULL) != 0) {    /* no thread to be had: on the spot */
+            pthread_attr_destroy(&at);
+            pthread_mutex_unlock(&g_reap_mu);
+            reap_now(j->blocks, j->n, j->rows); free(j);
+            return;
+        }
+        pthread_attr_destroy(&at);
+        g_reap_started = 1;
+        atexit(reaper_stop);
+    }
+    if (g_reap_tail) g_reap_tail->next = j; else g_reap_head = j;
+    g_reap_tail = j;
+    pthread_cond_signal(&g_reap_cv);
+    pthread_mutex_unlock(&g_reap_mu);
+}
 
 static event *new_event(record *R, int sink)
 {
@@ -192,6 +281,7 @@ static void rec_merge(record *R, struct mafAli *a1, struct mafAli *a2, int beg, 
 static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int radius, int minw)
 {
     struct mafAli *a1 = mz_pop_first(wk1), *a2 = mz_pop_first(wk2);
+    int off1 = 0, off2 = 0;                                 /* columns cut off a1 / a2 so far (keep_from) */
 #define BEG(a) ((a)->components->start)
 #define END(a) ((a)->components->start + (a)->components->size - 1)
 #define WANTED(a) ((a)->components->size >= minw && (row2 == 0 || (a)->components->next != NULL))
@@ -199,13 +289,13 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
         int beg1, end1, beg2, end2, beg, end, cb, ce;
         while (a1 && (!a2 || END(a1) < BEG(a2))) {         /* nothing of file 2 under a1 */
             if (R->has1 && WANTED(a1)) rec_block(R, SINK_1, a1);
-            mafAliFree(&a1);
-            a1 = mz_pop_first(wk1);
+            retire(R, a1, off1);
+            a1 = mz_pop_first(wk1); off1 = 0;
         }
         while (a2 && (!a1 || END(a2) < BEG(a1))) {
             if (R->has2 && WANTED(a2)) rec_block(R, SINK_2, a2);
-            mafAliFree(&a2);
-            a2 = mz_pop_first(wk2);
+            retire(R, a2, off2);
+            a2 = mz_pop_first(wk2); off2 = 0;
         }
         if (!a1 && !a2) break;
         if (!a1 || !a2 || END(a1) < BEG(a2) || END(a2) < BEG(a1)) continue;
@@ -237,19 +327,19 @@ static void walk(record *R, struct mafAli **wk1, struct mafAli **wk2, int v, int
         }
         rec_merge(R, a1, a2, beg, end, radius, v);
 
-        if (end1 < end2) a2 = keep_from(a2, end1 + 1);
-        if (end2 < end1) a1 = keep_from(a1, end2 + 1);
+        if (end1 < end2) a2 = keep_from(R, a2, end1 + 1, &off2);
+        if (end2 < end1) a1 = keep_from(R, a1, end2 + 1, &off1);
         if (end1 <= end2) {
             ce = mafPos2Col(a1->components, end1, a1->textSize);
             if (ce < a1->textSize - 1 && R->has1) rec_part(R, SINK_1, a1, ce + 1, a1->textSize - 1);
-            mafAliFree(&a1);
-            a1 = mz_pop_first(wk1);
+            retire(R, a1, off1);
+            a1 = mz_pop_first(wk1); off1 = 0;
         }
         if (end2 <= end1) {
             ce = mafPos2Col(a2->components, end2, a2->textSize);
             if (ce < a2->textSize - 1 && R->has2) rec_part(R, SINK_2, a2, ce + 1, a2->textSize - 1);
-            mafAliFree(&a2);
-            a2 = mz_pop_first(wk2);
+            retire(R, a2, off2);
+            a2 = mz_pop_first(wk2); off2 = 0;
         }
     }
 #undef BEG
@@ -331,6 +421,18 @@ static int walk_pieces(record *R, struct mafAli **arr1, const int *b1, const int
     for (k = 0; k < npieces; ++k) {
         record *P = &piece[k];
         if (P->arena) { arena_chunk *t = P->arena; while (t->next) t = t->next; t->next = R->arena; R->arena = P->arena; }
+        if (P->dead_rows) { struct mafComp *t = P->dead_rows; while (t->next) t = t->next; t->next = R->dead_rows; R->dead_rows = P->dead_rows; }
+    }
+    {   /* the pieces' retired blocks, behind one another */
+        int total = R->dead.n, at;
+        for (k = 0; k < npieces; ++k) total += piece[k].dead.n;
+        if (total > R->dead.cap) { R->dead.cap = total; R->dead.p = (struct mafAli **)realloc(R->dead.p, (size_t)total * sizeof *R->dead.p); if (!R->dead.p) mz_fatalf("out of memory"); }
+        for (k = 0, at = R->dead.n; k < npieces; ++k) {
+            if (piece[k].dead.n) memcpy(R->dead.p + at, piece[k].dead.p, (size_t)piece[k].dead.n * sizeof *R->dead.p);
+            at += piece[k].dead.n;
+            mz_blocks_drop(&piece[k].dead);
+        }
+        R->dead.n = total;
     }
     free(piece); free(cut1); free(cut2); free(ev0); free(mg0);
     return 1;
@@ -427,12 +529,10 @@ static struct mafAli *block_from_rows(const mz_preout *o, struct mafAli *a1, int
         }
         if (o->size[i] == 0) continue;
         for (start = src->start, j = 0; j < skip; ++j) start += src->text[j] != '-';
-        nc = mafCpyComp(src);
+        nc = mzi_row_new(src, o->OM);
         nc->start = start;
         nc->size = o->size[i];
-        nc->text = (char *)mz_xmalloc((size_t)o->OM + 1);
         memcpy(nc->text, o->rows + (size_t)i * (size_t)o->OM, (size_t)o->OM);
-        nc->text[o->OM] = 0;
         if (tail) tail->next = nc; else blk->components = nc;
         tail = nc;
     }
@@ -625,6 +725,9 @@ static void run_merges(record **RR, int nrec, int minw)
     for (i = 0; i < nheld; ++i) free(held[i]);
     free(held);
     free(jobs); free(outs); free(who); free(all);
+    /* nothing looks at the snapshots' names and text any more (what is left to replay are results and rendered text): the blocks
+     * the walks retired go, those of all records side by side */
+    for (r = 0; r < nrec; ++r) free_retired(RR[r]);
 }
 
 static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
@@ -648,6 +751,7 @@ static void replay(record *R, FILE *out, FILE *f1, FILE *f2, int minw)
         }
     }
     free(R->ev); free(R->mg);
+    free_retired(R);
     arena_release(&R->arena);
     memset(R, 0, sizeof *R);
 }
@@ -699,6 +803,7 @@ static void replay_lists(record *R, struct mafAli **out, struct mafAli **f1, str
         }
     }
     free(R->ev); free(R->mg);
+    free_retired(R);
     arena_release(&R->arena);
     memset(R, 0, sizeof *R);
     *out = L[SINK_OUT].head;

@@ -133,7 +133,7 @@ static void append_block(struct mafAli *a, struct mafAli *b)
             memcpy(t + n1, d->text, (size_t)n2);
             c->size += d->size;
         } else memset(t + n1, '-', (size_t)n2);
-        free(c->text);
+        mzi_row_free_field(c, c->text);
         c->text = t;
     }
     for (d = b->components; d; d = d->next)              /* rows only b has: dashes on the left, collected in reverse */

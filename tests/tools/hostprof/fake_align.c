@@ -11,6 +11,10 @@
 #include <time.h>
 
 char *argv0 = (char *)"roast_prof";
+int mz_roast_main(int argc, char **argv);
+int mz_multiz_main(int argc, char **argv);
+/* HOSTPROF_MAIN=multiz: the multiz command line instead of the tree driver's */
+int main(int argc, char **argv) { const char *e = getenv("HOSTPROF_MAIN"); return e && strcmp(e, "multiz") == 0 ? mz_multiz_main(argc, argv) : mz_roast_main(argc, argv); }
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 void mz_fatalf(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); exit(1); }
 void mz_fatal_status(const void *job, const void *out) { (void)job; (void)out; mz_fatalf("fake aligner: a refused job"); }
