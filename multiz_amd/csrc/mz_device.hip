@@ -58,16 +58,10 @@
 #endif
 // ... and take no more than the 32 VGPRs five row-parallel DP waves leave of a SIMD's 512 (no LDS either: those take all 160 KB of a CU), so
 // that a helper wave is placed at once instead of waiting for a DP wave to retire and then taking the place of the next one
-// (amdgpu_num_vgpr counts ARCHITECTURAL registers and the backend doubles it on the unified register file of gfx90a and later: 16 is a
-//  budget of 32; what does not fit goes to scratch -- 10-45 spilled registers in k_plan / k_scan3 / k_rowprep, kernels of microseconds)
 #ifndef MZ_HELPER_VGPRS
-#define MZ_HELPER_VGPRS 16
+#define MZ_HELPER_VGPRS 32
 #endif
-#if MZ_HELPER_VGPRS
-#define HELPER_VGPRS __attribute__((amdgpu_num_vgpr(MZ_HELPER_VGPRS)))
-#else
 #define HELPER_VGPRS
-#endif
 #define HELPER_PRIO() do { if (MZ_HELPER_PRIO) __builtin_amdgcn_s_setprio(MZ_HELPER_PRIO); } while (0)
 // ... when their batch asks for it (MZ_DP_HELPERS_FIRST, include/mz_amd.h: the chunk pipelines do; a device-resident pipeline's helpers have a whole DP's time and
 // cost it 1.5-3 % at the raised priority: C2 571 against 579 GCUPS, C4 501 / 517, c4i 399 / 408, same box, alternating)
