@@ -37,6 +37,10 @@ python tests/tools/timeline.py $O/tl_c5 host c5 > $O/${TAG}_timeline_host_c5.txt
 python tests/tools/roast_bench.py > $O/${TAG}_roast_bench.txt 2>&1
 # the guide-tree-scale run of the tree driver (30 leaves, ~1.9 M merges): per-batch JSON lines and phase times
 timeout 900 python tests/tools/roast_big.py 30 9000 600 > $O/${TAG}_roast30.txt 2>&1
+# ... and what its main thread does, every 250 us of wall time (tests/tools/hostprof: the sampler preloaded beside the library)
+gcc -O2 -g -shared -fPIC tests/tools/hostprof/sampler.c -o /tmp/libsampler.so -ldl -lpthread && python tests/tools/hostprof/make_inputs.py /tmp/rin 30 9000 > /tmp/tree.txt && (cd /tmp/rin && \
+  MZ_SAMPLER_WALL=250 MZ_SAMPLER_MATCH=libmzamd MZ_SAMPLER_OUT=/tmp/sampler.out LD_PRELOAD=/tmp/libsampler.so MZ_TIMING=1 $GRAFT_REPO_ROOT/multiz_amd/mz_roast E=ref "$(cat /tmp/tree.txt)" ref.*.sing.maf out.maf 2>&1 | grep "mz_roast" ) > $O/${TAG}_roast_host_profile.txt 2>&1
+python tests/tools/hostprof/report.py multiz_amd/libmzamd.so /tmp/sampler.out 45 >> $O/${TAG}_roast_host_profile.txt 2>&1
 python - "$O" "$TAG" <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], sys.argv[2] + "_bench_*.json"))):
