@@ -22,8 +22,9 @@
  * THEY STAND at that moment -- the rows they have, each row's start, size and text.  Nothing is copied for that but the bookkeeping:
  * cutting a block (keep_from) only moves its rows' text pointers forward, a row that runs out of bases is unlinked, not freed, and a
  * block the walk is through with is retired into the record (record.dead / dead_rows) instead of freed -- so the snapshots, which
- * come from a bump arena and share names and text with the originals, stay good until the merges are through (run_merges() frees
- * the retired blocks of all its records on all threads; a record that never gets there frees them when it goes).  (A level of a
+ * come from a bump arena and share names and text with the originals, stay good until the merges are through (run_merges() hands
+ * the retired blocks of all its records to the thread that frees them, free_retired(); a record that never gets there does when it
+ * goes).  (A level of a
  * guide tree is half a million merges of up to thirty rows: copying every row's names and text per snapshot, allocating every cut
  * row anew and freeing both inside the walk was most of the walk.) */
 typedef struct arena_chunk { struct arena_chunk *next; size_t used, cap; } arena_chunk;
